@@ -1,0 +1,56 @@
+"""ctypes binding of the C ABI declared in include/igs_rast.h (libigs_rast.so, gfx950).
+
+There is NO CPU fallback: if the HIP library cannot be built or loaded this module raises.
+"""
+import ctypes as C
+import os
+
+from . import build as _build
+
+_LIB = None
+
+ALLOC_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_size_t)
+_vp, _i, _f = C.c_void_p, C.c_int, C.c_float
+
+EXPORTS = ["igs_rast_version", "igs_rast_last_error", "igs_rast_forward", "igs_rast_backward_workspace_bytes",
+           "igs_rast_backward", "igs_rast_mark_visible", "igs_rast_debug_dump",
+           "igs_adam_step", "igs_l1_loss_fwd_bwd"]
+
+
+def lib():
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    try:
+        path = _build.build()
+    except Exception as e:  # noqa: BLE001
+        if os.path.exists(_build.LIB):
+            path = _build.LIB          # stale but present (e.g. no hipcc on this box): use what travelled
+        else:
+            raise RuntimeError("igs_amd: the HIP extension libigs_rast.so is missing and could not be built: %s" % e)
+    L = C.CDLL(path)
+    L.igs_rast_version.restype = _i
+    L.igs_rast_last_error.restype = C.c_char_p
+    L.igs_rast_forward.restype = _i
+    L.igs_rast_forward.argtypes = ([_vp, ALLOC_FN, _vp, ALLOC_FN, _vp, ALLOC_FN, _vp, _i, _i, _i, _vp, _i, _i]
+                                   + [_vp] * 5 + [_f, _vp, _vp, _vp, _vp, _vp, _f, _f, _f, _i] + [_vp] * 8 + [_i, _i, _i])
+    L.igs_rast_backward_workspace_bytes.restype = C.c_size_t
+    L.igs_rast_backward_workspace_bytes.argtypes = [_i]
+    L.igs_rast_backward.restype = _i
+    L.igs_rast_backward.argtypes = ([_vp, _i, _i, _i, _i, _vp, _i, _i] + [_vp] * 5 + [_f, _vp, _vp, _vp, _vp, _vp, _f, _f, _f]
+                                    + [_vp] * 5 + [_vp] * 7 + [_vp] + [_vp] * 8 + [_i, _i, _i])
+    L.igs_rast_mark_visible.restype = _i
+    L.igs_rast_mark_visible.argtypes = [_vp, _i, _vp, _vp, _vp, _vp]
+    L.igs_rast_debug_dump.restype = _i
+    L.igs_rast_debug_dump.argtypes = [_vp, _i, _i, _i, _i] + [_vp] * 8
+    if hasattr(L, "igs_adam_step"):
+        L.igs_adam_step.restype = _i
+        L.igs_adam_step.argtypes = [_vp, C.c_size_t, _vp, _vp, _vp, _vp, _f, _f, _f, _f, _f, _f]
+        L.igs_l1_loss_fwd_bwd.restype = _i
+        L.igs_l1_loss_fwd_bwd.argtypes = [_vp, C.c_size_t, _vp, _vp, _vp, _vp, _f]
+    _LIB = L
+    return L
+
+
+def last_error():
+    return lib().igs_rast_last_error().decode("utf-8", "replace")

@@ -1,0 +1,253 @@
+// api.hip -- C-ABI entry points (include/igs_rast.h) and host-side orchestration on a HIP stream.
+// Counterpart of CudaRasterizer::Rasterizer::{forward,backward,markVisible}
+// (DGR/cuda_rasterizer/rasterizer_impl.cu:176-188, 254-425, 429-571).
+#include "common.h"
+#include "../../include/igs_rast.h"
+#include <stdio.h>
+#include <string.h>
+
+static thread_local char g_err[512] = "";
+static int fail(int code, const char* what, hipError_t e = hipSuccess)
+{
+    if (e != hipSuccess) snprintf(g_err, sizeof g_err, "%s: %s", what, hipGetErrorString(e));
+    else snprintf(g_err, sizeof g_err, "%s", what);
+    return code;
+}
+#define HIP_TRY(expr, what) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return fail(IGS_RAST_E_HIP, what, e_); } while (0)
+#define DBG_SYNC(what) do { if (debug) { hipError_t e_ = hipStreamSynchronize(s); if (e_ != hipSuccess) return fail(IGS_RAST_E_HIP, what, e_); } } while (0)
+
+// pinned 4-byte read-back slot + event, one per host thread and device
+struct HostSlot { int device = -1; uint32_t* pinned = nullptr; hipEvent_t ev = nullptr; };
+static thread_local HostSlot g_slot;
+static int ensure_slot()
+{
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev), "hipGetDevice");
+    if (g_slot.device == dev && g_slot.pinned) return 0;
+    if (g_slot.pinned) { (void)hipHostFree(g_slot.pinned); (void)hipEventDestroy(g_slot.ev); g_slot = HostSlot(); }
+    HIP_TRY(hipHostMalloc((void**)&g_slot.pinned, 64, hipHostMallocDefault), "hipHostMalloc");
+    HIP_TRY(hipEventCreateWithFlags(&g_slot.ev, hipEventDisableTiming), "hipEventCreate");
+    g_slot.device = dev;
+    return 0;
+}
+
+static int ceil_log2(uint32_t n) { int b = 0; while ((1u << b) < n) b++; return b; }
+
+extern "C" int igs_rast_version(void) { return IGS_RAST_VERSION; }
+extern "C" const char* igs_rast_last_error(void) { return g_err; }
+extern "C" size_t igs_rast_backward_workspace_bytes(int P) { return (size_t)(P > 0 ? P : 0) * GACC_F * 4 + 512; }
+
+extern "C" int igs_rast_forward(
+    void* stream,
+    igs_rast_alloc_fn geometry_buffer, void* geometry_user, igs_rast_alloc_fn binning_buffer, void* binning_user,
+    igs_rast_alloc_fn image_buffer, void* image_user,
+    int P, int D, int M, const float* background, int width, int height,
+    const float* means3D, const float* shs, const float* colors_precomp, const float* opacities,
+    const float* scales, float scale_modifier, const float* rotations, const float* cov3D_precomp,
+    const float* viewmatrix, const float* projmatrix, const float* cam_pos,
+    float tan_fovx, float tan_fovy, float kernel_size, int prefiltered,
+    float* out_color, float* out_coord, float* out_mcoord, float* out_depth, float* out_mdepth, float* out_alpha,
+    float* out_normal, int* radii, int require_coord, int require_depth, int debug)
+{
+    hipStream_t s = (hipStream_t)stream;
+    if (P < 0 || width <= 0 || height <= 0) return fail(IGS_RAST_E_INVALID, "igs_rast_forward: bad sizes");
+    if (P == 0) return 0;                                       // rasterize_points.cu:90: nothing is launched
+    if (!geometry_buffer || !binning_buffer || !image_buffer) return fail(IGS_RAST_E_INVALID, "igs_rast_forward: NULL scratch callback");
+    if (!means3D || !opacities || !viewmatrix || !projmatrix || !cam_pos || !background || !radii)
+        return fail(IGS_RAST_E_INVALID, "igs_rast_forward: NULL required input");
+    if (!out_color || !out_coord || !out_mcoord || !out_depth || !out_mdepth || !out_alpha || !out_normal)
+        return fail(IGS_RAST_E_INVALID, "igs_rast_forward: NULL output");
+    if (!colors_precomp && !shs) return fail(IGS_RAST_E_INVALID, "igs_rast_forward: neither shs nor colors_precomp");
+    if (!cov3D_precomp && (!scales || !rotations)) return fail(IGS_RAST_E_INVALID, "igs_rast_forward: neither scales/rotations nor cov3D_precomp");
+    if (!colors_precomp && (M < (D + 1) * (D + 1) || D < 0 || D > 3)) return fail(IGS_RAST_E_INVALID, "igs_rast_forward: SH degree / coefficient count mismatch");
+    if (int rc = ensure_slot()) return rc;
+
+    const int gx = (width + TILE - 1) / TILE, gy = (height + TILE - 1) / TILE;
+    const size_t Tn = (size_t)gx * gy, HW = (size_t)width * height;
+
+    const GeomLayout GL(P);
+    char* gbase = geometry_buffer(geometry_user, GL.total);
+    if (!gbase) return fail(IGS_RAST_E_ALLOC, "geometry buffer callback returned NULL");
+    gbase = align_ptr(gbase);
+    const ImgLayout IL(HW, Tn);
+    char* ibase = image_buffer(image_user, IL.total);
+    if (!ibase) return fail(IGS_RAST_E_ALLOC, "image buffer callback returned NULL");
+    ibase = align_ptr(ibase);
+
+    float* rec = (float*)(gbase + GL.rec);
+    uint32_t* tiles = (uint32_t*)(gbase + GL.tiles);
+    uint32_t* keys_a = (uint32_t*)(gbase + GL.keys_a); uint32_t* keys_b = (uint32_t*)(gbase + GL.keys_b);
+    uint32_t* vals_a = (uint32_t*)(gbase + GL.vals_a); uint32_t* vals_b = (uint32_t*)(gbase + GL.vals_b);
+    uint32_t* ghist = (uint32_t*)(gbase + GL.hist);
+    uint32_t* blocksum = (uint32_t*)(gbase + GL.blocksum);
+    uint32_t* counters = (uint32_t*)(gbase + GL.counters);
+
+    FwdParams fp;
+    fp.P = P; fp.D = D; fp.M = M; fp.W = width; fp.H = height; fp.gx = gx; fp.gy = gy;
+    fp.means3D = means3D; fp.shs = shs; fp.colors_precomp = colors_precomp; fp.opacities = opacities;
+    fp.scales = scales; fp.rotations = rotations; fp.cov3D_precomp = cov3D_precomp;
+    fp.scale_modifier = scale_modifier; fp.tan_fovx = tan_fovx; fp.tan_fovy = tan_fovy;
+    fp.fy = height / (2.0f * tan_fovy); fp.fx = width / (2.0f * tan_fovx);       // rasterizer_impl.cu:288-289
+    fp.kernel_size = kernel_size; fp.prefiltered = prefiltered;
+    fp.view = viewmatrix; fp.proj = projmatrix; fp.campos = cam_pos;
+
+    HIP_TRY(hipMemsetAsync(counters, 0, 16, s), "memset counters");
+    HIP_TRY(launch_preprocess_fwd(s, fp, rec, tiles, keys_a, vals_a, radii, counters), "preprocess_fwd launch");
+    DBG_SYNC("preprocess_fwd");
+    // instance count: read back while the depth sort runs
+    HIP_TRY(hipMemcpyAsync(g_slot.pinned, counters, 8, hipMemcpyDeviceToHost, s), "memcpy count");
+    HIP_TRY(hipEventRecord(g_slot.ev, s), "event record");
+
+    uint32_t *dk = nullptr, *order = nullptr;
+    HIP_TRY(radix_sort_pairs(s, (uint32_t)P, keys_a, keys_b, vals_a, vals_b, ghist, 0, 32, &dk, &order), "depth sort launch");
+    DBG_SYNC("depth sort");
+    const int nblk = (P + 255) / 256;
+    HIP_TRY(launch_count_sorted(s, P, order, tiles, blocksum), "count_sorted launch");
+    HIP_TRY(launch_scan_blocksums(s, nblk, blocksum), "scan_blocksums launch");
+    DBG_SYNC("scan");
+
+    HIP_TRY(hipEventSynchronize(g_slot.ev), "event sync");
+    const uint32_t R = g_slot.pinned[0];
+    if (g_slot.pinned[1]) return fail(IGS_RAST_E_PREFILTER, "Point is filtered although prefiltered is set. This shouldn't happen!");
+    if (R > 0x7FFFFFFFu) return fail(IGS_RAST_E_INVALID, "instance count overflows int");
+
+    const BinLayout BL(R);
+    char* bbase = binning_buffer(binning_user, BL.total);
+    if (!bbase) return fail(IGS_RAST_E_ALLOC, "binning buffer callback returned NULL");
+    bbase = align_ptr(bbase);
+    uint32_t* point_list = (uint32_t*)(bbase + BL.point_list);
+    uint32_t* bkeys_a = (uint32_t*)(bbase + BL.keys_a); uint32_t* bkeys_b = (uint32_t*)(bbase + BL.keys_b);
+    uint32_t* bvals_b = (uint32_t*)(bbase + BL.vals_b);
+    uint32_t* bhist = (uint32_t*)(bbase + BL.hist);
+
+    uint32_t* ranges = (uint32_t*)(ibase + IL.ranges);
+    HIP_TRY(hipMemsetAsync(ranges, 0, Tn * 8, s), "memset ranges");               // rasterizer_impl.cu:383
+    if (R > 0) {
+        const int bits = ceil_log2((uint32_t)Tn);
+        const int passes = (bits + 7) / 8;
+        // arrange the ping-pong so that the sorted ids land in point_list
+        uint32_t *ka, *kb, *va, *vb;
+        if (passes % 2 == 0) { ka = bkeys_a; va = point_list; kb = bkeys_b; vb = bvals_b; }
+        else                 { ka = bkeys_b; va = bvals_b;   kb = bkeys_a; vb = point_list; }
+        HIP_TRY(launch_emit_instances(s, P, gx, gy, order, tiles, blocksum, rec, radii, ka, va), "emit launch");
+        DBG_SYNC("emit");
+        uint32_t *sk = nullptr, *sv = nullptr;
+        HIP_TRY(radix_sort_pairs(s, R, ka, kb, va, vb, bhist, 0, bits, &sk, &sv), "tile sort launch");
+        DBG_SYNC("tile sort");
+        if (sv != point_list) return fail(IGS_RAST_E_INVALID, "internal: sort ping-pong mismatch");
+        HIP_TRY(launch_tile_ranges(s, R, sk, ranges), "tile_ranges launch");
+        DBG_SYNC("tile_ranges");
+    }
+
+    BlendFwdArgs ba;
+    ba.W = width; ba.H = height; ba.gx = gx; ba.gy = gy; ba.fx = fp.fx; ba.fy = fp.fy; ba.bg = background;
+    ba.ranges = ranges; ba.point_list = point_list; ba.rec = rec; ba.colors_precomp = colors_precomp;
+    ba.out_color = out_color; ba.out_coord = out_coord; ba.out_mcoord = out_mcoord; ba.out_depth = out_depth;
+    ba.out_mdepth = out_mdepth; ba.out_alpha = out_alpha; ba.out_normal = out_normal;
+    ba.n_contrib = (uint32_t*)(ibase + IL.n_contrib);
+    ba.accum_coord = (float*)(ibase + IL.accum_coord); ba.accum_depth = (float*)(ibase + IL.accum_depth);
+    ba.normal_length = (float*)(ibase + IL.normal_length);
+    HIP_TRY(launch_blend_fwd(s, ba, require_coord != 0, require_depth != 0), "blend_fwd launch");
+    DBG_SYNC("blend_fwd");
+    return (int)R;
+}
+
+extern "C" int igs_rast_backward(
+    void* stream, int P, int D, int M, int R, const float* background, int width, int height,
+    const float* means3D, const float* shs, const float* colors_precomp, const float* alphas,
+    const float* scales, float scale_modifier, const float* rotations, const float* cov3D_precomp,
+    const float* viewmatrix, const float* projmatrix, const float* campos,
+    float tan_fovx, float tan_fovy, float kernel_size, const int* radii, const float* normalmap,
+    const char* geom_buffer, const char* binning_buffer, const char* image_buffer,
+    const float* dL_dpix, const float* dL_dpix_coord, const float* dL_dpix_mcoord, const float* dL_dpix_depth,
+    const float* dL_dpix_mdepth, const float* dL_dalphas, const float* dL_dpixel_normals,
+    void* workspace,
+    float* dL_dmean2D, float* dL_dcolor, float* dL_dopacity, float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh,
+    float* dL_dscale, float* dL_drot, int require_coord, int require_depth, int debug)
+{
+    hipStream_t s = (hipStream_t)stream;
+    if (P < 0 || R < 0 || width <= 0 || height <= 0) return fail(IGS_RAST_E_INVALID, "igs_rast_backward: bad sizes");
+    if (P == 0) return 0;                                       // rasterize_points.cu:195
+    if (!geom_buffer || !image_buffer || (!binning_buffer && R > 0) || !workspace)
+        return fail(IGS_RAST_E_INVALID, "igs_rast_backward: NULL scratch buffer");
+    if (!means3D || !alphas || !viewmatrix || !projmatrix || !campos || !background || !radii || !normalmap)
+        return fail(IGS_RAST_E_INVALID, "igs_rast_backward: NULL required input");
+    if (!dL_dpix || !dL_dpix_coord || !dL_dpix_mcoord || !dL_dpix_depth || !dL_dpix_mdepth || !dL_dalphas || !dL_dpixel_normals)
+        return fail(IGS_RAST_E_INVALID, "igs_rast_backward: NULL upstream gradient");
+    if (!dL_dmean2D || !dL_dcolor || !dL_dopacity || !dL_dmean3D || !dL_dcov3D || !dL_dscale || !dL_drot || (M > 0 && !dL_dsh))
+        return fail(IGS_RAST_E_INVALID, "igs_rast_backward: NULL output");
+
+    const int gx = (width + TILE - 1) / TILE, gy = (height + TILE - 1) / TILE;
+    const size_t Tn = (size_t)gx * gy, HW = (size_t)width * height;
+    const GeomLayout GL(P);
+    const ImgLayout IL(HW, Tn);
+    const BinLayout BL(R);
+    const char* gbase = align_ptr(geom_buffer);
+    const char* ibase = align_ptr(image_buffer);
+    const char* bbase = binning_buffer ? align_ptr(binning_buffer) : nullptr;
+    float* gacc = (float*)align_ptr((const char*)workspace);
+    const float fy = height / (2.0f * tan_fovy), fx = width / (2.0f * tan_fovx);
+
+    HIP_TRY(hipMemsetAsync(gacc, 0, (size_t)P * GACC_F * 4, s), "memset gacc");
+    BlendBwdArgs ba;
+    ba.W = width; ba.H = height; ba.gx = gx; ba.gy = gy; ba.fx = fx; ba.fy = fy; ba.bg = background;
+    ba.ranges = (const uint32_t*)(ibase + IL.ranges);
+    ba.point_list = bbase ? (const uint32_t*)(bbase + BL.point_list) : nullptr;
+    ba.rec = (const float*)(gbase + GL.rec); ba.colors_precomp = colors_precomp;
+    ba.alphas = alphas; ba.normalmap = normalmap;
+    ba.accum_coord = (const float*)(ibase + IL.accum_coord); ba.accum_depth = (const float*)(ibase + IL.accum_depth);
+    ba.normal_length = (const float*)(ibase + IL.normal_length); ba.n_contrib = (const uint32_t*)(ibase + IL.n_contrib);
+    ba.dL_dpix = dL_dpix; ba.dL_dcoord = dL_dpix_coord; ba.dL_dmcoord = dL_dpix_mcoord; ba.dL_ddepth = dL_dpix_depth;
+    ba.dL_dmdepth = dL_dpix_mdepth; ba.dL_dalpha = dL_dalphas; ba.dL_dnormal = dL_dpixel_normals;
+    ba.gacc = gacc;
+    if (R > 0) {
+        HIP_TRY(launch_blend_bwd(s, ba, require_coord != 0, require_depth != 0), "blend_bwd launch");
+        DBG_SYNC("blend_bwd");
+    }
+    GeomBwdArgs ga;
+    ga.P = P; ga.D = D; ga.M = shs ? M : 0; ga.W = width; ga.H = height;
+    ga.means3D = means3D; ga.shs = shs; ga.scales = scales; ga.rotations = rotations; ga.cov3D_precomp = cov3D_precomp;
+    ga.radii = radii; ga.scale_modifier = scale_modifier; ga.tan_fovx = tan_fovx; ga.tan_fovy = tan_fovy;
+    ga.fx = fx; ga.fy = fy; ga.kernel_size = kernel_size;
+    ga.view = viewmatrix; ga.proj = projmatrix; ga.campos = campos;
+    ga.rec = ba.rec; ga.gacc = gacc;
+    ga.dL_dmean2D = dL_dmean2D; ga.dL_dcolor = dL_dcolor; ga.dL_dopacity = dL_dopacity; ga.dL_dmean3D = dL_dmean3D;
+    ga.dL_dcov3D = dL_dcov3D; ga.dL_dsh = dL_dsh; ga.dL_dscale = dL_dscale; ga.dL_drot = dL_drot;
+    HIP_TRY(launch_geom_bwd(s, ga), "geom_bwd launch");
+    DBG_SYNC("geom_bwd");
+    return 0;
+}
+
+extern "C" int igs_rast_mark_visible(void* stream, int P, const float* means3D, const float* viewmatrix,
+                                     const float* projmatrix, uint8_t* present)
+{
+    (void)projmatrix;
+    if (P < 0) return fail(IGS_RAST_E_INVALID, "igs_rast_mark_visible: bad size");
+    if (P == 0) return 0;
+    if (!means3D || !viewmatrix || !present) return fail(IGS_RAST_E_INVALID, "igs_rast_mark_visible: NULL pointer");
+    HIP_TRY(launch_mark_visible((hipStream_t)stream, P, means3D, viewmatrix, present), "mark_visible launch");
+    return 0;
+}
+
+extern "C" int igs_rast_debug_dump(void* stream, int P, int R, int width, int height, const char* geom_buffer,
+                                   const char* binning_buffer, const char* image_buffer, float* rec32, uint32_t* tiles,
+                                   uint32_t* point_list, uint32_t* ranges, uint32_t* n_contrib)
+{
+    hipStream_t s = (hipStream_t)stream;
+    const int gx = (width + TILE - 1) / TILE, gy = (height + TILE - 1) / TILE;
+    const size_t Tn = (size_t)gx * gy, HW = (size_t)width * height;
+    const GeomLayout GL(P); const ImgLayout IL(HW, Tn); const BinLayout BL(R);
+    if (geom_buffer && P > 0) {
+        const char* g = align_ptr(geom_buffer);
+        if (rec32) HIP_TRY(hipMemcpyAsync(rec32, g + GL.rec, (size_t)P * REC_F * 4, hipMemcpyDeviceToDevice, s), "dump rec");
+        if (tiles) HIP_TRY(hipMemcpyAsync(tiles, g + GL.tiles, (size_t)P * 4, hipMemcpyDeviceToDevice, s), "dump tiles");
+    }
+    if (binning_buffer && R > 0 && point_list)
+        HIP_TRY(hipMemcpyAsync(point_list, align_ptr(binning_buffer) + BL.point_list, (size_t)R * 4, hipMemcpyDeviceToDevice, s), "dump point_list");
+    if (image_buffer) {
+        const char* i = align_ptr(image_buffer);
+        if (ranges) HIP_TRY(hipMemcpyAsync(ranges, i + IL.ranges, Tn * 8, hipMemcpyDeviceToDevice, s), "dump ranges");
+        if (n_contrib) HIP_TRY(hipMemcpyAsync(n_contrib, i + IL.n_contrib, HW * 8, hipMemcpyDeviceToDevice, s), "dump n_contrib");
+    }
+    return 0;
+}

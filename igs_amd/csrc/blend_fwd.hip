@@ -1,0 +1,156 @@
+// blend_fwd.hip -- tile-wise front-to-back alpha compositing for gfx950 (wave64).
+// Replaces FORWARD::render / renderCUDA (DGR/cuda_rasterizer/forward.cu:428-742).
+//
+// One 256-thread workgroup per 16x16 tile; each of its 4 waves owns an 8x8 pixel quad (lane = pixel), so a wave
+// whose 64 pixels are saturated or untouched by a splat skips it with one ballot.  Splats are staged 256 at a time
+// into LDS as packed 96-byte records gathered as whole 128-byte lines from the per-Gaussian record array; the inner
+// loop reads them back as wave-uniform (broadcast) ds_read_b128.  Tiles are handed to workgroups through an
+// XCD-aware remap so that the tiles sharing an L2 are spatial neighbours (neighbouring tiles share most splats).
+#include "common.h"
+
+template <bool COORD, bool DEPTH, bool NORMAL>
+__global__ void __launch_bounds__(256)
+blend_fwd_kernel(const BlendFwdArgs a)
+{
+    constexpr bool GEO = COORD || DEPTH || NORMAL;
+    constexpr int NQ = GEO ? 6 : 3;                     // float4 per staged record
+    __shared__ float4 chunk[CHUNK * NQ];
+    __shared__ int wave_done[4];
+
+    const uint32_t tile = xcd_remap(blockIdx.x, gridDim.x);
+    const uint32_t tx = tile % a.gx, ty = tile / a.gx;
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const uint32_t px = tx * TILE + (wid & 1) * 8 + (lane & 7);
+    const uint32_t py = ty * TILE + (wid >> 1) * 8 + (lane >> 3);
+    const bool inside = px < (uint32_t)a.W && py < (uint32_t)a.H;
+    const float pixfx = (float)px, pixfy = (float)py;
+
+    const uint2 range = ((const uint2*)a.ranges)[tile];
+    const int n = (int)(range.y - range.x);
+    const int rounds = (n + CHUNK - 1) / CHUNK;
+
+    bool done = !inside;
+    float T = 1.0f;
+    uint32_t last_contributor = 0, max_contributor = 0xFFFFFFFFu;
+    float C0 = 0, C1 = 0, C2 = 0, weight = 0;
+    float Co0 = 0, Co1 = 0, Co2 = 0, mC0 = 0, mC1 = 0, mC2 = 0, Depth = 0, mDepth = 0, N0 = 0, N1 = 0, N2 = 0;
+
+    if (tid < 4) wave_done[tid] = 0;
+    for (int i = 0; i < rounds; i++) {
+        __syncthreads();                                           // previous chunk consumed, wave_done published
+        if (wave_done[0] & wave_done[1] & wave_done[2] & wave_done[3]) break;
+        const int progress = i * CHUNK + (int)tid;
+        if (progress < n) {
+            const uint32_t id = a.point_list[range.x + progress];
+            const float4* src = (const float4*)(a.rec + (size_t)id * REC_F);
+            float4 q0 = src[0], q1 = src[1], q2 = src[2];
+            if (a.colors_precomp) {                                // feature_ptr = colors_precomp (rasterizer_impl.cu:394)
+                q1.z = a.colors_precomp[3 * (size_t)id]; q1.w = a.colors_precomp[3 * (size_t)id + 1];
+                q2.x = a.colors_precomp[3 * (size_t)id + 2];
+            }
+            chunk[tid * NQ + 0] = q0; chunk[tid * NQ + 1] = q1; chunk[tid * NQ + 2] = q2;
+            if constexpr (GEO) { chunk[tid * NQ + 3] = src[3]; chunk[tid * NQ + 4] = src[4]; chunk[tid * NQ + 5] = src[5]; }
+        }
+        __syncthreads();
+        const int cnt = min(CHUNK, n - i * CHUNK);
+        if (__ballot(!done) != 0ull) {
+            for (int j = 0; j < cnt; j++) {
+                const float4 q0 = chunk[j * NQ + 0];               // xy, conic.x, conic.y
+                const float4 q1 = chunk[j * NQ + 1];               // conic.z, opacity, r, g
+                const float dx = q0.x - pixfx, dy = q0.y - pixfy;
+                const float power = -0.5f * (q0.z * dx * dx + q1.x * dy * dy) - q0.w * dx * dy;
+                const float alpha = fminf(0.99f, q1.y * __expf(power));
+                const float test_T = T * (1.0f - alpha);
+                // negated comparisons keep the reference's behaviour for NaN (forward.cu:556-573: `if (x > 0) continue`)
+                const bool pass = !done && !(power > 0.0f) && !(alpha < 1.0f / 255.0f);
+                const bool contrib = pass && !(test_T < 0.0001f);
+                done = done || (pass && test_T < 0.0001f);
+                const uint64_t cm = __ballot(contrib);
+                if (cm == 0ull) { if (__ballot(!done) == 0ull) break; continue; }
+                const uint32_t contributor = (uint32_t)(i * CHUNK + j + 1);
+                const float aT = contrib ? alpha * T : 0.0f;
+                const float4 q2 = chunk[j * NQ + 2];               // b, ts, ray.x, ray.y
+                C0 += q1.z * aT; C1 += q1.w * aT; C2 += q2.x * aT;
+                const bool before_median = contrib && T > 0.5f;
+                if constexpr (GEO) {
+                    const float4 q3 = chunk[j * NQ + 3];           // view_point, n.x
+                    const float4 q5 = chunk[j * NQ + 5];           // cp4, cp5, n.y, n.z
+                    if constexpr (COORD) {
+                        const float4 q4 = chunk[j * NQ + 4];       // cp0..3
+                        const float c0 = q3.x + q4.x * dx + q4.y * dy;
+                        const float c1 = q3.y + q4.z * dx + q4.w * dy;
+                        const float c2 = q3.z + q5.x * dx + q5.y * dy;
+                        Co0 += c0 * aT; Co1 += c1 * aT; Co2 += c2 * aT;
+                        mC0 = before_median ? c0 : mC0; mC1 = before_median ? c1 : mC1; mC2 = before_median ? c2 : mC2;
+                    }
+                    if constexpr (DEPTH) {
+                        const float t = q2.y + (q2.z * dx + q2.w * dy);
+                        Depth += t * aT;
+                        mDepth = before_median ? t : mDepth;
+                    }
+                    if constexpr (NORMAL) { N0 += q3.w * aT; N1 += q5.z * aT; N2 += q5.w * aT; }
+                    max_contributor = before_median ? contributor : max_contributor;
+                }
+                weight += aT;
+                T = contrib ? test_T : T;
+                last_contributor = contrib ? contributor : last_contributor;
+            }
+        }
+        if (lane == 0) wave_done[wid] = (__ballot(!done) == 0ull) ? 1 : 0;
+    }
+
+    if (inside) {
+        const size_t HW = (size_t)a.H * a.W;
+        const size_t pix = (size_t)a.W * py + px;
+        a.n_contrib[pix] = last_contributor;
+        a.n_contrib[pix + HW] = max_contributor;
+        a.out_color[pix] = C0 + T * a.bg[0];
+        a.out_color[HW + pix] = C1 + T * a.bg[1];
+        a.out_color[2 * HW + pix] = C2 + T * a.bg[2];
+        a.out_alpha[pix] = weight;
+        const float pnx = (pixfx - a.W / 2.f) / a.fx, pny = (pixfy - a.H / 2.f) / a.fy;
+        const float ln = sqrtf(pnx * pnx + pny * pny + 1);
+        if constexpr (COORD) {
+            a.out_coord[pix] = last_contributor ? Co0 / weight : 0.f;
+            a.out_coord[HW + pix] = last_contributor ? Co1 / weight : 0.f;
+            a.out_coord[2 * HW + pix] = last_contributor ? Co2 / weight : 0.f;
+            a.accum_coord[pix] = Co0; a.accum_coord[HW + pix] = Co1; a.accum_coord[2 * HW + pix] = Co2;
+            a.out_mcoord[pix] = mC0; a.out_mcoord[HW + pix] = mC1; a.out_mcoord[2 * HW + pix] = mC2;
+        } else {
+            a.out_coord[pix] = 0.f; a.out_coord[HW + pix] = 0.f; a.out_coord[2 * HW + pix] = 0.f;
+            a.out_mcoord[pix] = 0.f; a.out_mcoord[HW + pix] = 0.f; a.out_mcoord[2 * HW + pix] = 0.f;
+        }
+        if constexpr (DEPTH) {
+            const float depth_ln = Depth / ln;
+            a.accum_depth[pix] = depth_ln;
+            a.out_depth[pix] = last_contributor ? depth_ln / weight : 0.f;
+            a.out_mdepth[pix] = mDepth / ln;
+        } else {
+            a.out_depth[pix] = 0.f; a.out_mdepth[pix] = 0.f;
+        }
+        if constexpr (NORMAL) {
+            if (last_contributor) {
+                float len = sqrtf(N0 * N0 + N1 * N1 + N2 * N2);
+                a.normal_length[pix] = len;
+                len = fmaxf(len, 1.0E-12F);
+                a.out_normal[pix] = N0 / len; a.out_normal[HW + pix] = N1 / len; a.out_normal[2 * HW + pix] = N2 / len;
+            } else {
+                a.normal_length[pix] = 1.f;
+                a.out_normal[pix] = 0.f; a.out_normal[HW + pix] = 0.f; a.out_normal[2 * HW + pix] = 0.f;
+            }
+        } else {
+            a.out_normal[pix] = 0.f; a.out_normal[HW + pix] = 0.f; a.out_normal[2 * HW + pix] = 0.f;
+        }
+    }
+}
+
+hipError_t launch_blend_fwd(hipStream_t s, const BlendFwdArgs& a, bool coord, bool depth)
+{
+    const dim3 grid(a.gx * a.gy), block(256);
+    // dispatch of forward.cu:732-739: NORMAL is on whenever COORD or DEPTH is
+    if (coord && depth) hipLaunchKernelGGL((blend_fwd_kernel<true, true, true>), grid, block, 0, s, a);
+    else if (coord) hipLaunchKernelGGL((blend_fwd_kernel<true, false, true>), grid, block, 0, s, a);
+    else if (depth) hipLaunchKernelGGL((blend_fwd_kernel<false, true, true>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((blend_fwd_kernel<false, false, false>), grid, block, 0, s, a);
+    return hipGetLastError();
+}

@@ -1,0 +1,197 @@
+// common.h -- shared declarations of the MI355X (gfx950) rasterizer library.
+// Private scratch layouts, kernel launch entry points, small device helpers.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+
+#define TILE 16              // reference config.h: BLOCK_X = BLOCK_Y = 16
+#define TILE_PIX 256
+#define CHUNK 256            // instances staged per LDS round
+
+// ---------------------------------------------------------------------------------------------
+// Packed per-Gaussian record: ONE 128-byte line per Gaussian (the blend kernels gather whole lines).
+//   float4 q0 = { xy.x, xy.y, conic.x, conic.y }
+//   float4 q1 = { conic.z, opacity*coef, r, g }
+//   float4 q2 = { b, ts, ray_plane.x, ray_plane.y }
+//   float4 q3 = { view_point.x, .y, .z, normal.x }
+//   float4 q4 = { camera_plane[0..3] }
+//   float4 q5 = { camera_plane[4], camera_plane[5], normal.y, normal.z }
+//   float4 q6 = { cov3D[0..3] }
+//   float4 q7 = { cov3D[4], cov3D[5], bits(clamped mask), bits(depth key) }
+// (reference GeometryState, rasterizer_impl.h:29-48, holds these as ~13 separate arrays)
+// ---------------------------------------------------------------------------------------------
+#define REC_F 32
+#define REC_BLEND_F 24       // floats staged into LDS by the blend kernels
+
+// Per-Gaussian gradient accumulator written by the blend backward (one 128-byte line, fp32 atomics):
+//   0..2  dL_dcolor            3..5  dL_dview_point      6..11 dL_dcamera_plane (d/fx, d/fy folded in)
+//   12    dL_dts               13,14 dL_dray_plane       15..17 dL_dnormal
+//   18,19 dL_dmean2D.xy (NDC-scaled)  20 dL_dmean2D.z (abs sum)
+//   21..23 dL_dconic (x, y, w)  24 dL_dopacity (before coef)
+#define GACC_F 32
+enum { GA_COLOR = 0, GA_VP = 3, GA_CP = 6, GA_TS = 12, GA_RP = 13, GA_NRM = 15, GA_M2D = 18, GA_M2DZ = 20,
+       GA_CONIC = 21, GA_OPA = 24, GA_USED = 25 };
+
+static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+#define SORT_ITEMS 16                      // elements per thread per sort sub-tile
+#define SORT_TILE (256 * SORT_ITEMS)       // 4096 elements per block sub-tile
+#define SORT_MAX_BLOCKS 256                // one block per CU
+
+struct GeomLayout {          // sizes in bytes, offsets from a 256-byte aligned base
+    size_t rec, tiles, keys_a, keys_b, vals_a, vals_b, hist, blocksum, counters, total;
+    __host__ explicit GeomLayout(size_t P) {
+        size_t o = 0;
+        rec = o;      o += align_up(P * REC_F * 4, 256);
+        tiles = o;    o += align_up(P * 4, 256);
+        keys_a = o;   o += align_up(P * 4, 256);
+        keys_b = o;   o += align_up(P * 4, 256);
+        vals_a = o;   o += align_up(P * 4, 256);     // after the depth sort: Gaussian ids in depth order
+        vals_b = o;   o += align_up(P * 4, 256);
+        hist = o;     o += align_up((size_t)256 * SORT_MAX_BLOCKS * 4, 256);
+        blocksum = o; o += align_up((P / 256 + 2) * 4, 256);   // per-256 block instance counts / offsets (depth order)
+        counters = o; o += 256;                                // [0] total instances, [1] prefilter violation flag
+        total = o + 256;
+    }
+};
+struct BinLayout {
+    size_t point_list, keys_a, keys_b, vals_b, hist, total;
+    __host__ explicit BinLayout(size_t R) {
+        size_t o = 0;
+        point_list = o; o += align_up(R * 4, 256);   // final sorted Gaussian ids (kept for backward)
+        keys_a = o;     o += align_up(R * 4, 256);
+        keys_b = o;     o += align_up(R * 4, 256);
+        vals_b = o;     o += align_up(R * 4, 256);
+        hist = o;       o += align_up((size_t)256 * SORT_MAX_BLOCKS * 4, 256);
+        total = o + 256;
+    }
+};
+struct ImgLayout {
+    size_t ranges, n_contrib, accum_coord, accum_depth, normal_length, total;
+    __host__ ImgLayout(size_t HW, size_t T) {
+        size_t o = 0;
+        ranges = o;        o += align_up(T * 8, 256);
+        n_contrib = o;     o += align_up(HW * 8, 256);
+        accum_coord = o;   o += align_up(HW * 12, 256);
+        accum_depth = o;   o += align_up(HW * 4, 256);
+        normal_length = o; o += align_up(HW * 4, 256);
+        total = o + 256;
+    }
+};
+static inline char* align_ptr(const char* p) { return (char*)(((uintptr_t)p + 255) & ~(uintptr_t)255); }
+
+struct FwdParams {
+    int P, D, M, W, H, gx, gy;
+    const float *means3D, *shs, *colors_precomp, *opacities, *scales, *rotations, *cov3D_precomp;
+    float scale_modifier, tan_fovx, tan_fovy, fx, fy, kernel_size;
+    int prefiltered;
+    const float *view, *proj, *campos;      // device pointers (transposed 4x4 matrices, camera centre)
+};
+
+// ---- launchers (each returns hipError_t of the launch) ----
+hipError_t launch_preprocess_fwd(hipStream_t s, const FwdParams& p, float* rec, uint32_t* tiles, uint32_t* depth_keys,
+                                 uint32_t* ident, int* radii, uint32_t* counters);
+hipError_t launch_mark_visible(hipStream_t s, int P, const float* means3D, const float* view, uint8_t* present);
+
+// stable LSD radix sort of (key,value) pairs on key bits [bit_lo, bit_hi); result ends in *out_keys/*out_vals
+// (ping-pong between a and b).  `hist` must hold 256*SORT_MAX_BLOCKS uint32.
+hipError_t radix_sort_pairs(hipStream_t s, uint32_t n, uint32_t* keys_a, uint32_t* keys_b, uint32_t* vals_a, uint32_t* vals_b,
+                            uint32_t* hist, int bit_lo, int bit_hi, uint32_t** out_keys, uint32_t** out_vals);
+hipError_t launch_count_sorted(hipStream_t s, int P, const uint32_t* order, const uint32_t* tiles, uint32_t* blocksum);
+hipError_t launch_scan_blocksums(hipStream_t s, int nblocks, uint32_t* blocksum);
+hipError_t launch_emit_instances(hipStream_t s, int P, int gx, int gy, const uint32_t* order, const uint32_t* tiles,
+                                 const uint32_t* blocksum, const float* rec, const int* radii, uint32_t* tile_keys,
+                                 uint32_t* vals);
+hipError_t launch_tile_ranges(hipStream_t s, uint32_t R, const uint32_t* tile_keys, uint32_t* ranges);
+
+struct BlendFwdArgs {
+    int W, H, gx, gy;
+    float fx, fy; const float* bg;
+    const uint32_t* ranges; const uint32_t* point_list; const float* rec; const float* colors_precomp;
+    float *out_color, *out_coord, *out_mcoord, *out_depth, *out_mdepth, *out_alpha, *out_normal;
+    uint32_t* n_contrib; float *accum_coord, *accum_depth, *normal_length;
+};
+hipError_t launch_blend_fwd(hipStream_t s, const BlendFwdArgs& a, bool coord, bool depth);
+
+struct BlendBwdArgs {
+    int W, H, gx, gy;
+    float fx, fy; const float* bg;
+    const uint32_t* ranges; const uint32_t* point_list; const float* rec; const float* colors_precomp;
+    const float *alphas, *normalmap, *accum_coord, *accum_depth, *normal_length; const uint32_t* n_contrib;
+    const float *dL_dpix, *dL_dcoord, *dL_dmcoord, *dL_ddepth, *dL_dmdepth, *dL_dalpha, *dL_dnormal;
+    float* gacc;
+};
+hipError_t launch_blend_bwd(hipStream_t s, const BlendBwdArgs& a, bool coord, bool depth);
+
+struct GeomBwdArgs {
+    int P, D, M, W, H;
+    const float *means3D, *shs, *scales, *rotations, *cov3D_precomp; const int* radii;
+    float scale_modifier, tan_fovx, tan_fovy, fx, fy, kernel_size;
+    const float *view, *proj, *campos;
+    const float* rec; const float* gacc;
+    float *dL_dmean2D, *dL_dcolor, *dL_dopacity, *dL_dmean3D, *dL_dcov3D, *dL_dsh, *dL_dscale, *dL_drot;
+};
+hipError_t launch_geom_bwd(hipStream_t s, const GeomBwdArgs& a);
+
+// ---------------------------------------------------------------------------------------------
+// device helpers
+// ---------------------------------------------------------------------------------------------
+#ifdef __HIPCC__
+struct M3 { float m[3][3]; };     // standard row-major [row][col]
+
+__device__ __forceinline__ M3 m3_mul(const M3& A, const M3& B) {
+    M3 R;
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) R.m[i][j] = A.m[i][0] * B.m[0][j] + A.m[i][1] * B.m[1][j] + A.m[i][2] * B.m[2][j];
+    return R;
+}
+__device__ __forceinline__ M3 m3_T(const M3& A) {
+    M3 R;
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) R.m[i][j] = A.m[j][i];
+    return R;
+}
+__device__ __forceinline__ float3 m3_vec(const M3& A, float3 v) {
+    return make_float3(A.m[0][0] * v.x + A.m[0][1] * v.y + A.m[0][2] * v.z,
+                       A.m[1][0] * v.x + A.m[1][1] * v.y + A.m[1][2] * v.z,
+                       A.m[2][0] * v.x + A.m[2][1] * v.y + A.m[2][2] * v.z);
+}
+__device__ __forceinline__ float3 m3T_vec(const M3& A, float3 v) {   // A^T v
+    return make_float3(A.m[0][0] * v.x + A.m[1][0] * v.y + A.m[2][0] * v.z,
+                       A.m[0][1] * v.x + A.m[1][1] * v.y + A.m[2][1] * v.z,
+                       A.m[0][2] * v.x + A.m[1][2] * v.y + A.m[2][2] * v.z);
+}
+__device__ __forceinline__ float dot3(float3 a, float3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ __forceinline__ float3 operator*(float3 a, float s) { return make_float3(a.x * s, a.y * s, a.z * s); }
+__device__ __forceinline__ float3 operator+(float3 a, float3 b) { return make_float3(a.x + b.x, a.y + b.y, a.z + b.z); }
+__device__ __forceinline__ float3 operator-(float3 a, float3 b) { return make_float3(a.x - b.x, a.y - b.y, a.z - b.z); }
+
+// the reference's transformPoint4x3 / 4x4 on the TRANSPOSED matrices the callers pass (auxiliary.h:74-93)
+__device__ __forceinline__ float3 xform4x3(float3 p, const float* m) {
+    return make_float3(m[0] * p.x + m[4] * p.y + m[8] * p.z + m[12], m[1] * p.x + m[5] * p.y + m[9] * p.z + m[13],
+                       m[2] * p.x + m[6] * p.y + m[10] * p.z + m[14]);
+}
+__device__ __forceinline__ float4 xform4x4(float3 p, const float* m) {
+    return make_float4(m[0] * p.x + m[4] * p.y + m[8] * p.z + m[12], m[1] * p.x + m[5] * p.y + m[9] * p.z + m[13],
+                       m[2] * p.x + m[6] * p.y + m[10] * p.z + m[14], m[3] * p.x + m[7] * p.y + m[11] * p.z + m[15]);
+}
+// tile rectangle of a splat (auxiliary.h:62-72); float->int conversions saturate on the GPU
+__device__ __forceinline__ void get_rect(float px, float py, int max_radius, int gx, int gy, int& x0, int& y0, int& x1, int& y1) {
+    float r = (float)max_radius;
+    x0 = min(gx, max(0, (int)((px - r) / (float)TILE)));
+    y0 = min(gy, max(0, (int)((py - r) / (float)TILE)));
+    x1 = min(gx, max(0, (int)((px + r + (float)TILE - 1.0f) / (float)TILE)));
+    y1 = min(gy, max(0, (int)((py + r + (float)TILE - 1.0f) / (float)TILE)));
+}
+// XCD-aware bijective remap: blocks b, b+8, .. share an XCD (round-robin dispatch), give each XCD a contiguous band of tiles
+__device__ __forceinline__ uint32_t xcd_remap(uint32_t b, uint32_t n) {
+    uint32_t q = n / 8, r = n % 8, xcd = b % 8, k = b / 8;
+    uint32_t base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + k;
+}
+#endif

@@ -1,0 +1,370 @@
+// geom_bwd.hip -- per-Gaussian backward (one thread per Gaussian), gfx950.
+// Fuses what the reference runs as two kernels plus 14 zero-filled temporaries:
+//   computeCov2DCUDA (DGR/cuda_rasterizer/backward.cu:145-488), preprocessCUDA backward (:560-628) with the SH
+//   backward (:21-140) and computeCov3D backward (:492-555).
+// Input is the 128-byte raw-moment accumulator line written by blend_bwd.hip; every output element is written
+// (zeros for culled Gaussians), so the caller needs no memsets.
+//
+// Quirks of the reference reproduced on purpose:
+//  * computeCov2DCUDA is handed dL_dconic in its `conic_opacity` parameter (rasterizer_impl.cu:569), so what it calls
+//    combined_opacity is dL_dconic.w;
+//  * the conic backward adds kernel_size to a and c, the forward conic does not (backward.cu:377-379);
+//  * no quaternion-normalisation backward (backward.cu:554).
+#include "geom_math.h"
+
+__constant__ float BSH_C0 = 0.28209479177387814f;
+__constant__ float BSH_C1 = 0.4886025119029199f;
+__constant__ float BSH_C2[5] = { 1.0925484305920792f, -1.0925484305920792f, 0.31539156525252005f, -1.0925484305920792f,
+                                 0.5462742152960396f };
+__constant__ float BSH_C3[7] = { -0.5900435899266435f, 2.890611442640554f, -0.4570457994644658f, 0.3731763325901154f,
+                                 -0.4570457994644658f, 1.445305721320277f, -0.5900435899266435f };
+
+__device__ __forceinline__ float3 dnormvdv(float3 v, float3 dv) {   // auxiliary.h:123-133
+    const float sum2 = v.x * v.x + v.y * v.y + v.z * v.z;
+    const float invsum32 = 1.0f / sqrtf(sum2 * sum2 * sum2);
+    float3 r;
+    r.x = ((+sum2 - v.x * v.x) * dv.x - v.y * v.x * dv.y - v.z * v.x * dv.z) * invsum32;
+    r.y = (-v.x * v.y * dv.x + (sum2 - v.y * v.y) * dv.y - v.z * v.y * dv.z) * invsum32;
+    r.z = (-v.x * v.z * dv.x - v.y * v.z * dv.y + (sum2 - v.z * v.z) * dv.z) * invsum32;
+    return r;
+}
+
+// SH backward (backward.cu:21-140): writes dL_dsh[M][3] (all M rows; rows beyond the active degree are zero) and
+// returns the contribution to dL_dmean through the view direction.
+__device__ __forceinline__ float3 sh_backward(int deg, int M, const float* __restrict__ sh, float3 dir_orig, uint32_t clamped,
+                                              float3 dL_dcolor, float* __restrict__ dsh)
+{
+    const float len = sqrtf(dot3(dir_orig, dir_orig));
+    const float x = dir_orig.x / len, y = dir_orig.y / len, z = dir_orig.z / len;
+    const float3 g = make_float3((clamped & 1u) ? 0.f : dL_dcolor.x, (clamped & 2u) ? 0.f : dL_dcolor.y, (clamped & 4u) ? 0.f : dL_dcolor.z);
+    auto L = [&](int k) { return make_float3(sh[3 * k], sh[3 * k + 1], sh[3 * k + 2]); };
+    auto W = [&](int k, float b) { dsh[3 * k] = b * g.x; dsh[3 * k + 1] = b * g.y; dsh[3 * k + 2] = b * g.z; };
+    float3 dx = make_float3(0, 0, 0), dy = make_float3(0, 0, 0), dz = make_float3(0, 0, 0);
+    W(0, BSH_C0);
+    if (deg > 0) {
+        W(1, -BSH_C1 * y); W(2, BSH_C1 * z); W(3, -BSH_C1 * x);
+        dx = L(3) * (-BSH_C1); dy = L(1) * (-BSH_C1); dz = L(2) * BSH_C1;
+        if (deg > 1) {
+            const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+            W(4, BSH_C2[0] * xy); W(5, BSH_C2[1] * yz); W(6, BSH_C2[2] * (2.f * zz - xx - yy)); W(7, BSH_C2[3] * xz);
+            W(8, BSH_C2[4] * (xx - yy));
+            dx = dx + (L(4) * (BSH_C2[0] * y) + L(6) * (BSH_C2[2] * 2.f * -x) + L(7) * (BSH_C2[3] * z) + L(8) * (BSH_C2[4] * 2.f * x));
+            dy = dy + (L(4) * (BSH_C2[0] * x) + L(5) * (BSH_C2[1] * z) + L(6) * (BSH_C2[2] * 2.f * -y) + L(8) * (BSH_C2[4] * 2.f * -y));
+            dz = dz + (L(5) * (BSH_C2[1] * y) + L(6) * (BSH_C2[2] * 2.f * 2.f * z) + L(7) * (BSH_C2[3] * x));
+            if (deg > 2) {
+                W(9, BSH_C3[0] * y * (3.f * xx - yy)); W(10, BSH_C3[1] * xy * z); W(11, BSH_C3[2] * y * (4.f * zz - xx - yy));
+                W(12, BSH_C3[3] * z * (2.f * zz - 3.f * xx - 3.f * yy)); W(13, BSH_C3[4] * x * (4.f * zz - xx - yy));
+                W(14, BSH_C3[5] * z * (xx - yy)); W(15, BSH_C3[6] * x * (xx - 3.f * yy));
+                dx = dx + (L(9) * (BSH_C3[0] * 3.f * 2.f * xy) + L(10) * (BSH_C3[1] * yz) + L(11) * (BSH_C3[2] * -2.f * xy)
+                           + L(12) * (BSH_C3[3] * -3.f * 2.f * xz) + L(13) * (BSH_C3[4] * (-3.f * xx + 4.f * zz - yy))
+                           + L(14) * (BSH_C3[5] * 2.f * xz) + L(15) * (BSH_C3[6] * 3.f * (xx - yy)));
+                dy = dy + (L(9) * (BSH_C3[0] * 3.f * (xx - yy)) + L(10) * (BSH_C3[1] * xz)
+                           + L(11) * (BSH_C3[2] * (-3.f * yy + 4.f * zz - xx)) + L(12) * (BSH_C3[3] * -3.f * 2.f * yz)
+                           + L(13) * (BSH_C3[4] * -2.f * xy) + L(14) * (BSH_C3[5] * -2.f * yz) + L(15) * (BSH_C3[6] * -3.f * 2.f * xy));
+                dz = dz + (L(10) * (BSH_C3[1] * xy) + L(11) * (BSH_C3[2] * 4.f * 2.f * yz) + L(12) * (BSH_C3[3] * 3.f * (2.f * zz - xx - yy))
+                           + L(13) * (BSH_C3[4] * 4.f * 2.f * xz) + L(14) * (BSH_C3[5] * (xx - yy)));
+            }
+        }
+    }
+    const int used = (deg + 1) * (deg + 1);
+    for (int k = used; k < M; k++) { dsh[3 * k] = 0.f; dsh[3 * k + 1] = 0.f; dsh[3 * k + 2] = 0.f; }
+    const float3 dL_ddir = make_float3(dot3(dx, g), dot3(dy, g), dot3(dz, g));
+    return dnormvdv(dir_orig, dL_ddir);
+}
+
+struct GBArgs { GeomBwdArgs a; };
+
+__global__ void __launch_bounds__(256)
+geom_bwd_kernel(const GBArgs args)
+{
+    const GeomBwdArgs& a = args.a;
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= a.P) return;
+
+    float3 o_m2d = make_float3(0, 0, 0), o_color = make_float3(0, 0, 0), o_mean = make_float3(0, 0, 0), o_scale = make_float3(0, 0, 0);
+    float o_opacity = 0.f, o_cov[6] = { 0, 0, 0, 0, 0, 0 };
+    float4 o_rot = make_float4(0, 0, 0, 0);
+    float* dsh = a.M ? a.dL_dsh + (size_t)idx * a.M * 3 : nullptr;
+    bool sh_written = false;
+
+    if (a.radii[idx] > 0) {
+        const float4* R4 = (const float4*)(a.rec + (size_t)idx * REC_F);
+        const float4* G4 = (const float4*)(a.gacc + (size_t)idx * GACC_F);
+        const float4 r0 = R4[0], r1 = R4[1], r2 = R4[2], r4 = R4[4], r5 = R4[5], r6 = R4[6], r7 = R4[7];
+        const float4 g0 = G4[0], g1 = G4[1], g2 = G4[2], g3 = G4[3], g4 = G4[4], g5 = G4[5], g6 = G4[6];
+        // ---- unpack raw moments ----
+        o_color = make_float3(g0.x, g0.y, g0.z);
+        const float Sv0 = g0.w, Sv1 = g1.x, Sv2 = g1.y;
+        const float Sx0 = g1.z, Sx1 = g1.w, Sx2 = g2.x, Sy0 = g2.y, Sy1 = g2.z, Sy2 = g2.w;
+        const float St = g3.x, Stx = g3.y, Sty = g3.z;
+        const float3 dL_dnormal = make_float3(g3.w, g4.x, g4.y);
+        const float Q0 = g4.z, Qx = g4.w, Qy = g5.x, Qxx = g5.y, Qxy = g5.z, Qyy = g5.w, Z = g6.x;
+        const float conx = r0.z, cony = r0.w, conz = r1.x, opac = r1.y;
+        const float cpl[6] = { r4.x, r4.y, r4.z, r4.w, r5.x, r5.y };
+        const float rplx = r2.z, rply = r2.w;
+        // ---- what the reference accumulated with atomics (backward.cu:878-1013) ----
+        const float halfW = 0.5f * a.W, halfH = 0.5f * a.H;                                   // ddelx_dx, ddely_dy (backward.cu:792-793)
+        o_m2d.x = (-(conx * Qx + cony * Qy) + cpl[0] * Sv0 + cpl[2] * Sv1 + cpl[4] * Sv2 + rplx * St) * halfW;
+        o_m2d.y = (-(conz * Qy + cony * Qx) + cpl[1] * Sv0 + cpl[3] * Sv1 + cpl[5] * Sv2 + rply * St) * halfH;
+        o_m2d.z = Z;
+        const float dLc_x = -0.5f * Qxx, dLc_y = -0.5f * Qxy, dLc_z = -0.5f * Qyy;         // dL_dconic .x .y .w
+        const float c0x = Sx0 / a.fx, c0y = Sy0 / a.fy, c1x = Sx1 / a.fx, c1y = Sy1 / a.fy, c2x = Sx2 / a.fx, c2y = Sy2 / a.fy;
+        const float drx = Stx / a.fx, dry = Sty / a.fy;
+        const float dL_dts = St;
+        float dL_dopacity = (opac != 0.f) ? Q0 / opac : 0.f;
+
+        const float3 mean = make_float3(a.means3D[3 * idx], a.means3D[3 * idx + 1], a.means3D[3 * idx + 2]);
+        float cov3D[6];
+        if (a.cov3D_precomp) {
+#pragma unroll
+            for (int k = 0; k < 6; k++) cov3D[k] = a.cov3D_precomp[6 * (size_t)idx + k];
+        } else { cov3D[0] = r6.x; cov3D[1] = r6.y; cov3D[2] = r6.z; cov3D[3] = r6.w; cov3D[4] = r7.x; cov3D[5] = r7.y; }
+        const uint32_t clamped = __float_as_uint(r7.z);
+
+        // ================= computeCov2DCUDA (backward.cu:145-488) =================
+        Cov2DCtx c;
+        cov2d_ctx(c, mean, cov3D, a.view, a.fx, a.fy, a.tan_fovx, a.tan_fovy, a.kernel_size);
+        const float3 t = c.t;
+        const float u = c.txtz, v = c.tytz, u2 = u * u, v2 = v * v, uv = u * v;
+        const float combined_opacity = dLc_z;          // sic: dL_dconic.w, see header
+        float dVs[6] = { 0, 0, 0, 0, 0, 0 };            // symmetric sums of dL_dVrk: [00, 01+10, 02+20, 11, 12+21, 22]
+        float DN[3][3] = { { 0, 0, 0 }, { 0, 0, 0 }, { 0, 0, 0 } };   // dL_dnJ as a math matrix: DN[r][c] = dL_dcnv[r] * rnv[c]
+        float plane0 = 0.f, plane1 = 0.f, dL_du = 0.f, dL_dv = 0.f, dL_dl = 0.f, l = 1.f, nl = 1.f;
+        if (!c.degenerate) {
+            const float vb = dot3(c.uvh_m, c.uvh), vbn = dot3(c.uvh_mn, c.uvh);
+            l = sqrtf(t.x * t.x + t.y * t.y + t.z * t.z);
+            const float clamp_vb = fmaxf(vb, 0.0000001f), clamp_vbn = fmaxf(vbn, 0.0000001f);
+            nl = u2 + v2 + 1;
+            const float factor_normal = l / nl;
+            const float3 m = make_float3(c.uvh_mn.x / clamp_vbn, c.uvh_mn.y / clamp_vbn, c.uvh_mn.z / clamp_vbn);   // uvh_m_vb
+            plane0 = (v2 + 1) * m.x + (-uv) * m.y + (-u) * m.z;
+            plane1 = (-uv) * m.x + (u2 + 1) * m.y + (-v) * m.z;
+            const float cp0x = (-(v2 + 1) * t.z + plane0 * t.x) / nl, cp0y = (uv * t.z + plane1 * t.x) / nl;
+            const float cp1x = (uv * t.z + plane0 * t.y) / nl,        cp1y = (-(u2 + 1) * t.z + plane1 * t.y) / nl;
+            const float cp2x = (t.x + plane0 * t.z) / nl,             cp2y = (t.y + plane1 * t.z) / nl;
+            const float rpx = plane0 * factor_normal, rpy = plane1 * factor_normal;
+            const float3 rnv = make_float3(-plane0 * factor_normal, -plane1 * factor_normal, -1.f);
+            // N (rows): (1/z, 0, x/l), (0, 1/z, y/l), (-x/z^2, -y/z^2, z/l)
+            const float n00 = 1 / t.z, n02 = t.x / l, n11 = 1 / t.z, n12 = t.y / l;
+            const float n20 = -(t.x) / (t.z * t.z), n21 = -(t.y) / (t.z * t.z), n22 = t.z / l;
+            const float3 cnv = make_float3(n00 * rnv.x + 0.0f * rnv.y + n02 * rnv.z, 0.0f * rnv.x + n11 * rnv.y + n12 * rnv.z,
+                                           n20 * rnv.x + n21 * rnv.y + n22 * rnv.z);
+            const float lv = sqrtf(dot3(cnv, cnv));
+            const float3 nv = cnv * (1.0f / lv);
+            const float3 dLn_lv = make_float3(dL_dnormal.x / lv, dL_dnormal.y / lv, dL_dnormal.z / lv);
+            const float3 dL_dcnv = dLn_lv - nv * dot3(nv, dLn_lv);
+            // N^T * dL_dcnv
+            const float3 dL_drnv = make_float3(n00 * dL_dcnv.x + 0.0f * dL_dcnv.y + n20 * dL_dcnv.z,
+                                               0.0f * dL_dcnv.x + n11 * dL_dcnv.y + n21 * dL_dcnv.z,
+                                               n02 * dL_dcnv.x + n12 * dL_dcnv.y + n22 * dL_dcnv.z);
+            const float cn[3] = { dL_dcnv.x, dL_dcnv.y, dL_dcnv.z }, rn[3] = { rnv.x, rnv.y, rnv.z };
+#pragma unroll
+            for (int r = 0; r < 3; r++)
+#pragma unroll
+                for (int q = 0; q < 3; q++) DN[r][q] = cn[r] * rn[q];
+            dL_dl = (-plane0 * dL_drnv.x - plane1 * dL_drnv.y + plane0 * drx + plane1 * dry) / nl;
+            const float dpx = (t.x * c0x + t.y * c1x + t.z * c2x - l * dL_drnv.x + drx * l) / nl;
+            const float dpy = (t.x * c0y + t.y * c1y + t.z * c2y - l * dL_drnv.y + dry * l) / nl;
+            const float dL_dnl = (-c0x * cp0x - c0y * cp0y - c1x * cp1x - c1y * cp1y - c2x * cp2x - c2y * cp2y
+                                  - dL_drnv.x * rnv.x - dL_drnv.y * rnv.y - drx * rpx - dry * rpy) / nl;
+            const float tmp = dpx * plane0 + dpy * plane1;
+            const float3 Wu = m3T_vec(c.Rwc, c.uvh);                      // W * uvh = Rwc^T uvh
+            // Ni^T * (dpx, dpy, 0):  Ni rows (v2+1,-uv,-u), (-uv,u2+1,-v), (0,0,0)
+            const float3 NiT_dpa = make_float3((v2 + 1) * dpx + (-uv) * dpy, (-uv) * dpx + (u2 + 1) * dpy, (-u) * dpx + (-v) * dpy);
+            if (c.well) {
+                const float3 av = m3_vec(c.Vinv, Wu);
+                const float3 inner = Wu * (-tmp) + m3T_vec(c.Rwc, NiT_dpa);
+                M3 Vd;
+#pragma unroll
+                for (int r = 0; r < 3; r++)
+#pragma unroll
+                    for (int q = 0; q < 3; q++) Vd.m[r][q] = c.Vinv.m[r][q] / clamp_vb;
+                const float3 bv = m3_vec(Vd, inner);
+                const float A_[3] = { av.x, av.y, av.z }, B_[3] = { bv.x, bv.y, bv.z };
+                dVs[0] = -(A_[0] * B_[0]); dVs[3] = -(A_[1] * B_[1]); dVs[5] = -(A_[2] * B_[2]);
+                dVs[1] = -(A_[1] * B_[0]) + -(A_[0] * B_[1]);
+                dVs[2] = -(A_[2] * B_[0]) + -(A_[0] * B_[2]);
+                dVs[4] = -(A_[2] * B_[1]) + -(A_[1] * B_[2]);
+            } else {
+                const float dL_dvb = -tmp / clamp_vb;
+                const float3 qv = make_float3((v2 + 1) * (dpx / clamp_vb) + (-uv) * (dpy / clamp_vb),
+                                              (-uv) * (dpx / clamp_vb) + (u2 + 1) * (dpy / clamp_vb),
+                                              (-u) * (dpx / clamp_vb) + (-v) * (dpy / clamp_vb));
+                const float3 rv = Wu * dL_dvb + m3T_vec(c.Rwc, qv);       // dVi = Wu rv^T
+                // (dVi + dVi^T) emin = Wu (rv.emin) + rv (Wu.emin)
+                const float3 dLv = Wu * dot3(rv, c.emin) + rv * dot3(Wu, c.emin);
+                const float evj[3] = { c.ev0, c.ev1, c.ev2 };
+                const float3 vcj[3] = { c.vc0, c.vc1, c.vc2 };
+                float acc[3][3] = { { 0, 0, 0 }, { 0, 0, 0 }, { 0, 0, 0 } };
+                const float em[3] = { c.emin.x, c.emin.y, c.emin.z };
+#pragma unroll
+                for (int j = 0; j < 3; j++) {
+                    if (j != c.min_id) {
+                        const float sc = dot3(vcj[j], dLv) / fminf(c.evmin - evj[j], -0.0000001f);
+                        const float vj[3] = { vcj[j].x * sc, vcj[j].y * sc, vcj[j].z * sc };
+#pragma unroll
+                        for (int r = 0; r < 3; r++)
+#pragma unroll
+                            for (int q = 0; q < 3; q++) acc[r][q] += vj[r] * em[q];
+                    }
+                }
+                dVs[0] = acc[0][0]; dVs[3] = acc[1][1]; dVs[5] = acc[2][2];
+                dVs[1] = acc[1][0] + acc[0][1]; dVs[2] = acc[2][0] + acc[0][2]; dVs[4] = acc[2][1] + acc[1][2];
+            }
+            // dL_duvh = 2(-tmp) m + (Cinv/clamp_vb) Ni^T dpa
+            M3 Cd;
+#pragma unroll
+            for (int r = 0; r < 3; r++)
+#pragma unroll
+                for (int q = 0; q < 3; q++) Cd.m[r][q] = c.Cinv.m[r][q] / clamp_vb;
+            const float3 dL_duvh = m * (2 * (-tmp)) + m3_vec(Cd, NiT_dpa);
+            // DI = dpa m^T
+            const float DI01 = dpx * m.y, DI10 = dpy * m.x, DI11 = dpy * m.y, DI02 = dpx * m.z, DI00 = dpx * m.x, DI12 = dpy * m.z;
+            dL_du = dL_dnl * 2 * u + dL_duvh.x + (DI10 + DI01) * (-v) + 2 * DI11 * u - DI02
+                    + (c0y * t.y + c1x * t.y + c1y * (-2 * t.x)) / nl;
+            dL_dv = dL_dnl * 2 * v + dL_duvh.y + (DI10 + DI01) * (-u) + 2 * DI00 * v - DI12
+                    + (c0x * (-2 * t.y) + c0y * t.x + c1x * t.x) / nl;
+        }
+        // backward.cu:367-375 (double literals)
+        const float coef = c.coef, det_0 = c.det0, det_1 = c.det1, ks = a.kernel_size;
+        const float opacity = (float)((double)combined_opacity / ((double)coef + 1e-6));
+        const float dL_dcoef = dL_dopacity * opacity;
+        const float dL_dsqrtcoef = (float)((double)dL_dcoef * 0.5 * 1. / ((double)coef + 1e-6));
+        const float dL_ddet0 = (float)((double)dL_dsqrtcoef / ((double)det_1 + 1e-6));
+        const float dL_ddet1 = (float)((double)(dL_dsqrtcoef * det_0) * (double)(-1.f / ((double)(det_1 * det_1) + 1e-6)));
+        const float dcoef_da = dL_ddet0 * c.cov2[2] + dL_ddet1 * (c.cov2[2] + ks);
+        const float dcoef_db = (float)((double)dL_ddet0 * (-2. * (double)c.cov2[1]) + (double)dL_ddet1 * (-2. * (double)c.cov2[1]));
+        const float dcoef_dc = dL_ddet0 * c.cov2[0] + dL_ddet1 * (c.cov2[0] + ks);
+        const float ca = c.cov2[0] + ks, cb = c.cov2[1], cc = c.cov2[2] + ks;
+        const float denom = ca * cc - cb * cb;
+        float dL_da = 0, dL_db = 0, dL_dc = 0;
+        const float denom2inv = 1.0f / ((denom * denom) + 0.0000001f);
+#define T_(c_, r_) c.A[c_][r_]
+        if (denom2inv != 0) {
+            dL_da = denom2inv * (-cc * cc * dLc_x + 2 * cb * cc * dLc_y + (denom - ca * cc) * dLc_z);
+            dL_dc = denom2inv * (-ca * ca * dLc_z + 2 * ca * cb * dLc_y + (denom - ca * cc) * dLc_x);
+            dL_db = denom2inv * 2 * (cb * cc * dLc_x - (denom + 2 * cb * cb) * dLc_y + ca * cb * dLc_z);
+            if (c.coef_zero) {
+                dL_dopacity = 0;
+            } else {
+                dL_da += dcoef_da; dL_dc += dcoef_dc; dL_db += dcoef_db;
+                dL_dopacity = dL_dopacity * coef;
+            }
+            o_cov[0] = (T_(0, 0) * T_(0, 0) * dL_da + T_(0, 0) * T_(1, 0) * dL_db + T_(1, 0) * T_(1, 0) * dL_dc);
+            o_cov[3] = (T_(0, 1) * T_(0, 1) * dL_da + T_(0, 1) * T_(1, 1) * dL_db + T_(1, 1) * T_(1, 1) * dL_dc);
+            o_cov[5] = (T_(0, 2) * T_(0, 2) * dL_da + T_(0, 2) * T_(1, 2) * dL_db + T_(1, 2) * T_(1, 2) * dL_dc);
+            o_cov[1] = 2 * T_(0, 0) * T_(0, 1) * dL_da + (T_(0, 0) * T_(1, 1) + T_(0, 1) * T_(1, 0)) * dL_db + 2 * T_(1, 0) * T_(1, 1) * dL_dc;
+            o_cov[2] = 2 * T_(0, 0) * T_(0, 2) * dL_da + (T_(0, 0) * T_(1, 2) + T_(0, 2) * T_(1, 0)) * dL_db + 2 * T_(1, 0) * T_(1, 2) * dL_dc;
+            o_cov[4] = 2 * T_(0, 2) * T_(0, 1) * dL_da + (T_(0, 1) * T_(1, 2) + T_(0, 2) * T_(1, 1)) * dL_db + 2 * T_(1, 1) * T_(1, 2) * dL_dc;
+        }
+        o_cov[0] += dVs[0]; o_cov[3] += dVs[3]; o_cov[5] += dVs[5];
+        o_cov[1] += dVs[1]; o_cov[2] += dVs[2]; o_cov[4] += dVs[4];
+        o_opacity = dL_dopacity;
+#define V_(c_, r_) c.Sigma.m[c_][r_]
+        const float dL_dT00 = 2 * (T_(0, 0) * V_(0, 0) + T_(0, 1) * V_(0, 1) + T_(0, 2) * V_(0, 2)) * dL_da + (T_(1, 0) * V_(0, 0) + T_(1, 1) * V_(0, 1) + T_(1, 2) * V_(0, 2)) * dL_db;
+        const float dL_dT01 = 2 * (T_(0, 0) * V_(1, 0) + T_(0, 1) * V_(1, 1) + T_(0, 2) * V_(1, 2)) * dL_da + (T_(1, 0) * V_(1, 0) + T_(1, 1) * V_(1, 1) + T_(1, 2) * V_(1, 2)) * dL_db;
+        const float dL_dT02 = 2 * (T_(0, 0) * V_(2, 0) + T_(0, 1) * V_(2, 1) + T_(0, 2) * V_(2, 2)) * dL_da + (T_(1, 0) * V_(2, 0) + T_(1, 1) * V_(2, 1) + T_(1, 2) * V_(2, 2)) * dL_db;
+        const float dL_dT10 = 2 * (T_(1, 0) * V_(0, 0) + T_(1, 1) * V_(0, 1) + T_(1, 2) * V_(0, 2)) * dL_dc + (T_(0, 0) * V_(0, 0) + T_(0, 1) * V_(0, 1) + T_(0, 2) * V_(0, 2)) * dL_db;
+        const float dL_dT11 = 2 * (T_(1, 0) * V_(1, 0) + T_(1, 1) * V_(1, 1) + T_(1, 2) * V_(1, 2)) * dL_dc + (T_(0, 0) * V_(1, 0) + T_(0, 1) * V_(1, 1) + T_(0, 2) * V_(1, 2)) * dL_db;
+        const float dL_dT12 = 2 * (T_(1, 0) * V_(2, 0) + T_(1, 1) * V_(2, 1) + T_(1, 2) * V_(2, 2)) * dL_dc + (T_(0, 0) * V_(2, 0) + T_(0, 1) * V_(2, 1) + T_(0, 2) * V_(2, 2)) * dL_db;
+#undef V_
+#undef T_
+        // glm W[c][r] = Rwc[c][r]
+        const float dL_dJ00 = c.Rwc.m[0][0] * dL_dT00 + c.Rwc.m[0][1] * dL_dT01 + c.Rwc.m[0][2] * dL_dT02;
+        const float dL_dJ02 = c.Rwc.m[2][0] * dL_dT00 + c.Rwc.m[2][1] * dL_dT01 + c.Rwc.m[2][2] * dL_dT02;
+        const float dL_dJ11 = c.Rwc.m[1][0] * dL_dT10 + c.Rwc.m[1][1] * dL_dT11 + c.Rwc.m[1][2] * dL_dT12;
+        const float dL_dJ12 = c.Rwc.m[2][0] * dL_dT10 + c.Rwc.m[2][1] * dL_dT11 + c.Rwc.m[2][2] * dL_dT12;
+        const float tz = 1.f / t.z, tz2 = tz * tz, tz3 = tz2 * tz;
+        const float l3 = l * l * l;
+        // glm dL_dnJ[a][b] = DN[b][a]
+        const float dL_dtx = c.xgm * (-a.fx * tz2 * dL_dJ02 + dL_du * tz
+                                      - DN[2][0] * tz2 + DN[0][2] * (1 / l - t.x * t.x / l3) + DN[1][2] * (-t.x * t.y / l3) + DN[2][2] * (-t.x * t.z / l3)
+                                      + (c0x * plane0 + c0y * plane1 + c2x) / nl
+                                      + dL_dl * t.x / l);
+        const float dL_dty = c.ygm * (-a.fy * tz2 * dL_dJ12 + dL_dv * tz
+                                      - DN[2][1] * tz2 + DN[0][2] * (-t.x * t.y / l3) + DN[1][2] * (1 / l - t.y * t.y / l3) + DN[2][2] * (-t.y * t.z / l3)
+                                      + (c1x * plane0 + c1y * plane1 + c2y) / nl
+                                      + dL_dl * t.y / l);
+        const float dL_dtz = -a.fx * tz2 * dL_dJ00 - a.fy * tz2 * dL_dJ11 + (2 * a.fx * t.x) * tz3 * dL_dJ02 + (2 * a.fy * t.y) * tz3 * dL_dJ12
+                             - (dL_du * t.x + dL_dv * t.y) * tz2
+                             + (DN[0][0] + DN[1][1]) * (-tz2) + DN[2][0] * (2 * t.x * tz3) + DN[2][1] * (2 * t.y * tz3)
+                             + (DN[0][2] * t.x + DN[1][2] * t.y) * (-t.z / l3) + DN[2][2] * (1 / l - t.z * t.z / l3)
+                             + (c0x * (-(v2 + 1)) + c0y * uv + c1x * uv + c1y * (-(u2 + 1)) + c2x * plane0 + c2y * plane1) / nl
+                             + dL_dl * t.z / l;
+        // transformVec4x3Transpose (auxiliary.h:105-113)
+        o_mean = make_float3(a.view[0] * dL_dtx + a.view[1] * dL_dty + a.view[2] * dL_dtz,
+                             a.view[4] * dL_dtx + a.view[5] * dL_dty + a.view[6] * dL_dtz,
+                             a.view[8] * dL_dtx + a.view[9] * dL_dty + a.view[10] * dL_dtz);
+
+        // ================= preprocessCUDA backward (backward.cu:560-628) =================
+        {
+            const float4 m_hom = xform4x4(mean, a.proj);
+            const float m_w = 1.0f / (m_hom.w + 0.0000001f);
+            const float* pr = a.proj;
+            const float mul1 = (pr[0] * mean.x + pr[4] * mean.y + pr[8] * mean.z + pr[12]) * m_w * m_w;
+            const float mul2 = (pr[1] * mean.x + pr[5] * mean.y + pr[9] * mean.z + pr[13]) * m_w * m_w;
+            const float gx = o_m2d.x, gy = o_m2d.y;
+            const float d1x = (pr[0] * m_w - pr[3] * mul1) * gx + (pr[1] * m_w - pr[3] * mul2) * gy;
+            const float d1y = (pr[4] * m_w - pr[7] * mul1) * gx + (pr[5] * m_w - pr[7] * mul2) * gy;
+            const float d1z = (pr[8] * m_w - pr[11] * mul1) * gx + (pr[9] * m_w - pr[11] * mul2) * gy;
+            const float3 mv = xform4x3(mean, a.view);
+            const float tt = sqrtf(mv.x * mv.x + mv.y * mv.y + mv.z * mv.z);
+            const float3 q = make_float3(Sv0 + mv.x / tt * dL_dts, Sv1 + mv.y / tt * dL_dts, Sv2 + mv.z / tt * dL_dts);
+            const float3 d2 = make_float3(a.view[0] * q.x + a.view[1] * q.y + a.view[2] * q.z,
+                                          a.view[4] * q.x + a.view[5] * q.y + a.view[6] * q.z,
+                                          a.view[8] * q.x + a.view[9] * q.y + a.view[10] * q.z);
+            o_mean.x += d1x + d2.x; o_mean.y += d1y + d2.y; o_mean.z += d1z + d2.z;
+        }
+        if (a.shs) {
+            const float3 dir_orig = mean - make_float3(a.campos[0], a.campos[1], a.campos[2]);
+            const float3 dm = sh_backward(a.D, a.M, a.shs + (size_t)idx * a.M * 3, dir_orig, clamped, o_color, dsh);
+            o_mean = o_mean + dm;
+            sh_written = true;
+        }
+        if (a.scales) {       // computeCov3D backward (backward.cu:492-555)
+            const float3 sc = make_float3(a.scales[3 * idx], a.scales[3 * idx + 1], a.scales[3 * idx + 2]);
+            const float4 qr = make_float4(a.rotations[4 * idx], a.rotations[4 * idx + 1], a.rotations[4 * idx + 2], a.rotations[4 * idx + 3]);
+            const float r = qr.x, x = qr.y, y = qr.z, z = qr.w;
+            const M3 Rq = quat_rot(qr);
+            const float s[3] = { a.scale_modifier * sc.x, a.scale_modifier * sc.y, a.scale_modifier * sc.z };
+            float dS[3][3];
+            dS[0][0] = o_cov[0]; dS[0][1] = 0.5f * o_cov[1]; dS[0][2] = 0.5f * o_cov[2];
+            dS[1][0] = 0.5f * o_cov[1]; dS[1][1] = o_cov[3]; dS[1][2] = 0.5f * o_cov[4];
+            dS[2][0] = 0.5f * o_cov[2]; dS[2][1] = 0.5f * o_cov[4]; dS[2][2] = o_cov[5];
+            // M = S Rq^T : M[k][j] = s_k Rq[j][k];  dM = (2 M) dSigma
+            float dM[3][3];
+#pragma unroll
+            for (int k = 0; k < 3; k++)
+#pragma unroll
+                for (int b = 0; b < 3; b++)
+                    dM[k][b] = (2.0f * (s[k] * Rq.m[0][k])) * dS[0][b] + (2.0f * (s[k] * Rq.m[1][k])) * dS[1][b] + (2.0f * (s[k] * Rq.m[2][k])) * dS[2][b];
+            const float ds0 = Rq.m[0][0] * dM[0][0] + Rq.m[1][0] * dM[0][1] + Rq.m[2][0] * dM[0][2];
+            const float ds1 = Rq.m[0][1] * dM[1][0] + Rq.m[1][1] * dM[1][1] + Rq.m[2][1] * dM[1][2];
+            const float ds2 = Rq.m[0][2] * dM[2][0] + Rq.m[1][2] * dM[2][1] + Rq.m[2][2] * dM[2][2];
+            o_scale = make_float3(ds0, ds1, ds2);
+            // X[a][b] = glm dL_dMt[a][b] after the column scaling = s_a * dM[a][b]
+#define X_(a_, b_) (dM[a_][b_] * s[a_])
+            o_rot.x = 2 * z * (X_(0, 1) - X_(1, 0)) + 2 * y * (X_(2, 0) - X_(0, 2)) + 2 * x * (X_(1, 2) - X_(2, 1));
+            o_rot.y = 2 * y * (X_(1, 0) + X_(0, 1)) + 2 * z * (X_(2, 0) + X_(0, 2)) + 2 * r * (X_(1, 2) - X_(2, 1)) - 4 * x * (X_(2, 2) + X_(1, 1));
+            o_rot.z = 2 * x * (X_(1, 0) + X_(0, 1)) + 2 * r * (X_(2, 0) - X_(0, 2)) + 2 * z * (X_(1, 2) + X_(2, 1)) - 4 * y * (X_(2, 2) + X_(0, 0));
+            o_rot.w = 2 * r * (X_(0, 1) - X_(1, 0)) + 2 * x * (X_(2, 0) + X_(0, 2)) + 2 * y * (X_(1, 2) + X_(2, 1)) - 4 * z * (X_(1, 1) + X_(0, 0));
+#undef X_
+        }
+    }
+    a.dL_dmean2D[3 * idx] = o_m2d.x; a.dL_dmean2D[3 * idx + 1] = o_m2d.y; a.dL_dmean2D[3 * idx + 2] = o_m2d.z;
+    a.dL_dcolor[3 * idx] = o_color.x; a.dL_dcolor[3 * idx + 1] = o_color.y; a.dL_dcolor[3 * idx + 2] = o_color.z;
+    a.dL_dopacity[idx] = o_opacity;
+    a.dL_dmean3D[3 * idx] = o_mean.x; a.dL_dmean3D[3 * idx + 1] = o_mean.y; a.dL_dmean3D[3 * idx + 2] = o_mean.z;
+#pragma unroll
+    for (int k = 0; k < 6; k++) a.dL_dcov3D[6 * (size_t)idx + k] = o_cov[k];
+    a.dL_dscale[3 * idx] = o_scale.x; a.dL_dscale[3 * idx + 1] = o_scale.y; a.dL_dscale[3 * idx + 2] = o_scale.z;
+    a.dL_drot[4 * idx] = o_rot.x; a.dL_drot[4 * idx + 1] = o_rot.y; a.dL_drot[4 * idx + 2] = o_rot.z; a.dL_drot[4 * idx + 3] = o_rot.w;
+    if (dsh && !sh_written) for (int k = 0; k < a.M * 3; k++) dsh[k] = 0.f;
+}
+
+hipError_t launch_geom_bwd(hipStream_t s, const GeomBwdArgs& a)
+{
+    GBArgs g; g.a = a;
+    hipLaunchKernelGGL(geom_bwd_kernel, dim3((a.P + 255) / 256), dim3(256), 0, s, g);
+    return hipGetLastError();
+}

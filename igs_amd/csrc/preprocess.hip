@@ -1,0 +1,169 @@
+// preprocess.hip -- per-Gaussian forward stage (one thread per Gaussian), gfx950.
+// Replaces FORWARD::preprocess / preprocessCUDA (DGR/cuda_rasterizer/forward.cu:307-423), checkFrustum
+// (rasterizer_impl.cu:54-66) and the tiles_touched reduction that the reference does with cub::DeviceScan.
+#include "geom_math.h"
+
+__constant__ float SH_C0 = 0.28209479177387814f;
+__constant__ float SH_C1 = 0.4886025119029199f;
+__constant__ float SH_C2[5] = { 1.0925484305920792f, -1.0925484305920792f, 0.31539156525252005f, -1.0925484305920792f,
+                                0.5462742152960396f };
+__constant__ float SH_C3[7] = { -0.5900435899266435f, 2.890611442640554f, -0.4570457994644658f, 0.3731763325901154f,
+                                -0.4570457994644658f, 1.445305721320277f, -0.5900435899266435f };
+
+// SH -> RGB (forward.cu:23-74).  sh points at this Gaussian's [M][3] coefficients.
+__device__ __forceinline__ float3 sh_to_rgb(int deg, const float* __restrict__ sh, float3 dir, uint32_t& clamped) {
+    const float3* c = (const float3*)sh;
+    auto L = [&](int k) { return make_float3(sh[3 * k], sh[3 * k + 1], sh[3 * k + 2]); };
+    float3 res = L(0) * SH_C0;
+    if (deg > 0) {
+        float x = dir.x, y = dir.y, z = dir.z;
+        res = res - L(1) * (SH_C1 * y) + L(2) * (SH_C1 * z) - L(3) * (SH_C1 * x);
+        if (deg > 1) {
+            float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+            res = res + L(4) * (SH_C2[0] * xy) + L(5) * (SH_C2[1] * yz) + L(6) * (SH_C2[2] * (2.0f * zz - xx - yy))
+                  + L(7) * (SH_C2[3] * xz) + L(8) * (SH_C2[4] * (xx - yy));
+            if (deg > 2) {
+                res = res + L(9) * (SH_C3[0] * y * (3.0f * xx - yy)) + L(10) * (SH_C3[1] * xy * z)
+                      + L(11) * (SH_C3[2] * y * (4.0f * zz - xx - yy)) + L(12) * (SH_C3[3] * z * (2.0f * zz - 3.0f * xx - 3.0f * yy))
+                      + L(13) * (SH_C3[4] * x * (4.0f * zz - xx - yy)) + L(14) * (SH_C3[5] * z * (xx - yy))
+                      + L(15) * (SH_C3[6] * x * (xx - 3.0f * yy));
+            }
+        }
+    }
+    (void)c;
+    res.x += 0.5f; res.y += 0.5f; res.z += 0.5f;
+    clamped = (res.x < 0 ? 1u : 0u) | (res.y < 0 ? 2u : 0u) | (res.z < 0 ? 4u : 0u);
+    return make_float3(fmaxf(res.x, 0.f), fmaxf(res.y, 0.f), fmaxf(res.z, 0.f));
+}
+
+struct PreArgs { FwdParams p; };
+
+__global__ void __launch_bounds__(256)
+preprocess_fwd_kernel(const PreArgs a, float* __restrict__ rec, uint32_t* __restrict__ tiles, uint32_t* __restrict__ depth_keys,
+                      uint32_t* __restrict__ ident, int* __restrict__ radii, uint32_t* __restrict__ counters)
+{
+    const FwdParams& p = a.p;
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    uint32_t my_tiles = 0;
+    if (idx < p.P) {
+        int radius = 0;
+        uint32_t dkey = 0xFFFFFFFFu;      // culled Gaussians sort to the end (they own no instances anyway)
+        float4* R4 = (float4*)(rec + (size_t)idx * REC_F);
+        const float3 p_orig = make_float3(p.means3D[3 * idx], p.means3D[3 * idx + 1], p.means3D[3 * idx + 2]);
+        const float3 p_view = xform4x3(p_orig, p.view);
+        do {
+            if (p_view.z <= 0.2f) {                       // auxiliary.h:170
+                if (p.prefiltered) atomicOr(&counters[1], 1u);
+                break;
+            }
+            const float4 p_hom = xform4x4(p_orig, p.proj);
+            const float p_w = 1.0f / (p_hom.w + 0.0000001f);
+            const float ppx = p_hom.x * p_w, ppy = p_hom.y * p_w;
+            float cov3D[6];
+            if (p.cov3D_precomp) {
+#pragma unroll
+                for (int k = 0; k < 6; k++) cov3D[k] = p.cov3D_precomp[6 * (size_t)idx + k];
+            } else {
+                const float3 s = make_float3(p.scales[3 * idx], p.scales[3 * idx + 1], p.scales[3 * idx + 2]);
+                const float4 q = make_float4(p.rotations[4 * idx], p.rotations[4 * idx + 1], p.rotations[4 * idx + 2], p.rotations[4 * idx + 3]);   // caller arrays: no alignment assumption
+                cov3d_from_scale_rot(s, p.scale_modifier, q, cov3D);
+            }
+            Cov2DCtx c;
+            cov2d_ctx(c, p_orig, cov3D, p.view, p.fx, p.fy, p.tan_fovx, p.tan_fovy, p.kernel_size);
+            float cp[6] = { 0, 0, 0, 0, 0, 0 }, rp[2] = { 0, 0 };
+            float3 nrm = make_float3(0, 0, 0);
+            if (!c.degenerate) {                           // forward.cu:169-262
+                const float3 t = c.t;
+                const float u = c.txtz, v = c.tytz, u2 = u * u, v2 = v * v, uv = u * v;
+                const float l = sqrtf(t.x * t.x + t.y * t.y + t.z * t.z);
+                const float vbn = dot3(c.uvh_mn, c.uvh);
+                const float nl = u2 + v2 + 1;
+                const float factor_normal = l / nl;
+                const float den = fmaxf(vbn, 0.0000001f);
+                const float3 q = make_float3(c.uvh_mn.x / den, c.uvh_mn.y / den, c.uvh_mn.z / den);
+                const float plane0 = (v2 + 1) * q.x + (-uv) * q.y + (-u) * q.z;
+                const float plane1 = (-uv) * q.x + (u2 + 1) * q.y + (-v) * q.z;
+                cp[0] = (-(v2 + 1) * t.z + plane0 * t.x) / nl / p.fx; cp[1] = (uv * t.z + plane1 * t.x) / nl / p.fy;
+                cp[2] = (uv * t.z + plane0 * t.y) / nl / p.fx;        cp[3] = (-(u2 + 1) * t.z + plane1 * t.y) / nl / p.fy;
+                cp[4] = (t.x + plane0 * t.z) / nl / p.fx;             cp[5] = (t.y + plane1 * t.z) / nl / p.fy;
+                rp[0] = plane0 * l / nl / p.fx; rp[1] = plane1 * l / nl / p.fy;
+                const float3 rn = make_float3(-plane0 * factor_normal, -plane1 * factor_normal, -1.f);
+                // nJ (std rows): (1/z, 0, x/l), (0, 1/z, y/l), (-x/z^2, -y/z^2, z/l)
+                const float3 cn = make_float3((1 / t.z) * rn.x + 0.0f * rn.y + (t.x / l) * rn.z,
+                                              0.0f * rn.x + (1 / t.z) * rn.y + (t.y / l) * rn.z,
+                                              (-(t.x) / (t.z * t.z)) * rn.x + (-(t.y) / (t.z * t.z)) * rn.y + (t.z / l) * rn.z);
+                const float inv = 1.0f / sqrtf(dot3(cn, cn));
+                nrm = cn * inv;
+            }
+            const float ts = sqrtf(p_view.x * p_view.x + p_view.y * p_view.y + p_view.z * p_view.z);
+            const float coef = c.coef_zero ? 0.0f : c.coef;
+            // geometry that the reference stores even for Gaussians it drops later is irrelevant: nothing reads it
+            const float cx = c.cov2[0], cy = c.cov2[1], cz = c.cov2[2];
+            const float det = cx * cz - cy * cy;
+            if (det == 0.0f) break;
+            const float det_inv = 1.f / det;
+            const float3 conic = make_float3(cz * det_inv, -cy * det_inv, cx * det_inv);
+            const float mid = 0.5f * (cx + cz);
+            const float lambda1 = mid + sqrtf(fmaxf(0.1f, mid * mid - det));
+            const float lambda2 = mid - sqrtf(fmaxf(0.1f, mid * mid - det));
+            const float my_radius = ceilf(3.f * sqrtf(fmaxf(lambda1, lambda2)));
+            // ndc2Pix (auxiliary.h:57-60) is evaluated in double
+            const float pix = (float)((((double)ppx + 1.0) * (double)p.W - 1.0) * 0.5);
+            const float piy = (float)((((double)ppy + 1.0) * (double)p.H - 1.0) * 0.5);
+            int x0, y0, x1, y1;
+            get_rect(pix, piy, (int)my_radius, p.gx, p.gy, x0, y0, x1, y1);
+            if ((x1 - x0) * (y1 - y0) == 0) break;
+            float3 rgb = make_float3(0, 0, 0);
+            uint32_t clamped = 0;
+            if (p.colors_precomp == nullptr) {
+                float3 dir = p_orig - make_float3(p.campos[0], p.campos[1], p.campos[2]);
+                const float len = sqrtf(dot3(dir, dir));
+                dir = make_float3(dir.x / len, dir.y / len, dir.z / len);
+                rgb = sh_to_rgb(p.D, p.shs + (size_t)idx * p.M * 3, dir, clamped);
+            } else {
+                rgb = make_float3(p.colors_precomp[3 * idx], p.colors_precomp[3 * idx + 1], p.colors_precomp[3 * idx + 2]);
+            }
+            radius = (int)my_radius;
+            my_tiles = (uint32_t)((y1 - y0) * (x1 - x0));
+            dkey = __float_as_uint(p_view.z);
+            R4[0] = make_float4(pix, piy, conic.x, conic.y);
+            R4[1] = make_float4(conic.z, p.opacities[idx] * coef, rgb.x, rgb.y);
+            R4[2] = make_float4(rgb.z, ts, rp[0], rp[1]);
+            R4[3] = make_float4(p_view.x, p_view.y, p_view.z, nrm.x);
+            R4[4] = make_float4(cp[0], cp[1], cp[2], cp[3]);
+            R4[5] = make_float4(cp[4], cp[5], nrm.y, nrm.z);
+            R4[6] = make_float4(cov3D[0], cov3D[1], cov3D[2], cov3D[3]);
+            R4[7] = make_float4(cov3D[4], cov3D[5], __uint_as_float(clamped), __uint_as_float(dkey));
+        } while (0);
+        radii[idx] = radius;
+        tiles[idx] = my_tiles;
+        depth_keys[idx] = dkey;
+        ident[idx] = (uint32_t)idx;
+    }
+    // total instance count: wave reduction, one atomic per wave that has something to add
+    uint32_t v = my_tiles;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    if ((threadIdx.x & 63) == 0 && v) atomicAdd(&counters[0], v);
+}
+
+hipError_t launch_preprocess_fwd(hipStream_t s, const FwdParams& p, float* rec, uint32_t* tiles, uint32_t* depth_keys,
+                                 uint32_t* ident, int* radii, uint32_t* counters)
+{
+    PreArgs a; a.p = p;
+    hipLaunchKernelGGL(preprocess_fwd_kernel, dim3((p.P + 255) / 256), dim3(256), 0, s, a, rec, tiles, depth_keys, ident, radii, counters);
+    return hipGetLastError();
+}
+
+__global__ void mark_visible_kernel(int P, const float* __restrict__ means3D, const float* __restrict__ view, uint8_t* __restrict__ present)
+{
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= P) return;
+    const float3 pv = xform4x3(make_float3(means3D[3 * idx], means3D[3 * idx + 1], means3D[3 * idx + 2]), view);
+    present[idx] = pv.z <= 0.2f ? 0 : 1;
+}
+hipError_t launch_mark_visible(hipStream_t s, int P, const float* means3D, const float* view, uint8_t* present)
+{
+    hipLaunchKernelGGL(mark_visible_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, means3D, view, present);
+    return hipGetLastError();
+}

@@ -1,0 +1,78 @@
+// refine_ops.hip -- bandwidth-bound helpers of the per-frame refine loop (gfx950): fused Adam step and fused L1
+// loss forward+backward.  Counterparts in the reference are plain PyTorch: torch.optim.Adam(lr=0, eps=1e-15) built in
+// GaussianModel.load_fromstream (igs/models/gaussian_model.py:295-348) and l1_loss (igs/utils/loss_utils.py:17-18).
+#include "common.h"
+#include "../../include/igs_rast.h"
+
+// torch.optim.Adam semantics (no weight decay, no amsgrad):
+//   m = b1*m + (1-b1)*g ; v = b2*v + (1-b2)*g*g ; p -= (lr/bc1) * m / (sqrt(v)/sqrt(bc2) + eps)
+__global__ void __launch_bounds__(256)
+adam_kernel(size_t n4, size_t n, float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+            float lr_over_bc1, float b1, float b2, float eps, float inv_sqrt_bc2)
+{
+    const size_t stride = (size_t)gridDim.x * 256;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+        float4 P4 = ((float4*)p)[i], M4 = ((float4*)m)[i], V4 = ((float4*)v)[i];
+        const float4 G4 = ((const float4*)g)[i];
+        float* pp = (float*)&P4; float* mm = (float*)&M4; float* vv = (float*)&V4; const float* gg = (const float*)&G4;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            mm[k] = b1 * mm[k] + (1.f - b1) * gg[k];
+            vv[k] = b2 * vv[k] + (1.f - b2) * gg[k] * gg[k];
+            pp[k] -= lr_over_bc1 * mm[k] / (sqrtf(vv[k]) * inv_sqrt_bc2 + eps);
+        }
+        ((float4*)p)[i] = P4; ((float4*)m)[i] = M4; ((float4*)v)[i] = V4;
+    }
+    // tail
+    for (size_t i = n4 * 4 + (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+        const float gi = g[i];
+        const float mi = b1 * m[i] + (1.f - b1) * gi;
+        const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+        m[i] = mi; v[i] = vi;
+        p[i] -= lr_over_bc1 * mi / (sqrtf(vi) * inv_sqrt_bc2 + eps);
+    }
+}
+
+extern "C" int igs_adam_step(void* stream, size_t n, float* param, const float* grad, float* exp_avg, float* exp_avg_sq,
+                             float lr, float beta1, float beta2, float eps, float bias_correction1, float bias_correction2_sqrt)
+{
+    if (n == 0) return 0;
+    if (!param || !grad || !exp_avg || !exp_avg_sq) return IGS_RAST_E_INVALID;
+    const bool aligned = (((uintptr_t)param | (uintptr_t)grad | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) & 15) == 0;
+    const size_t n4 = aligned ? n / 4 : 0;
+    size_t blocks = (n / 4 + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    if (blocks == 0) blocks = 1;
+    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, n4, n, param, grad, exp_avg, exp_avg_sq,
+                       lr / bias_correction1, beta1, beta2, eps, 1.0f / bias_correction2_sqrt);
+    return hipGetLastError() == hipSuccess ? 0 : IGS_RAST_E_HIP;
+}
+
+// L1: loss_sum += sum |pred - gt| ; grad = sign(pred - gt) * scale        (mean => scale = upstream / n)
+__global__ void __launch_bounds__(256)
+l1_kernel(size_t n, const float* __restrict__ pred, const float* __restrict__ gt, float* __restrict__ grad, float* __restrict__ loss_sum, float scale)
+{
+    __shared__ float ws[4];
+    const size_t stride = (size_t)gridDim.x * 256;
+    float acc = 0.f;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+        const float d = pred[i] - gt[i];
+        acc += fabsf(d);
+        grad[i] = d > 0.f ? scale : (d < 0.f ? -scale : 0.f);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+    if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(loss_sum, ws[0] + ws[1] + ws[2] + ws[3]);
+}
+
+extern "C" int igs_l1_loss_fwd_bwd(void* stream, size_t n, const float* pred, const float* gt, float* grad, float* loss_sum, float scale)
+{
+    if (n == 0) return 0;
+    if (!pred || !gt || !grad || !loss_sum) return IGS_RAST_E_INVALID;
+    size_t blocks = (n + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(l1_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, n, pred, gt, grad, loss_sum, scale);
+    return hipGetLastError() == hipSuccess ? 0 : IGS_RAST_E_HIP;
+}

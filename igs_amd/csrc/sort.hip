@@ -1,0 +1,246 @@
+// sort.hip -- binning stage for gfx950: stable LSD radix sort, instance emission, tile ranges.
+//
+// The reference builds 64-bit (tile | depth) keys for every (Gaussian, tile) instance and sorts all R of them with
+// cub::DeviceRadixSort over 32+log2(T) bits (rasterizer_impl.cu:70-111, 373-381): 6 passes over 12-byte pairs at
+// 1352x1014.  Here the same ORDER is produced with far less traffic:
+//   1. sort the P Gaussians by depth bits (32-bit keys, 4 passes over P pairs);
+//   2. emit the instances in that order (coalesced, load-balanced: a block of 256 Gaussians scatters its instances
+//      cooperatively instead of one thread looping over its tiles);
+//   3. stable-sort the R instances by tile id only (ceil(log2 T / 8) = 2 passes over 8-byte pairs).
+// Stability of every pass makes the result identical to a stable sort on (tile, depth) with ties in Gaussian-index
+// order, which is what the reference's stable LSD sort yields.
+#include "common.h"
+
+#define RADIX 256
+
+__device__ __forceinline__ uint32_t digit_of(uint32_t key, int shift, uint32_t mask) { return (key >> shift) & mask; }
+
+// ---- pass 1: per-block digit histogram, digit-major layout hist[d * nb + b] ----
+__global__ void __launch_bounds__(256)
+radix_hist_kernel(const uint32_t* __restrict__ keys, uint32_t n, uint32_t per_block, int shift, uint32_t mask, uint32_t* __restrict__ hist)
+{
+    __shared__ uint32_t h[RADIX];
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t beg = blockIdx.x * per_block;
+    const uint32_t end = min(n, beg + per_block);
+    for (uint32_t e = beg + threadIdx.x; e < end; e += 256) atomicAdd(&h[digit_of(keys[e], shift, mask)], 1u);
+    __syncthreads();
+    hist[threadIdx.x * gridDim.x + blockIdx.x] = h[threadIdx.x];
+}
+
+// ---- single-block exclusive scan (in place) of up to a few 100k uint32; also returns the total in *total if given ----
+__global__ void __launch_bounds__(1024)
+exclusive_scan_kernel(uint32_t* __restrict__ data, uint32_t n, uint32_t* __restrict__ total)
+{
+    __shared__ uint32_t wave_sums[16];
+    __shared__ uint32_t carry_s;
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const uint32_t per = (n + 1023) / 1024;
+    const uint32_t beg = min(n, tid * per), end = min(n, beg + per);
+    uint32_t sum = 0;
+    for (uint32_t i = beg; i < end; i++) sum += data[i];
+    // inclusive scan of `sum` across the 1024 threads
+    uint32_t v = sum;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) { uint32_t t = __shfl_up(v, off, 64); if (lane >= (uint32_t)off) v += t; }
+    if (lane == 63) wave_sums[wid] = v;
+    __syncthreads();
+    if (tid == 0) { uint32_t c = 0; for (int w = 0; w < 16; w++) { uint32_t t = wave_sums[w]; wave_sums[w] = c; c += t; } carry_s = c; }
+    __syncthreads();
+    uint32_t run = v - sum + wave_sums[wid];
+    for (uint32_t i = beg; i < end; i++) { uint32_t t = data[i]; data[i] = run; run += t; }
+    if (total && tid == 0) *total = carry_s;
+}
+
+// ---- pass 3: stable scatter ----
+__global__ void __launch_bounds__(256)
+radix_scatter_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in, uint32_t* __restrict__ keys_out,
+                     uint32_t* __restrict__ vals_out, uint32_t n, uint32_t per_block, int shift, uint32_t mask,
+                     const uint32_t* __restrict__ hist)
+{
+    __shared__ uint32_t wave_cnt[4][RADIX];
+    __shared__ uint32_t base[RADIX];
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const uint64_t lt_mask = (1ull << lane) - 1ull;
+    base[tid] = hist[tid * gridDim.x + blockIdx.x];
+    const uint32_t beg = blockIdx.x * per_block;
+    const uint32_t end = min(n, beg + per_block);
+    for (uint32_t sub = beg; sub < end; sub += SORT_TILE) {
+#pragma unroll
+        for (int w = 0; w < 4; w++) wave_cnt[w][tid] = 0;
+        __syncthreads();
+        uint32_t key[SORT_ITEMS], val[SORT_ITEMS], rank[SORT_ITEMS];
+        const uint32_t e0 = sub + wid * (SORT_ITEMS * 64) + lane;
+#pragma unroll
+        for (int i = 0; i < SORT_ITEMS; i++) {
+            const uint32_t e = e0 + i * 64;
+            const bool valid = e < end;
+            key[i] = valid ? keys_in[e] : 0xFFFFFFFFu;
+            val[i] = valid ? vals_in[e] : 0u;
+        }
+#pragma unroll
+        for (int i = 0; i < SORT_ITEMS; i++) {
+            const uint32_t e = e0 + i * 64;
+            const bool valid = e < end;
+            const uint32_t d = digit_of(key[i], shift, mask);
+            uint64_t peers = __ballot(valid);
+#pragma unroll
+            for (int b = 0; b < 8; b++) {
+                const bool bit = (d >> b) & 1u;
+                const uint64_t bal = __ballot(bit);
+                peers &= bit ? bal : ~bal;
+            }
+            const uint32_t r = __popcll(peers & lt_mask);
+            uint32_t old = 0;
+            if (valid) {
+                old = wave_cnt[wid][d];                       // every peer reads before the leader updates
+                if (r == 0) wave_cnt[wid][d] = old + __popcll(peers);
+            }
+            rank[i] = old + r;
+        }
+        __syncthreads();
+        {   // digit `tid`: turn per-wave counts into per-wave bases, advance the running base
+            uint32_t run = base[tid];
+#pragma unroll
+            for (int w = 0; w < 4; w++) { const uint32_t t = wave_cnt[w][tid]; wave_cnt[w][tid] = run; run += t; }
+            base[tid] = run;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < SORT_ITEMS; i++) {
+            const uint32_t e = e0 + i * 64;
+            if (e < end) {
+                const uint32_t pos = wave_cnt[wid][digit_of(key[i], shift, mask)] + rank[i];
+                keys_out[pos] = key[i];
+                vals_out[pos] = val[i];
+            }
+        }
+        __syncthreads();
+    }
+}
+
+hipError_t radix_sort_pairs(hipStream_t s, uint32_t n, uint32_t* keys_a, uint32_t* keys_b, uint32_t* vals_a, uint32_t* vals_b,
+                            uint32_t* hist, int bit_lo, int bit_hi, uint32_t** out_keys, uint32_t** out_vals)
+{
+    uint32_t *kin = keys_a, *kout = keys_b, *vin = vals_a, *vout = vals_b;
+    if (n > 0) {
+        uint32_t nb = (n + SORT_TILE - 1) / SORT_TILE;
+        if (nb > SORT_MAX_BLOCKS) nb = SORT_MAX_BLOCKS;
+        uint32_t per = (n + nb - 1) / nb;
+        per = (per + SORT_TILE - 1) / SORT_TILE * SORT_TILE;
+        nb = (n + per - 1) / per;
+        for (int lo = bit_lo; lo < bit_hi; lo += 8) {
+            const int nbits = (bit_hi - lo) < 8 ? (bit_hi - lo) : 8;
+            const uint32_t mask = (1u << nbits) - 1u;
+            hipLaunchKernelGGL(radix_hist_kernel, dim3(nb), dim3(256), 0, s, kin, n, per, lo, mask, hist);
+            hipLaunchKernelGGL(exclusive_scan_kernel, dim3(1), dim3(1024), 0, s, hist, (uint32_t)(RADIX * nb), (uint32_t*)nullptr);
+            hipLaunchKernelGGL(radix_scatter_kernel, dim3(nb), dim3(256), 0, s, kin, vin, kout, vout, n, per, lo, mask, hist);
+            uint32_t* t = kin; kin = kout; kout = t;
+            t = vin; vin = vout; vout = t;
+        }
+    }
+    *out_keys = kin; *out_vals = vin;
+    return hipGetLastError();
+}
+
+// ---- instance counts in depth order: blocksum[b] = sum over sorted positions [256b, 256b+256) of tiles[order[s]] ----
+__global__ void __launch_bounds__(256)
+count_sorted_kernel(int P, const uint32_t* __restrict__ order, const uint32_t* __restrict__ tiles, uint32_t* __restrict__ blocksum)
+{
+    __shared__ uint32_t ws[4];
+    const int s = blockIdx.x * 256 + threadIdx.x;
+    uint32_t v = (s < P) ? tiles[order[s]] : 0u;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) blocksum[blockIdx.x] = ws[0] + ws[1] + ws[2] + ws[3];
+}
+hipError_t launch_count_sorted(hipStream_t s, int P, const uint32_t* order, const uint32_t* tiles, uint32_t* blocksum)
+{
+    hipLaunchKernelGGL(count_sorted_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, order, tiles, blocksum);
+    return hipGetLastError();
+}
+hipError_t launch_scan_blocksums(hipStream_t s, int nblocks, uint32_t* blocksum)
+{
+    hipLaunchKernelGGL(exclusive_scan_kernel, dim3(1), dim3(1024), 0, s, blocksum, (uint32_t)nblocks, (uint32_t*)nullptr);
+    return hipGetLastError();
+}
+
+// ---- emission: a block owns 256 depth-consecutive Gaussians and writes all their (tile, id) pairs cooperatively ----
+__global__ void __launch_bounds__(256)
+emit_instances_kernel(int P, int gx, int gy, const uint32_t* __restrict__ order, const uint32_t* __restrict__ tiles,
+                      const uint32_t* __restrict__ blocksum, const float* __restrict__ rec, const int* __restrict__ radii,
+                      uint32_t* __restrict__ tile_keys, uint32_t* __restrict__ vals)
+{
+    __shared__ uint32_t incl[256];     // inclusive scan of instance counts
+    __shared__ uint32_t gid[256];
+    __shared__ int rx0[256], ry0[256], rw[256];
+    __shared__ uint32_t ws[4];
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int s = blockIdx.x * 256 + tid;
+    uint32_t cnt = 0, g = 0;
+    int x0 = 0, y0 = 0, x1 = 0, y1 = 0;
+    if (s < P) {
+        g = order[s];
+        cnt = tiles[g];
+        if (cnt) {
+            const float2 xy = *(const float2*)(rec + (size_t)g * REC_F);
+            get_rect(xy.x, xy.y, radii[g], gx, gy, x0, y0, x1, y1);    // same call as the reference's duplicateWithKeys
+        }
+    }
+    uint32_t v = cnt;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) { uint32_t t = __shfl_up(v, off, 64); if (lane >= (uint32_t)off) v += t; }
+    if (lane == 63) ws[wid] = v;
+    __syncthreads();
+    uint32_t woff = 0;
+    for (uint32_t w = 0; w < wid; w++) woff += ws[w];
+    const uint32_t total = ws[0] + ws[1] + ws[2] + ws[3];
+    incl[tid] = v + woff;
+    gid[tid] = g; rx0[tid] = x0; ry0[tid] = y0; rw[tid] = x1 - x0;
+    __syncthreads();
+    const uint32_t base = blocksum[blockIdx.x];
+    for (uint32_t k = tid; k < total; k += 256) {
+        // smallest j with incl[j] > k
+        uint32_t lo = 0, hi = 255;
+#pragma unroll
+        for (int it = 0; it < 8; it++) { const uint32_t mid = (lo + hi) >> 1; if (incl[mid] > k) hi = mid; else lo = mid + 1; }
+        const uint32_t j = lo;
+        const uint32_t local = k - (j ? incl[j - 1] : 0u);
+        const int w = rw[j];
+        const int ty = ry0[j] + (int)(local / (uint32_t)w), tx = rx0[j] + (int)(local % (uint32_t)w);
+        tile_keys[base + k] = (uint32_t)(ty * gx + tx);
+        vals[base + k] = gid[j];
+    }
+}
+hipError_t launch_emit_instances(hipStream_t s, int P, int gx, int gy, const uint32_t* order, const uint32_t* tiles,
+                                 const uint32_t* blocksum, const float* rec, const int* radii, uint32_t* tile_keys,
+                                 uint32_t* vals)
+{
+    hipLaunchKernelGGL(emit_instances_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, gx, gy, order, tiles, blocksum, rec,
+                       radii, tile_keys, vals);
+    return hipGetLastError();
+}
+
+// ---- per-tile [start,end) in the sorted list (identifyTileRanges, rasterizer_impl.cu:151-173; ranges pre-zeroed) ----
+__global__ void __launch_bounds__(256)
+tile_ranges_kernel(uint32_t R, const uint32_t* __restrict__ tile_keys, uint32_t* __restrict__ ranges)
+{
+    const uint32_t idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= R) return;
+    const uint32_t cur = tile_keys[idx];
+    if (idx == 0) ranges[2 * cur] = 0;
+    else {
+        const uint32_t prev = tile_keys[idx - 1];
+        if (cur != prev) { ranges[2 * prev + 1] = idx; ranges[2 * cur] = idx; }
+    }
+    if (idx == R - 1) ranges[2 * cur + 1] = R;
+}
+hipError_t launch_tile_ranges(hipStream_t s, uint32_t R, const uint32_t* tile_keys, uint32_t* ranges)
+{
+    if (R == 0) return hipSuccess;
+    hipLaunchKernelGGL(tile_ranges_kernel, dim3((R + 255) / 256), dim3(256), 0, s, R, tile_keys, ranges);
+    return hipGetLastError();
+}

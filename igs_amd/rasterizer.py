@@ -1,0 +1,347 @@
+"""Host-side mirror of the reference's rasterizer binding, on top of the C ABI (include/igs_rast.h).
+
+Layers (reference file:line in parentheses; DGR = submodules/RaDe-GS/submodules/diff-gaussian-rasterization):
+  * `_C`-level functions `rasterize_gaussians`, `rasterize_gaussians_backward`, `mark_visible`,
+    `integrate_gaussians_to_points` with the positional signatures of DGR/rasterize_points.h:18-107
+    (what DGR/ext.cpp:15-20 exports);
+  * `_RasterizeGaussians`, `GaussianRasterizationSettings`, `GaussianRasterizer`, `rasterize_gaussians_autograd`
+    = DGR/diff_gaussian_rasterization_rade/__init__.py:21-243, same field order, argument validation messages,
+    saved tensors and 8-tuple output order `(color, radii, coord, mcoord, depth, mdepth, alpha, normal)`.
+
+torch is used for device memory and the current stream only; all arithmetic runs in libigs_rast.so.
+There is no CPU path: calling these functions without the HIP library / a GPU raises.
+"""
+import ctypes as C
+from typing import NamedTuple
+
+import torch
+import torch.nn as nn
+
+from . import _cabi
+
+
+class RasterizerError(RuntimeError):
+    pass
+
+
+def _ptr(t):
+    """Device pointer or NULL for the reference's "empty tensor" convention (data_ptr()==nullptr)."""
+    if t is None or t.numel() == 0:
+        return None
+    return t.data_ptr()
+
+
+def _prep(t, device, what):
+    if t is None or t.numel() == 0:
+        return None
+    if t.device != device:
+        raise RasterizerError("%s must live on %s (got %s)" % (what, device, t.device))
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t.contiguous()
+
+
+class _Scratch:
+    """uint8 tensor grown on demand by the library (rasterize_points.cu:27-33, resizeFunctional)."""
+
+    def __init__(self, device):
+        self.device = device
+        self.tensor = torch.empty(0, dtype=torch.uint8, device=device)
+        self.cb = _cabi.ALLOC_FN(self._alloc)
+
+    def _alloc(self, _user, nbytes):
+        try:
+            self.tensor = torch.empty(int(nbytes), dtype=torch.uint8, device=self.device)
+            return self.tensor.data_ptr()
+        except Exception:  # noqa: BLE001  (an exception must not cross the C frame)
+            return None
+
+
+def _check(rc, what):
+    if rc < 0:
+        raise RasterizerError("%s failed (%d): %s" % (what, rc, _cabi.last_error()))
+    return rc
+
+
+def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp, viewmatrix,
+                        projmatrix, tan_fovx, tan_fovy, kernel_size, image_height, image_width, sh, degree, campos,
+                        prefiltered, require_coord, require_depth, debug):
+    """`_C.rasterize_gaussians` (RasterizeGaussiansCUDA, DGR/rasterize_points.cu:35-133).
+
+    Returns (num_rendered, color, coord, mcoord, alpha, normal, depth, mdepth, radii, geomBuffer, binningBuffer, imgBuffer)."""
+    if means3D.dim() != 2 or means3D.size(1) != 3:
+        raise RasterizerError("means3D must have dimensions (num_points, 3)")
+    if not means3D.is_cuda:
+        raise RasterizerError("igs_amd rasterizer: tensors must be on a GPU (no CPU fallback)")
+    L = _cabi.lib()
+    dev = means3D.device
+    P, H, W = means3D.size(0), int(image_height), int(image_width)
+    with torch.cuda.device(dev):
+        means3D_c = _prep(means3D, dev, "means3D")
+        colors_c, opacity_c, scales_c, rotations_c = (_prep(colors, dev, "colors_precomp"), _prep(opacity, dev, "opacities"),
+                                                      _prep(scales, dev, "scales"), _prep(rotations, dev, "rotations"))
+        cov_c, sh_c = _prep(cov3D_precomp, dev, "cov3D_precomp"), _prep(sh, dev, "shs")
+        bg_c, view_c, proj_c, campos_c = (_prep(background, dev, "bg"), _prep(viewmatrix, dev, "viewmatrix"),
+                                          _prep(projmatrix, dev, "projmatrix"), _prep(campos, dev, "campos"))
+        M = sh_c.size(1) if sh_c is not None else 0
+        # one allocation for the seven images; every pixel is written by the kernels when P > 0
+        imgs = (torch.empty if P > 0 else torch.zeros)((15, H, W), dtype=torch.float32, device=dev)
+        color, coord, mcoord = imgs[0:3], imgs[3:6], imgs[6:9]
+        depth, mdepth, alpha, normal = imgs[9:10], imgs[10:11], imgs[11:12], imgs[12:15]
+        radii = torch.empty((P,), dtype=torch.int32, device=dev) if P > 0 else torch.zeros((0,), dtype=torch.int32, device=dev)
+        geom, binning, img = _Scratch(dev), _Scratch(dev), _Scratch(dev)
+        rendered = 0
+        if P != 0:
+            stream = torch.cuda.current_stream(dev).cuda_stream
+            rendered = L.igs_rast_forward(
+                stream, geom.cb, None, binning.cb, None, img.cb, None, P, int(degree), M, _ptr(bg_c), W, H,
+                _ptr(means3D_c), _ptr(sh_c), _ptr(colors_c), _ptr(opacity_c), _ptr(scales_c), float(scale_modifier),
+                _ptr(rotations_c), _ptr(cov_c), _ptr(view_c), _ptr(proj_c), _ptr(campos_c), float(tan_fovx), float(tan_fovy),
+                float(kernel_size), int(bool(prefiltered)), _ptr(color), _ptr(coord), _ptr(mcoord), _ptr(depth), _ptr(mdepth),
+                _ptr(alpha), _ptr(normal), _ptr(radii), int(bool(require_coord)), int(bool(require_depth)), int(bool(debug)))
+            _check(rendered, "igs_rast_forward")
+    return (rendered, color, coord, mcoord, alpha, normal, depth, mdepth, radii, geom.tensor, binning.tensor, img.tensor)
+
+
+def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rotations, scale_modifier, cov3D_precomp,
+                                 viewmatrix, projmatrix, tan_fovx, tan_fovy, kernel_size, dL_dout_color, dL_dout_coord,
+                                 dL_dout_mcoord, dL_dout_depth, dL_dout_mdepth, dL_dout_alpha, dL_dout_normal, normalmap, sh,
+                                 degree, campos, geomBuffer, R, binningBuffer, imageBuffer, alphas, require_coord,
+                                 require_depth, debug):
+    """`_C.rasterize_gaussians_backward` (RasterizeGaussiansBackwardCUDA, DGR/rasterize_points.cu:135-246).
+
+    Returns (dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations)."""
+    L = _cabi.lib()
+    dev = means3D.device
+    P = means3D.size(0)
+    H, W = dL_dout_color.size(1), dL_dout_color.size(2)
+    with torch.cuda.device(dev):
+        sh_c = _prep(sh, dev, "shs")
+        M = sh_c.size(1) if sh_c is not None else 0
+        f32 = dict(dtype=torch.float32, device=dev)
+        alloc = torch.empty if P > 0 else torch.zeros
+        dL_dsh = alloc((P, M, 3), **f32)
+        # one allocation for the other per-Gaussian gradients, carved into dense [P,k] arrays:
+        # m2d 3 | colors 3 | opacity 1 | means3D 3 | cov3D 6 | scales 3 | rot 4
+        block = alloc((23 * P,), **f32)
+        o = 0
+        def carve(k):
+            nonlocal o
+            t = block[o:o + k * P].view(P, k)
+            o += k * P
+            return t
+        dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D = carve(3), carve(3), carve(1), carve(3)
+        dL_dcov3D, dL_dscales, dL_drotations = carve(6), carve(3), carve(4)
+        if P != 0:
+            means3D_c = _prep(means3D, dev, "means3D")
+            colors_c, scales_c, rotations_c, cov_c = (_prep(colors, dev, "colors_precomp"), _prep(scales, dev, "scales"),
+                                                      _prep(rotations, dev, "rotations"), _prep(cov3D_precomp, dev, "cov3D_precomp"))
+            bg_c, view_c, proj_c, campos_c = (_prep(background, dev, "bg"), _prep(viewmatrix, dev, "viewmatrix"),
+                                              _prep(projmatrix, dev, "projmatrix"), _prep(campos, dev, "campos"))
+            grads = [_prep(g, dev, "grad") for g in (dL_dout_color, dL_dout_coord, dL_dout_mcoord, dL_dout_depth,
+                                                     dL_dout_mdepth, dL_dout_alpha, dL_dout_normal)]
+            alphas_c, normal_c = _prep(alphas, dev, "alphas"), _prep(normalmap, dev, "normalmap")
+            radii_c = radii.contiguous()
+            ws = torch.empty(L.igs_rast_backward_workspace_bytes(P), dtype=torch.uint8, device=dev)
+            stream = torch.cuda.current_stream(dev).cuda_stream
+            rc = L.igs_rast_backward(
+                stream, P, int(degree), M, int(R), _ptr(bg_c), W, H, _ptr(means3D_c), _ptr(sh_c), _ptr(colors_c), _ptr(alphas_c),
+                _ptr(scales_c), float(scale_modifier), _ptr(rotations_c), _ptr(cov_c), _ptr(view_c), _ptr(proj_c), _ptr(campos_c),
+                float(tan_fovx), float(tan_fovy), float(kernel_size), _ptr(radii_c), _ptr(normal_c), _ptr(geomBuffer),
+                _ptr(binningBuffer), _ptr(imageBuffer), *[_ptr(g) for g in grads], _ptr(ws),
+                _ptr(dL_dmeans2D), _ptr(dL_dcolors), _ptr(dL_dopacity), _ptr(dL_dmeans3D), _ptr(dL_dcov3D), _ptr(dL_dsh),
+                _ptr(dL_dscales), _ptr(dL_drotations), int(bool(require_coord)), int(bool(require_depth)), int(bool(debug)))
+            _check(rc, "igs_rast_backward")
+    return (dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations)
+
+
+def mark_visible(means3D, viewmatrix, projmatrix):
+    """`_C.mark_visible` (DGR/rasterize_points.cu:248-267)."""
+    L = _cabi.lib()
+    if not means3D.is_cuda:
+        raise RasterizerError("igs_amd rasterizer: tensors must be on a GPU (no CPU fallback)")
+    dev = means3D.device
+    P = means3D.size(0)
+    present = torch.zeros((P,), dtype=torch.bool, device=dev)
+    if P != 0:
+        with torch.cuda.device(dev):
+            m, v, p = _prep(means3D, dev, "means3D"), _prep(viewmatrix, dev, "viewmatrix"), _prep(projmatrix, dev, "projmatrix")
+            _check(L.igs_rast_mark_visible(torch.cuda.current_stream(dev).cuda_stream, P, _ptr(m), _ptr(v), _ptr(p),
+                                           present.data_ptr()), "igs_rast_mark_visible")
+    return present
+
+
+def integrate_gaussians_to_points(*_args, **_kw):
+    """`_C.integrate_gaussians_to_points` (GOF tetrahedra integration, DGR/rasterize_points.cu:269-387) is mesh-extraction
+    only and never reached from IGS (out of scope)."""
+    raise NotImplementedError("integrate_gaussians_to_points is outside the IGS hot path and is not implemented")
+
+
+def debug_dump(P, R, W, H, geomBuffer, binningBuffer, imgBuffer):
+    """Per-stage scratch contents as torch tensors (tests / roofline harness)."""
+    L = _cabi.lib()
+    dev = geomBuffer.device
+    T = ((W + 15) // 16) * ((H + 15) // 16)
+    with torch.cuda.device(dev):
+        rec = torch.zeros((P, 32), dtype=torch.float32, device=dev)
+        tiles = torch.zeros((P,), dtype=torch.int32, device=dev)
+        pl = torch.zeros((R,), dtype=torch.int32, device=dev)
+        ranges = torch.zeros((T, 2), dtype=torch.int32, device=dev)
+        nc = torch.zeros((2, H, W), dtype=torch.int32, device=dev)
+        _check(L.igs_rast_debug_dump(torch.cuda.current_stream(dev).cuda_stream, P, R, W, H, _ptr(geomBuffer), _ptr(binningBuffer),
+                                     _ptr(imgBuffer), rec.data_ptr(), tiles.data_ptr(), _ptr(pl), ranges.data_ptr(), nc.data_ptr()),
+               "igs_rast_debug_dump")
+    return dict(rec=rec, tiles_touched=tiles, point_list=pl, ranges=ranges, n_contrib=nc)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# autograd binding: DGR/diff_gaussian_rasterization_rade/__init__.py
+# ---------------------------------------------------------------------------------------------------------------
+def cpu_deep_copy_tuple(input_tuple):
+    return tuple(item.cpu().clone() if isinstance(item, torch.Tensor) else item for item in input_tuple)
+
+
+def _make_function(clamp_grads):
+    class _RasterizeGaussians(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings):
+            args = (raster_settings.bg, means3D, colors_precomp, opacities, scales, rotations, raster_settings.scale_modifier,
+                    cov3Ds_precomp, raster_settings.viewmatrix, raster_settings.projmatrix, raster_settings.tanfovx,
+                    raster_settings.tanfovy, raster_settings.kernel_size, raster_settings.image_height,
+                    raster_settings.image_width, sh, raster_settings.sh_degree, raster_settings.campos,
+                    raster_settings.prefiltered, raster_settings.require_coord, raster_settings.require_depth,
+                    raster_settings.debug)
+            if raster_settings.debug:
+                cpu_args = cpu_deep_copy_tuple(args)
+                try:
+                    out = rasterize_gaussians(*args)
+                except Exception as ex:
+                    torch.save(cpu_args, "snapshot_fw.dump")
+                    print("\nAn error occured in forward. Please forward snapshot_fw.dump for debugging.")
+                    raise ex
+            else:
+                out = rasterize_gaussians(*args)
+            num_rendered, color, coord, mcoord, alpha, normal, depth, mdepth, radii, geomBuffer, binningBuffer, imgBuffer = out
+            ctx.raster_settings = raster_settings
+            ctx.num_rendered = num_rendered
+            ctx.save_for_backward(colors_precomp, means3D, scales, rotations, cov3Ds_precomp, normal, radii, sh, geomBuffer,
+                                  binningBuffer, imgBuffer, alpha)
+            ctx.mark_non_differentiable(radii)
+            return color, radii, coord, mcoord, depth, mdepth, alpha, normal
+
+        @staticmethod
+        def backward(ctx, grad_color, grad_radii, grad_coord, grad_mcoord, grad_depth, grad_mdepth, grad_alpha, grad_normal):
+            num_rendered = ctx.num_rendered
+            raster_settings = ctx.raster_settings
+            (colors_precomp, means3D, scales, rotations, cov3Ds_precomp, normal, radii, sh, geomBuffer, binningBuffer, imgBuffer,
+             alpha) = ctx.saved_tensors
+            H, W = raster_settings.image_height, raster_settings.image_width
+
+            def z(g, c):   # autograd hands None for outputs that did not take part in the loss
+                return g if g is not None else torch.zeros((c, H, W), dtype=torch.float32, device=means3D.device)
+
+            args = (raster_settings.bg, means3D, radii, colors_precomp, scales, rotations, raster_settings.scale_modifier,
+                    cov3Ds_precomp, raster_settings.viewmatrix, raster_settings.projmatrix, raster_settings.tanfovx,
+                    raster_settings.tanfovy, raster_settings.kernel_size, z(grad_color, 3), z(grad_coord, 3), z(grad_mcoord, 3),
+                    z(grad_depth, 1), z(grad_mdepth, 1), z(grad_alpha, 1), z(grad_normal, 3), normal, sh,
+                    raster_settings.sh_degree, raster_settings.campos, geomBuffer, num_rendered, binningBuffer, imgBuffer, alpha,
+                    raster_settings.require_coord, raster_settings.require_depth, raster_settings.debug)
+            if raster_settings.debug:
+                cpu_args = cpu_deep_copy_tuple(args)
+                try:
+                    out = rasterize_gaussians_backward(*args)
+                except Exception as ex:
+                    torch.save(cpu_args, "snapshot_bw.dump")
+                    print("\nAn error occured in backward. Writing snapshot_bw.dump for debugging.\n")
+                    raise ex
+            else:
+                out = rasterize_gaussians_backward(*args)
+            grad_means2D, grad_colors_precomp, grad_opacities, grad_means3D, grad_cov3Ds_precomp, grad_sh, grad_scales, grad_rotations = out
+            if clamp_grads:     # DGRC/diff_gaussian_rasterization_rade_clamp/__init__.py:156-162
+                grad_means3D = torch.clamp(grad_means3D, -15, 15)
+                grad_sh = torch.clamp(grad_sh, -15, 15)
+                grad_opacities = torch.clamp(grad_opacities, -15, 15)
+                grad_scales = torch.clamp(grad_scales, -15, 15)
+                grad_rotations = torch.clamp(grad_rotations, -15, 15)
+            if NAN_CHECKS:
+                # the reference does 7 separate `.any()` host syncs (__init__.py:156-162); one fused check here
+                bad = torch.stack([torch.isnan(g).any() for g in (grad_means3D, grad_means2D, grad_sh, grad_colors_precomp,
+                                                                 grad_opacities, grad_scales, grad_rotations)])
+                assert not bool(bad.any())
+            # shapes autograd expects: the gradient of an absent (empty CPU) input is None
+            def m(g, ref):
+                return g if (ref is not None and ref.numel() > 0) else None
+            return (grad_means3D, grad_means2D, m(grad_sh, sh), m(grad_colors_precomp, colors_precomp), grad_opacities,
+                    m(grad_scales, scales), m(grad_rotations, rotations), m(grad_cov3Ds_precomp, cov3Ds_precomp), None)
+
+    return _RasterizeGaussians
+
+
+NAN_CHECKS = True      # mirrors the reference's NaN asserts on every backward; the refine loop may turn them off
+_RasterizeGaussians = _make_function(False)
+_RasterizeGaussiansClamp = _make_function(True)
+
+
+class GaussianRasterizationSettings(NamedTuple):
+    """Field order is API (DGR/diff_gaussian_rasterization_rade/__init__.py:177-192)."""
+    image_height: int
+    image_width: int
+    tanfovx: float
+    tanfovy: float
+    kernel_size: float
+    bg: torch.Tensor
+    scale_modifier: float
+    viewmatrix: torch.Tensor
+    projmatrix: torch.Tensor
+    sh_degree: int
+    campos: torch.Tensor
+    prefiltered: bool
+    require_depth: bool
+    require_coord: bool
+    debug: bool
+
+
+def _make_api(fn_cls):
+    def rasterize_gaussians_autograd(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
+                                     raster_settings):
+        return fn_cls.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings)
+
+    class GaussianRasterizer(nn.Module):
+        def __init__(self, raster_settings):
+            super().__init__()
+            self.raster_settings = raster_settings
+
+        def markVisible(self, positions):
+            with torch.no_grad():
+                rs = self.raster_settings
+                return mark_visible(positions, rs.viewmatrix, rs.projmatrix)
+
+        def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
+                    cov3D_precomp=None):
+            raster_settings = self.raster_settings
+            if (shs is None and colors_precomp is None) or (shs is not None and colors_precomp is not None):
+                raise Exception('Please provide excatly one of either SHs or precomputed colors!')
+            if ((scales is None or rotations is None) and cov3D_precomp is None) or \
+                    ((scales is not None or rotations is not None) and cov3D_precomp is not None):
+                raise Exception('Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!')
+            if shs is None:
+                shs = torch.Tensor([])
+            if colors_precomp is None:
+                colors_precomp = torch.Tensor([])
+            if scales is None:
+                scales = torch.Tensor([])
+            if rotations is None:
+                rotations = torch.Tensor([])
+            if cov3D_precomp is None:
+                cov3D_precomp = torch.Tensor([])
+            return rasterize_gaussians_autograd(means3D, means2D, shs, colors_precomp, opacities, scales, rotations,
+                                                cov3D_precomp, raster_settings)
+
+        def integrate(self, *args, **kwargs):
+            return integrate_gaussians_to_points(*args, **kwargs)
+
+    return rasterize_gaussians_autograd, GaussianRasterizer
+
+
+rasterize_gaussians_autograd, GaussianRasterizer = _make_api(_RasterizeGaussians)
+rasterize_gaussians_autograd_clamp, GaussianRasterizerClamp = _make_api(_RasterizeGaussiansClamp)

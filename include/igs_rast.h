@@ -1,0 +1,163 @@
+/*
+ * igs_rast.h -- C ABI of the MI355X-native differentiable Gaussian-splat rasterizer.
+ *
+ * This is the drop-in boundary for the hot path of asd56585452/IGS: the entry points are what the
+ * reference's torch glue binds to (DGR = submodules/RaDe-GS/submodules/diff-gaussian-rasterization):
+ *
+ *   igs_rast_forward       <-> CudaRasterizer::Rasterizer::forward   (DGR/cuda_rasterizer/rasterizer.h:31-65,
+ *                              called from RasterizeGaussiansCUDA, DGR/rasterize_points.cu:98-130)
+ *   igs_rast_backward      <-> CudaRasterizer::Rasterizer::backward  (rasterizer.h:67-112,
+ *                              called from RasterizeGaussiansBackwardCUDA, rasterize_points.cu:197-242)
+ *   igs_rast_mark_visible  <-> CudaRasterizer::Rasterizer::markVisible (rasterizer.h:24-29, rasterize_points.cu:259-263)
+ *
+ * Conventions (identical to the reference unless stated):
+ *   - plain device pointers to contiguous fp32 / int32 data, row-major; no torch types;
+ *   - optional inputs are signalled by NULL (the reference relies on data_ptr()==nullptr of empty tensors);
+ *   - viewmatrix / projmatrix are the TRANSPOSED 4x4 matrices the callers build (row-vector convention);
+ *   - the three scratch buffers are opaque byte buffers grown through callbacks; they must stay alive and
+ *     unmodified until the matching backward call, and P, R (= the value forward returned), W, H must be the same;
+ *   - `stream` is a hipStream_t (pass the framework's current stream; NULL = default stream).  All work is
+ *     enqueued on it.  forward performs ONE host synchronisation (a 4-byte read-back of the instance count,
+ *     like rasterizer_impl.cu:354); backward performs none;
+ *   - image outputs of forward must be zero-filled by the caller when P == 0 (nothing is launched, as in
+ *     rasterize_points.cu:90); for P > 0 every pixel of every output is written;
+ *   - backward writes every element of its eight outputs (no pre-zeroing needed) and uses a caller-provided
+ *     workspace of igs_rast_backward_workspace_bytes(P) bytes (contents undefined on entry).
+ *
+ * Return values: forward returns num_rendered (>= 0) or a negative IGS_RAST_E_* code; the others return 0 or a
+ * negative code.  igs_rast_last_error() returns a static, thread-local description of the last failure.
+ */
+#ifndef IGS_RAST_H
+#define IGS_RAST_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define IGS_RAST_VERSION 1
+
+#define IGS_RAST_E_INVALID   (-1)   /* bad argument (NULL required pointer, negative size, ...) */
+#define IGS_RAST_E_HIP       (-2)   /* a HIP runtime call or kernel launch failed */
+#define IGS_RAST_E_ALLOC     (-3)   /* a scratch callback returned NULL */
+#define IGS_RAST_E_PREFILTER (-4)   /* `prefiltered` set but a point was culled (the reference __trap()s, auxiliary.h:172-176) */
+#define IGS_RAST_E_CHANNELS  (-5)   /* reserved: non-RGB without precomputed colours (rasterizer_impl.cu:308-311) */
+
+/* Scratch growth callback: make the buffer at least `bytes` long and return its device address
+ * (the reference's std::function<char*(size_t)> resizeFunctional, rasterize_points.cu:27-33). */
+typedef char* (*igs_rast_alloc_fn)(void* user, size_t bytes);
+
+int igs_rast_version(void);
+const char* igs_rast_last_error(void);
+
+int igs_rast_forward(
+    void* stream,
+    igs_rast_alloc_fn geometry_buffer, void* geometry_user,
+    igs_rast_alloc_fn binning_buffer, void* binning_user,
+    igs_rast_alloc_fn image_buffer, void* image_user,
+    int P, int D, int M,
+    const float* background,              /* [3] */
+    int width, int height,
+    const float* means3D,                 /* [P,3] */
+    const float* shs,                     /* [P,M,3] or NULL */
+    const float* colors_precomp,          /* [P,3] or NULL */
+    const float* opacities,               /* [P] */
+    const float* scales,                  /* [P,3] or NULL */
+    float scale_modifier,
+    const float* rotations,               /* [P,4] (w,x,y,z) or NULL */
+    const float* cov3D_precomp,           /* [P,6] or NULL */
+    const float* viewmatrix,              /* [16] */
+    const float* projmatrix,              /* [16] */
+    const float* cam_pos,                 /* [3] */
+    float tan_fovx, float tan_fovy,
+    float kernel_size,
+    int prefiltered,
+    float* out_color,                     /* [3,H,W] */
+    float* out_coord,                     /* [3,H,W] */
+    float* out_mcoord,                    /* [3,H,W] */
+    float* out_depth,                     /* [1,H,W] */
+    float* out_mdepth,                    /* [1,H,W] */
+    float* out_alpha,                     /* [1,H,W] */
+    float* out_normal,                    /* [3,H,W] */
+    int* radii,                           /* [P] */
+    int require_coord, int require_depth,
+    int debug);                           /* debug != 0: synchronise and check after every launch (auxiliary.h:404-411) */
+
+size_t igs_rast_backward_workspace_bytes(int P);
+
+int igs_rast_backward(
+    void* stream,
+    int P, int D, int M, int R,
+    const float* background,
+    int width, int height,
+    const float* means3D,
+    const float* shs,
+    const float* colors_precomp,
+    const float* alphas,                  /* forward's out_alpha */
+    const float* scales,
+    float scale_modifier,
+    const float* rotations,
+    const float* cov3D_precomp,
+    const float* viewmatrix,
+    const float* projmatrix,
+    const float* campos,
+    float tan_fovx, float tan_fovy,
+    float kernel_size,
+    const int* radii,
+    const float* normalmap,               /* forward's out_normal */
+    const char* geom_buffer,
+    const char* binning_buffer,
+    const char* image_buffer,
+    const float* dL_dpix,                 /* [3,H,W] */
+    const float* dL_dpix_coord,           /* [3,H,W] */
+    const float* dL_dpix_mcoord,          /* [3,H,W] */
+    const float* dL_dpix_depth,           /* [1,H,W] */
+    const float* dL_dpix_mdepth,          /* [1,H,W] */
+    const float* dL_dalphas,              /* [1,H,W] */
+    const float* dL_dpixel_normals,       /* [3,H,W] */
+    void* workspace,
+    float* dL_dmean2D,                    /* [P,3]  (z = sum |.|, the GOF densification statistic) */
+    float* dL_dcolor,                     /* [P,3] */
+    float* dL_dopacity,                   /* [P] */
+    float* dL_dmean3D,                    /* [P,3] */
+    float* dL_dcov3D,                     /* [P,6] */
+    float* dL_dsh,                        /* [P,M,3] (ignored when M == 0) */
+    float* dL_dscale,                     /* [P,3] */
+    float* dL_drot,                       /* [P,4] */
+    int require_coord, int require_depth,
+    int debug);
+
+int igs_rast_mark_visible(void* stream, int P, const float* means3D, const float* viewmatrix,
+                          const float* projmatrix, uint8_t* present /* [P], 0/1 */);
+
+/* ---- introspection for tests and the roofline harness (no reference counterpart) ---- */
+
+/* Copies per-stage scratch contents into caller-provided DEVICE arrays (any may be NULL) so that the HIP
+ * stages can be compared one by one with the CPU oracle's intermediates:
+ *   rec32     [P,32] the packed per-Gaussian record (layout in igs_amd/csrc/common.h)
+ *   tiles     [P]    tiles touched
+ *   point_list[R]    sorted Gaussian ids
+ *   ranges    [T,2]  per-tile [start,end)
+ *   n_contrib [2,H,W] last / median contributor counts */
+int igs_rast_debug_dump(void* stream, int P, int R, int width, int height,
+                        const char* geom_buffer, const char* binning_buffer, const char* image_buffer,
+                        float* rec32, uint32_t* tiles, uint32_t* point_list, uint32_t* ranges, uint32_t* n_contrib);
+
+/* ---- refine-loop helpers ("next" rows of SURVEY.md 8f: fused loss / fused multi-group Adam) ---- */
+
+/* One Adam step over a flat fp32 parameter span, torch.optim.Adam semantics without weight decay / amsgrad, as
+ * built by GaussianModel.load_fromstream (igs/models/gaussian_model.py:295-348: Adam(lr=0, eps=1e-15), per-group lr).
+ * bias_correction1 = 1 - beta1^t, bias_correction2_sqrt = sqrt(1 - beta2^t). */
+int igs_adam_step(void* stream, size_t n, float* param, const float* grad, float* exp_avg, float* exp_avg_sq,
+                  float lr, float beta1, float beta2, float eps, float bias_correction1, float bias_correction2_sqrt);
+
+/* Fused L1 loss forward + backward (igs/utils/loss_utils.py:17-18): *loss_sum += sum |pred - gt| (caller zeroes it),
+ * grad[i] = sign(pred[i] - gt[i]) * scale. */
+int igs_l1_loss_fwd_bwd(void* stream, size_t n, const float* pred, const float* gt, float* grad, float* loss_sum, float scale);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
