@@ -14,7 +14,9 @@ _vp, _i, _f = C.c_void_p, C.c_int, C.c_float
 
 EXPORTS = ["igs_rast_version", "igs_rast_last_error", "igs_rast_forward", "igs_rast_backward_workspace_bytes",
            "igs_rast_backward", "igs_rast_mark_visible", "igs_rast_debug_dump",
-           "igs_adam_step", "igs_l1_loss_fwd_bwd"]
+           "igs_rast_profile_enable", "igs_rast_profile_read", "igs_adam_step", "igs_l1_loss_fwd_bwd"]
+
+STAGES = ["preprocess", "depth_sort", "scan", "emit", "tile_sort", "ranges", "blend_fwd", "memset", "blend_bwd", "geom_bwd"]
 
 
 def lib():
@@ -43,6 +45,10 @@ def lib():
     L.igs_rast_mark_visible.argtypes = [_vp, _i, _vp, _vp, _vp, _vp]
     L.igs_rast_debug_dump.restype = _i
     L.igs_rast_debug_dump.argtypes = [_vp, _i, _i, _i, _i] + [_vp] * 8
+    L.igs_rast_profile_enable.restype = _i
+    L.igs_rast_profile_enable.argtypes = [_i]
+    L.igs_rast_profile_read.restype = _i
+    L.igs_rast_profile_read.argtypes = [_vp, _vp, _vp, _vp, _i]
     if hasattr(L, "igs_adam_step"):
         L.igs_adam_step.restype = _i
         L.igs_adam_step.argtypes = [_vp, C.c_size_t, _vp, _vp, _vp, _vp, _f, _f, _f, _f, _f, _f]
@@ -54,3 +60,18 @@ def lib():
 
 def last_error():
     return lib().igs_rast_last_error().decode("utf-8", "replace")
+
+
+def profile_enable(on=True):
+    lib().igs_rast_profile_enable(int(bool(on)))
+
+
+def profile_read(reset=True):
+    """{stage: (ms_sum, count)}, sum of num_rendered, number of forward calls."""
+    n = len(STAGES)
+    ms = (C.c_double * n)()
+    cnt = (C.c_longlong * n)()
+    r = C.c_double(0)
+    calls = C.c_longlong(0)
+    lib().igs_rast_profile_read(ms, cnt, C.byref(r), C.byref(calls), int(bool(reset)))
+    return {STAGES[i]: (ms[i], cnt[i]) for i in range(n)}, r.value, calls.value

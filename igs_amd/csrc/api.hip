@@ -33,6 +33,53 @@ static int ensure_slot()
 
 static int ceil_log2(uint32_t n) { int b = 0; while ((1u << b) < n) b++; return b; }
 
+// ---- optional per-stage timing with HIP events on the caller's stream (roofline harness, bench.py) ----
+enum { ST_PREPROCESS = 0, ST_DEPTH_SORT, ST_SCAN, ST_EMIT, ST_TILE_SORT, ST_RANGES, ST_BLEND_FWD, ST_MEMSET, ST_BLEND_BWD,
+       ST_GEOM_BWD, ST_COUNT, ST_GAP = -1 };
+struct Prof {
+    bool on = false;
+    static const int CAP = 4096;
+    hipEvent_t ev[CAP]; int tag[CAP]; int n = 0; bool created = false;
+    double ms[ST_COUNT] = {0}; long long cnt[ST_COUNT] = {0}; double r_sum = 0; long long calls = 0;
+};
+static Prof g_prof;
+static void prof_collect()
+{
+    if (g_prof.n == 0) return;
+    (void)hipEventSynchronize(g_prof.ev[g_prof.n - 1]);
+    for (int i = 1; i < g_prof.n; i++) {
+        const int t = g_prof.tag[i];
+        if (t < 0) continue;                       // a mark that only starts a new interval
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, g_prof.ev[i - 1], g_prof.ev[i]) == hipSuccess) { g_prof.ms[t] += ms; g_prof.cnt[t]++; }
+    }
+    g_prof.n = 0;
+}
+// records "stage `tag` ended here" (tag = ST_GAP: only a start mark)
+static void prof_mark(hipStream_t s, int tag)
+{
+    if (!g_prof.on) return;
+    if (!g_prof.created) { for (int i = 0; i < Prof::CAP; i++) (void)hipEventCreate(&g_prof.ev[i]); g_prof.created = true; }
+    if (g_prof.n >= Prof::CAP - 1) {                // keep the last mark as the start of the next interval
+        const hipEvent_t last = g_prof.ev[g_prof.n - 1];
+        prof_collect();
+        (void)last;
+        (void)hipEventRecord(g_prof.ev[0], s); g_prof.tag[0] = ST_GAP; g_prof.n = 1;
+        if (tag == ST_GAP) return;
+    }
+    (void)hipEventRecord(g_prof.ev[g_prof.n], s); g_prof.tag[g_prof.n] = tag; g_prof.n++;
+}
+extern "C" int igs_rast_profile_enable(int on) { if (!on) prof_collect(); g_prof.on = on != 0; return 0; }
+extern "C" int igs_rast_profile_read(double* ms_sum, long long* count, double* r_sum, long long* calls, int reset)
+{
+    prof_collect();
+    for (int i = 0; i < ST_COUNT; i++) { if (ms_sum) ms_sum[i] = g_prof.ms[i]; if (count) count[i] = g_prof.cnt[i]; }
+    if (r_sum) *r_sum = g_prof.r_sum;
+    if (calls) *calls = g_prof.calls;
+    if (reset) { for (int i = 0; i < ST_COUNT; i++) { g_prof.ms[i] = 0; g_prof.cnt[i] = 0; } g_prof.r_sum = 0; g_prof.calls = 0; }
+    return ST_COUNT;
+}
+
 extern "C" int igs_rast_version(void) { return IGS_RAST_VERSION; }
 extern "C" const char* igs_rast_last_error(void) { return g_err; }
 extern "C" size_t igs_rast_backward_workspace_bytes(int P) { return (size_t)(P > 0 ? P : 0) * GACC_F * 4 + 512; }
@@ -92,19 +139,24 @@ extern "C" int igs_rast_forward(
     fp.view = viewmatrix; fp.proj = projmatrix; fp.campos = cam_pos;
 
     HIP_TRY(hipMemsetAsync(counters, 0, 16, s), "memset counters");
+    prof_mark(s, ST_GAP);
     HIP_TRY(launch_preprocess_fwd(s, fp, rec, tiles, keys_a, vals_a, radii, counters), "preprocess_fwd launch");
     DBG_SYNC("preprocess_fwd");
+    prof_mark(s, ST_PREPROCESS);
     // instance count: read back while the depth sort runs
     HIP_TRY(hipMemcpyAsync(g_slot.pinned, counters, 8, hipMemcpyDeviceToHost, s), "memcpy count");
     HIP_TRY(hipEventRecord(g_slot.ev, s), "event record");
+    prof_mark(s, ST_GAP);
 
     uint32_t *dk = nullptr, *order = nullptr;
     HIP_TRY(radix_sort_pairs(s, (uint32_t)P, keys_a, keys_b, vals_a, vals_b, ghist, 0, 32, &dk, &order), "depth sort launch");
     DBG_SYNC("depth sort");
+    prof_mark(s, ST_DEPTH_SORT);
     const int nblk = (P + 255) / 256;
     HIP_TRY(launch_count_sorted(s, P, order, tiles, blocksum), "count_sorted launch");
     HIP_TRY(launch_scan_blocksums(s, nblk, blocksum), "scan_blocksums launch");
     DBG_SYNC("scan");
+    prof_mark(s, ST_SCAN);
 
     HIP_TRY(hipEventSynchronize(g_slot.ev), "event sync");
     const uint32_t R = g_slot.pinned[0];
@@ -122,6 +174,7 @@ extern "C" int igs_rast_forward(
 
     uint32_t* ranges = (uint32_t*)(ibase + IL.ranges);
     HIP_TRY(hipMemsetAsync(ranges, 0, Tn * 8, s), "memset ranges");               // rasterizer_impl.cu:383
+    prof_mark(s, ST_GAP);
     if (R > 0) {
         const int bits = ceil_log2((uint32_t)Tn);
         const int passes = (bits + 7) / 8;
@@ -131,12 +184,15 @@ extern "C" int igs_rast_forward(
         else                 { ka = bkeys_b; va = bvals_b;   kb = bkeys_a; vb = point_list; }
         HIP_TRY(launch_emit_instances(s, P, gx, gy, order, tiles, blocksum, rec, radii, ka, va), "emit launch");
         DBG_SYNC("emit");
+        prof_mark(s, ST_EMIT);
         uint32_t *sk = nullptr, *sv = nullptr;
         HIP_TRY(radix_sort_pairs(s, R, ka, kb, va, vb, bhist, 0, bits, &sk, &sv), "tile sort launch");
         DBG_SYNC("tile sort");
+        prof_mark(s, ST_TILE_SORT);
         if (sv != point_list) return fail(IGS_RAST_E_INVALID, "internal: sort ping-pong mismatch");
         HIP_TRY(launch_tile_ranges(s, R, sk, ranges), "tile_ranges launch");
         DBG_SYNC("tile_ranges");
+        prof_mark(s, ST_RANGES);
     }
 
     BlendFwdArgs ba;
@@ -149,6 +205,8 @@ extern "C" int igs_rast_forward(
     ba.normal_length = (float*)(ibase + IL.normal_length);
     HIP_TRY(launch_blend_fwd(s, ba, require_coord != 0, require_depth != 0), "blend_fwd launch");
     DBG_SYNC("blend_fwd");
+    prof_mark(s, ST_BLEND_FWD);
+    if (g_prof.on) { g_prof.r_sum += (double)R; g_prof.calls++; }
     return (int)R;
 }
 
@@ -188,7 +246,9 @@ extern "C" int igs_rast_backward(
     float* gacc = (float*)align_ptr((const char*)workspace);
     const float fy = height / (2.0f * tan_fovy), fx = width / (2.0f * tan_fovx);
 
+    prof_mark(s, ST_GAP);
     HIP_TRY(hipMemsetAsync(gacc, 0, (size_t)P * GACC_F * 4, s), "memset gacc");
+    prof_mark(s, ST_MEMSET);
     BlendBwdArgs ba;
     ba.W = width; ba.H = height; ba.gx = gx; ba.gy = gy; ba.fx = fx; ba.fy = fy; ba.bg = background;
     ba.ranges = (const uint32_t*)(ibase + IL.ranges);
@@ -203,6 +263,7 @@ extern "C" int igs_rast_backward(
     if (R > 0) {
         HIP_TRY(launch_blend_bwd(s, ba, require_coord != 0, require_depth != 0), "blend_bwd launch");
         DBG_SYNC("blend_bwd");
+        prof_mark(s, ST_BLEND_BWD);
     }
     GeomBwdArgs ga;
     ga.P = P; ga.D = D; ga.M = shs ? M : 0; ga.W = width; ga.H = height;
@@ -215,6 +276,7 @@ extern "C" int igs_rast_backward(
     ga.dL_dcov3D = dL_dcov3D; ga.dL_dsh = dL_dsh; ga.dL_dscale = dL_dscale; ga.dL_drot = dL_drot;
     HIP_TRY(launch_geom_bwd(s, ga), "geom_bwd launch");
     DBG_SYNC("geom_bwd");
+    prof_mark(s, ST_GEOM_BWD);
     return 0;
 }
 

@@ -11,25 +11,16 @@
 //  * Per-splat gradients are accumulated as 25 RAW MOMENTS of the per-pair weights (sums of w, w*dx, w*dy, q*dx^2, ...);
 //    everything that is a per-splat linear combination of those (conic / mean2D / camera-plane / ray-plane gradients,
 //    the 1/focal factors) is applied once per Gaussian in geom_bwd.hip instead of once per pair.
-//  * The 64 lanes of a wave are summed with DPP row operations; one 25-lane, 100-byte contiguous global atomic per
-//    (wave, splat) replaces 25 x 64 scalar atomics.
+//  * The 64 lanes of a wave are summed by a transpose through LDS (25 conflict-free ds_write_b32, then every lane
+//    adds up one half-row with 8 ds_read_b128): ~60 instructions per (wave, splat) instead of 25 six-step butterflies,
+//    and the totals land one per lane, so ONE 25-lane, 100-byte contiguous global atomic per (wave, splat) replaces
+//    the reference's 25 x 64 scalar atomics.
+//  * As in the forward, each wave only walks the splats whose alpha >= 1/255 footprint reaches its 8x8 quad.
 // T is recovered exactly like the reference does (T_final = 1 - out_alpha, T <- T / (1 - alpha), backward.cu:706,857).
-#include "common.h"
+#include "blend_common.h"
 
-template <int CTRL, int ROW_MASK, int BANK_MASK>
-__device__ __forceinline__ float dpp_mov(float v) {
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, BANK_MASK, false));
-}
-// sum over the 64 lanes; the total is valid in lanes 48..63 (rocPRIM-style gfx9 DPP sequence)
-__device__ __forceinline__ float wave_sum_hi(float v) {
-    v += dpp_mov<0xB1, 0xf, 0xf>(v);     // quad_perm [1,0,3,2]
-    v += dpp_mov<0x4E, 0xf, 0xf>(v);     // quad_perm [2,3,0,1]
-    v += dpp_mov<0x141, 0xf, 0xf>(v);    // row_half_mirror
-    v += dpp_mov<0x140, 0xf, 0xf>(v);    // row_mirror
-    v += dpp_mov<0x142, 0xa, 0xf>(v);    // row_bcast15 -> rows 1,3
-    v += dpp_mov<0x143, 0xc, 0xf>(v);    // row_bcast31 -> rows 2,3
-    return v;
-}
+#define BCHUNK 128            // splats staged per round in the backward (LDS is shared with the reduction scratch)
+#define RED_STRIDE 68         // floats per row of the per-wave transpose buffer: 16-byte aligned rows, conflict-free b128 reads
 
 // gacc slots (raw moments), see geom_bwd.hip for how they are combined:
 //  0..2  sum w*dL/dpix_ch            3..5  Sv = sum dLc_ch          6..8 Sx = sum dLc_ch*dx     9..11 Sy = sum dLc_ch*dy
@@ -41,9 +32,11 @@ blend_bwd_kernel(const BlendBwdArgs a)
 {
     constexpr bool GEO = COORD || DEPTH || NORMAL;
     constexpr int NQ = GEO ? 6 : 3;
-    __shared__ float4 chunk[CHUNK * NQ];
-    __shared__ uint32_t chunk_id[CHUNK];
+    __shared__ float4 chunk[BCHUNK * NQ];
+    __shared__ uint32_t chunk_id[BCHUNK];
+    __shared__ uint64_t quad_bits[4][2];                // [quad][staging wave pair]: BCHUNK = 2 x 64 splats
     __shared__ int wave_max[4];
+    __shared__ __attribute__((aligned(16))) float red[4][GA_USED * RED_STRIDE];
 
     const uint32_t tile = xcd_remap(blockIdx.x, gridDim.x);
     const uint32_t tx = tile % a.gx, ty = tile / a.gx;
@@ -52,11 +45,13 @@ blend_bwd_kernel(const BlendBwdArgs a)
     const uint32_t py = ty * TILE + (wid >> 1) * 8 + (lane >> 3);
     const bool inside = px < (uint32_t)a.W && py < (uint32_t)a.H;
     const float pixfx = (float)px, pixfy = (float)py;
+    const float tile_x0 = (float)(tx * TILE), tile_y0 = (float)(ty * TILE);
     const size_t HW = (size_t)a.H * a.W;
     const size_t pix = (size_t)a.W * py + px;
 
     const uint2 range = ((const uint2*)a.ranges)[tile];
-    int last_contributor = inside ? (int)a.n_contrib[pix] : 0;
+    // clamped to the tile's list length: a corrupt image buffer must not turn into an out-of-bounds gather
+    int last_contributor = inside ? (int)min(a.n_contrib[pix], range.y - range.x) : 0;
     const uint32_t max_contributor = inside ? a.n_contrib[pix + HW] : 0u;
 
     // ---- per-pixel upstream gradients (backward.cu:732-781); zero for pixels nothing was blended into, whose
@@ -109,100 +104,125 @@ blend_bwd_kernel(const BlendBwdArgs a)
     }
     __syncthreads();
     const int n = max(max(wave_max[0], wave_max[1]), max(wave_max[2], wave_max[3]));   // elements [0, n) of the range
-    const int rounds = (n + CHUNK - 1) / CHUNK;
+    const int rounds = (n + BCHUNK - 1) / BCHUNK;
+    for (int k = 0; k < GA_USED; k++) red[wid][k * RED_STRIDE + lane] = 0.f;
 
     float T = T_final, S = 0.f, Dprev = 0.f, last_alpha = 0.f;
     const float halfW = 0.5f * a.W, halfH = 0.5f * a.H;
+    float* myred = red[wid];
+    const int rk = lane & 31, rh = lane >> 5;            // this lane sums row rk, half rh of the transpose buffer
 
     for (int i = 0; i < rounds; i++) {
         __syncthreads();
-        const int progress = i * CHUNK + (int)tid;          // position counted from the back of [0, n)
-        if (progress < n) {
-            const uint32_t id = a.point_list[range.x + (uint32_t)(n - 1 - progress)];
-            const float4* src = (const float4*)(a.rec + (size_t)id * REC_F);
-            float4 q0 = src[0], q1 = src[1], q2 = src[2];
-            if (a.colors_precomp) {
-                q1.z = a.colors_precomp[3 * (size_t)id]; q1.w = a.colors_precomp[3 * (size_t)id + 1];
-                q2.x = a.colors_precomp[3 * (size_t)id + 2];
+        uint32_t qmask = 0;
+        if (tid < BCHUNK) {
+            const int progress = i * BCHUNK + (int)tid;      // position counted from the back of [0, n)
+            if (progress < n) {
+                const uint32_t id = a.point_list[range.x + (uint32_t)(n - 1 - progress)];
+                const float4* src = (const float4*)(a.rec + (size_t)id * REC_F);
+                float4 q0 = src[0], q1 = src[1], q2 = src[2];
+                if (a.colors_precomp) {
+                    q1.z = a.colors_precomp[3 * (size_t)id]; q1.w = a.colors_precomp[3 * (size_t)id + 1];
+                    q2.x = a.colors_precomp[3 * (size_t)id + 2];
+                }
+                chunk[tid * NQ + 0] = q0; chunk[tid * NQ + 1] = q1; chunk[tid * NQ + 2] = q2;
+                if constexpr (GEO) { chunk[tid * NQ + 3] = src[3]; chunk[tid * NQ + 4] = src[4]; chunk[tid * NQ + 5] = src[5]; }
+                chunk_id[tid] = id;
+                qmask = quad_reach_mask(q0, q1, tile_x0, tile_y0);
             }
-            chunk[tid * NQ + 0] = q0; chunk[tid * NQ + 1] = q1; chunk[tid * NQ + 2] = q2;
-            if constexpr (GEO) { chunk[tid * NQ + 3] = src[3]; chunk[tid * NQ + 4] = src[4]; chunk[tid * NQ + 5] = src[5]; }
-            chunk_id[tid] = id;
+        }
+        if (wid < 2) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const uint64_t b = __ballot((qmask >> q) & 1u);
+                if (lane == 0) quad_bits[q][wid] = b;
+            }
         }
         __syncthreads();
-        const int cnt = min(CHUNK, n - i * CHUNK);
-        for (int j = 0; j < cnt; j++) {
-            const int eidx = n - 1 - (i * CHUNK + j);       // 0-based position in the tile's list = the reference's `contributor`
-            const float4 q0 = chunk[j * NQ + 0];
-            const float4 q1 = chunk[j * NQ + 1];
-            const float dx = q0.x - pixfx, dy = q0.y - pixfy;
-            const float power = -0.5f * (q0.z * dx * dx + q1.x * dy * dy) - q0.w * dx * dy;
-            const float G = __expf(power);
-            const float alpha = fminf(0.99f, q1.y * G);
-            const bool valid = (eidx < last_contributor) && !(power > 0.0f) && !(alpha < 1.0f / 255.0f);
-            if (__ballot(valid) == 0ull) continue;
+        for (int sw = 0; sw < 2; sw++) {
+            uint64_t bits = quad_bits[wid][sw];
+            bits = uniform64(bits);
+            while (bits != 0ull) {
+                const int j = sw * 64 + __builtin_ctzll(bits);
+                bits &= bits - 1;
+                const int eidx = n - 1 - (i * BCHUNK + j);      // 0-based position in the tile's list = the reference's `contributor`
+                const float4 q0 = chunk[j * NQ + 0];
+                const float4 q1 = chunk[j * NQ + 1];
+                const float dx = q0.x - pixfx, dy = q0.y - pixfy;
+                const float power = gauss_power(q0.z, q0.w, q1.x, dx, dy);
+                const float G = __expf(power);
+                const float alpha = fminf(0.99f, q1.y * G);
+                const bool valid = (eidx < last_contributor) && !(power > 0.0f) && !(alpha < 1.0f / 255.0f);
+                if (__ballot(valid) == 0ull) continue;
 
-            const float4 q2 = chunk[j * NQ + 2];
-            const float one_m = 1.f - alpha;
-            T = valid ? T / one_m : T;
-            const float w = valid ? alpha * T : 0.f;
-            const bool is_med = valid && ((uint32_t)(eidx + 1) == max_contributor);
+                const float4 q2 = chunk[j * NQ + 2];
+                const float one_m = 1.f - alpha;
+                T = valid ? T / one_m : T;
+                const float w = valid ? alpha * T : 0.f;
+                const bool is_med = valid && ((uint32_t)(eidx + 1) == max_contributor);
 
-            float D = q1.z * gp0 + q1.w * gp1 + q2.x * gp2 + g_alpha;
-            float dLc0 = 0, dLc1 = 0, dLc2 = 0, dLt = 0;
-            float4 q3, q4, q5;
-            if constexpr (GEO) { q3 = chunk[j * NQ + 3]; q5 = chunk[j * NQ + 5]; }
-            if constexpr (COORD) {
-                q4 = chunk[j * NQ + 4];
-                const float c0 = q3.x + q4.x * dx + q4.y * dy;
-                const float c1 = q3.y + q4.z * dx + q4.w * dy;
-                const float c2 = q3.z + q5.x * dx + q5.y * dy;
-                D += c0 * gc0 + c1 * gc1 + c2 * gc2;
-                dLc0 = w * gc0 + (is_med ? gm0 : 0.f);
-                dLc1 = w * gc1 + (is_med ? gm1 : 0.f);
-                dLc2 = w * gc2 + (is_med ? gm2 : 0.f);
-            }
-            if constexpr (DEPTH) {
-                const float t = q2.y + (q2.z * dx + q2.w * dy);
-                D += t * g_t;
-                dLt = w * g_t + (is_med ? g_mt : 0.f);
-            }
-            if constexpr (NORMAL) D += q3.w * gn0 + q5.z * gn1 + q5.w * gn2;
-
-            const float Snew = last_alpha * Dprev + (1.f - last_alpha) * S;
-            float dL_dopa = (D - Snew) * T + (-T_final / one_m) * bg_dot;
-            S = valid ? Snew : S;
-            Dprev = valid ? D : Dprev;
-            last_alpha = valid ? alpha : last_alpha;
-            const float dL_dG = valid ? q1.y * dL_dopa : 0.f;
-            const float q = dL_dG * G;
-            const float qdx = q * dx, qdy = q * dy;
-            const float gxa = q0.z * qdx + q0.w * qdy;      // -dL/d(delx) of the Gaussian term
-            const float gya = q1.x * qdy + q0.w * qdx;
-
-            float v[GA_USED];
-            v[0] = w * gp0; v[1] = w * gp1; v[2] = w * gp2;
-            v[3] = dLc0; v[4] = dLc1; v[5] = dLc2;
-            v[6] = dLc0 * dx; v[7] = dLc1 * dx; v[8] = dLc2 * dx;
-            v[9] = dLc0 * dy; v[10] = dLc1 * dy; v[11] = dLc2 * dy;
-            v[12] = dLt; v[13] = dLt * dx; v[14] = dLt * dy;
-            v[15] = w * gn0; v[16] = w * gn1; v[17] = w * gn2;
-            v[18] = q; v[19] = qdx; v[20] = qdy; v[21] = qdx * dx; v[22] = qdx * dy; v[23] = qdy * dy;
-            v[24] = fabsf(gxa * halfW) + fabsf(gya * halfH);
-
-            float out = 0.f;
-#pragma unroll
-            for (int k = 0; k < GA_USED; k++) {
-                const bool live = (k < 3) || (k >= 18) || (COORD && k >= 3 && k < 12) || (DEPTH && k >= 12 && k < 15)
-                                  || (NORMAL && k >= 15 && k < 18);
-                if (live) {
-                    const float tot = wave_sum_hi(v[k]);
-                    const int s = __builtin_amdgcn_readlane(__float_as_int(tot), 63);
-                    // lane k of `out` <- total (immediate lane select: no SGPR lane-select hazard)
-                    asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(out) : "s"(s), "n"(k));
+                float D = q1.z * gp0 + q1.w * gp1 + q2.x * gp2 + g_alpha;
+                float dLc0 = 0, dLc1 = 0, dLc2 = 0, dLt = 0;
+                float4 q3, q4, q5;
+                if constexpr (GEO) { q3 = chunk[j * NQ + 3]; q5 = chunk[j * NQ + 5]; }
+                if constexpr (COORD) {
+                    q4 = chunk[j * NQ + 4];
+                    const float c0 = q3.x + q4.x * dx + q4.y * dy;
+                    const float c1 = q3.y + q4.z * dx + q4.w * dy;
+                    const float c2 = q3.z + q5.x * dx + q5.y * dy;
+                    D += c0 * gc0 + c1 * gc1 + c2 * gc2;
+                    dLc0 = w * gc0 + (is_med ? gm0 : 0.f);
+                    dLc1 = w * gc1 + (is_med ? gm1 : 0.f);
+                    dLc2 = w * gc2 + (is_med ? gm2 : 0.f);
                 }
+                if constexpr (DEPTH) {
+                    const float t = q2.y + (q2.z * dx + q2.w * dy);
+                    D += t * g_t;
+                    dLt = w * g_t + (is_med ? g_mt : 0.f);
+                }
+                if constexpr (NORMAL) D += q3.w * gn0 + q5.z * gn1 + q5.w * gn2;
+
+                const float Snew = last_alpha * Dprev + (1.f - last_alpha) * S;
+                const float dL_dopa = (D - Snew) * T + (-T_final / one_m) * bg_dot;
+                S = valid ? Snew : S;
+                Dprev = valid ? D : Dprev;
+                last_alpha = valid ? alpha : last_alpha;
+                const float dL_dG = valid ? q1.y * dL_dopa : 0.f;
+                const float q = dL_dG * G;
+                const float qdx = q * dx, qdy = q * dy;
+                const float gxa = q0.z * qdx + q0.w * qdy;      // -dL/d(delx) of the Gaussian term
+                const float gya = q1.x * qdy + q0.w * qdx;
+
+                // ---- transpose-reduce over the 64 pixels of the wave: row k of `myred` = the 64 per-lane values of moment k
+                float* col = myred + lane;
+                col[0 * RED_STRIDE] = w * gp0; col[1 * RED_STRIDE] = w * gp1; col[2 * RED_STRIDE] = w * gp2;
+                if constexpr (COORD) {
+                    col[3 * RED_STRIDE] = dLc0; col[4 * RED_STRIDE] = dLc1; col[5 * RED_STRIDE] = dLc2;
+                    col[6 * RED_STRIDE] = dLc0 * dx; col[7 * RED_STRIDE] = dLc1 * dx; col[8 * RED_STRIDE] = dLc2 * dx;
+                    col[9 * RED_STRIDE] = dLc0 * dy; col[10 * RED_STRIDE] = dLc1 * dy; col[11 * RED_STRIDE] = dLc2 * dy;
+                }
+                if constexpr (DEPTH) { col[12 * RED_STRIDE] = dLt; col[13 * RED_STRIDE] = dLt * dx; col[14 * RED_STRIDE] = dLt * dy; }
+                if constexpr (NORMAL) { col[15 * RED_STRIDE] = w * gn0; col[16 * RED_STRIDE] = w * gn1; col[17 * RED_STRIDE] = w * gn2; }
+                col[18 * RED_STRIDE] = q; col[19 * RED_STRIDE] = qdx; col[20 * RED_STRIDE] = qdy;
+                col[21 * RED_STRIDE] = qdx * dx; col[22 * RED_STRIDE] = qdx * dy; col[23 * RED_STRIDE] = qdy * dy;
+                col[24 * RED_STRIDE] = fabsf(gxa * halfW) + fabsf(gya * halfH);
+                // rows that are structurally zero in this template instance were zeroed once before the loop
+                float part = 0.f;
+                if (rk < GA_USED) {
+                    const float4* row = (const float4*)(myred + rk * RED_STRIDE + rh * 32);
+                    float4 s0 = row[0], s1 = row[1], s2 = row[2], s3 = row[3], s4 = row[4], s5 = row[5], s6 = row[6], s7 = row[7];
+                    s0.x += s1.x; s0.y += s1.y; s0.z += s1.z; s0.w += s1.w;
+                    s2.x += s3.x; s2.y += s3.y; s2.z += s3.z; s2.w += s3.w;
+                    s4.x += s5.x; s4.y += s5.y; s4.z += s5.z; s4.w += s5.w;
+                    s6.x += s7.x; s6.y += s7.y; s6.z += s7.z; s6.w += s7.w;
+                    s0.x += s2.x; s0.y += s2.y; s0.z += s2.z; s0.w += s2.w;
+                    s4.x += s6.x; s4.y += s6.y; s4.z += s6.z; s4.w += s6.w;
+                    s0.x += s4.x; s0.y += s4.y; s0.z += s4.z; s0.w += s4.w;
+                    part = (s0.x + s0.y) + (s0.z + s0.w);
+                }
+                const float tot = part + __shfl_xor(part, 32, 64);
+                if (lane < GA_USED) atomicAdd(&a.gacc[(size_t)chunk_id[j] * GACC_F + lane], tot);
             }
-            if (lane < GA_USED) atomicAdd(&a.gacc[(size_t)chunk_id[j] * GACC_F + lane], out);
         }
     }
 }

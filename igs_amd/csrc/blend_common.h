@@ -1,0 +1,45 @@
+// blend_common.h -- helpers shared by the forward and backward tile-blend kernels (device only).
+#pragma once
+#include "common.h"
+
+// Gaussian exponent exactly as the reference associates it (forward.cu:555, backward.cu:847), WITHOUT fused
+// multiply-adds: the sign of a power that rounds to +-1e-8 next to a splat centre decides `if (power > 0) continue`,
+// so the operation order is kept identical to the oracle's to keep such threshold flips as rare as they can be.
+__device__ __forceinline__ float gauss_power(float cx, float cy, float cz, float dx, float dy)
+{
+#pragma clang fp contract(off)
+    return -0.5f * (cx * dx * dx + cz * dy * dy) - cy * dx * dy;
+}
+
+// Which of the four 8x8 quads of a tile can this splat contribute to at all?  bit q = (qy << 1) | qx.
+// A pair contributes only if alpha = min(0.99, o * exp(power)) >= 1/255, i.e. power >= -tau with tau = ln(255 o):
+// the pixel must lie inside the ellipse  d^T conic d <= 2 tau, whose bounding box has half extents
+// sqrt(2 tau conic.z / det), sqrt(2 tau conic.x / det).  The test is conservative (extents inflated, any
+// non-finite / non-positive-definite conic means "all quads"), so it never removes a pair the reference would blend.
+__device__ __forceinline__ uint32_t quad_reach_mask(float4 q0, float4 q1, float tile_x0, float tile_y0)
+{
+    const float o = q1.y;
+    if (o < (1.0f / 255.0f)) return 0u;                       // alpha <= o < 1/255 for every pixel
+    const float cx = q0.z, cy = q0.w, cz = q1.x;
+    const float det = cx * cz - cy * cy;
+    if (!(det > 0.f) || !(cx > 0.f) || !(cz > 0.f) || !(det < 3.0e38f)) return 0xFu;
+    const float two_tau = 2.0f * __logf(255.0f * o) * 1.002f + 1e-3f;
+    if (!(two_tau < 3.0e38f)) return 0xFu;
+    const float inv = 1.0f / det;
+    const float ex = sqrtf(two_tau * cz * inv) * 1.001f + 0.02f;
+    const float ey = sqrtf(two_tau * cx * inv) * 1.001f + 0.02f;
+    if (!(ex < 3.0e38f) || !(ey < 3.0e38f)) return 0xFu;
+    const float lx = q0.x - ex - tile_x0, hx = q0.x + ex - tile_x0;      // reach interval in tile-local pixel coordinates
+    const float ly = q0.y - ey - tile_y0, hy = q0.y + ey - tile_y0;
+    const bool x0 = (hx >= 0.f) && (lx <= 7.f), x1 = (hx >= 8.f) && (lx <= 15.f);
+    const bool y0 = (hy >= 0.f) && (ly <= 7.f), y1 = (hy >= 8.f) && (ly <= 15.f);
+    return (x0 && y0 ? 1u : 0u) | (x1 && y0 ? 2u : 0u) | (x0 && y1 ? 4u : 0u) | (x1 && y1 ? 8u : 0u);
+}
+
+// wave-uniform copy of a 64-bit value (readfirstlane returns a SIGNED int: widen through uint32_t, not int)
+__device__ __forceinline__ uint64_t uniform64(uint64_t v)
+{
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32));
+    return (uint64_t)lo | ((uint64_t)hi << 32);
+}

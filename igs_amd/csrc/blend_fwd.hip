@@ -1,12 +1,15 @@
 // blend_fwd.hip -- tile-wise front-to-back alpha compositing for gfx950 (wave64).
 // Replaces FORWARD::render / renderCUDA (DGR/cuda_rasterizer/forward.cu:428-742).
 //
-// One 256-thread workgroup per 16x16 tile; each of its 4 waves owns an 8x8 pixel quad (lane = pixel), so a wave
-// whose 64 pixels are saturated or untouched by a splat skips it with one ballot.  Splats are staged 256 at a time
-// into LDS as packed 96-byte records gathered as whole 128-byte lines from the per-Gaussian record array; the inner
-// loop reads them back as wave-uniform (broadcast) ds_read_b128.  Tiles are handed to workgroups through an
-// XCD-aware remap so that the tiles sharing an L2 are spatial neighbours (neighbouring tiles share most splats).
-#include "common.h"
+// One 256-thread workgroup per 16x16 tile; each of its 4 waves owns an 8x8 pixel quad (lane = pixel).
+// Splats are staged 256 at a time into LDS as packed 96-byte records gathered as whole 128-byte lines from the
+// per-Gaussian record array.  While staging, the thread that holds a splat also decides which of the four quads
+// it can reach at all (bounding box of the alpha >= 1/255 ellipse against the quad's pixel-centre rectangle,
+// conservative); a ballot turns that into one 256-bit "to do" set per quad, so each wave walks only its own
+// splats with scalar bit-scans (s_ff1) and reads them back as wave-uniform (broadcast) ds_read_b128, the next
+// record being fetched while the current one is blended.
+// Tiles are handed to workgroups through an XCD-aware remap so that the tiles sharing an L2 are neighbours.
+#include "blend_common.h"
 
 template <bool COORD, bool DEPTH, bool NORMAL>
 __global__ void __launch_bounds__(256)
@@ -15,6 +18,7 @@ blend_fwd_kernel(const BlendFwdArgs a)
     constexpr bool GEO = COORD || DEPTH || NORMAL;
     constexpr int NQ = GEO ? 6 : 3;                     // float4 per staged record
     __shared__ float4 chunk[CHUNK * NQ];
+    __shared__ uint64_t quad_bits[4][4];                // [quad][staging wave]
     __shared__ int wave_done[4];
 
     const uint32_t tile = xcd_remap(blockIdx.x, gridDim.x);
@@ -24,6 +28,7 @@ blend_fwd_kernel(const BlendFwdArgs a)
     const uint32_t py = ty * TILE + (wid >> 1) * 8 + (lane >> 3);
     const bool inside = px < (uint32_t)a.W && py < (uint32_t)a.H;
     const float pixfx = (float)px, pixfy = (float)py;
+    const float tile_x0 = (float)(tx * TILE), tile_y0 = (float)(ty * TILE);
 
     const uint2 range = ((const uint2*)a.ranges)[tile];
     const int n = (int)(range.y - range.x);
@@ -40,6 +45,7 @@ blend_fwd_kernel(const BlendFwdArgs a)
         __syncthreads();                                           // previous chunk consumed, wave_done published
         if (wave_done[0] & wave_done[1] & wave_done[2] & wave_done[3]) break;
         const int progress = i * CHUNK + (int)tid;
+        uint32_t qmask = 0;
         if (progress < n) {
             const uint32_t id = a.point_list[range.x + progress];
             const float4* src = (const float4*)(a.rec + (size_t)id * REC_F);
@@ -50,50 +56,70 @@ blend_fwd_kernel(const BlendFwdArgs a)
             }
             chunk[tid * NQ + 0] = q0; chunk[tid * NQ + 1] = q1; chunk[tid * NQ + 2] = q2;
             if constexpr (GEO) { chunk[tid * NQ + 3] = src[3]; chunk[tid * NQ + 4] = src[4]; chunk[tid * NQ + 5] = src[5]; }
+            qmask = quad_reach_mask(q0, q1, tile_x0, tile_y0);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const uint64_t b = __ballot((qmask >> q) & 1u);
+            if (lane == 0) quad_bits[q][wid] = b;
         }
         __syncthreads();
-        const int cnt = min(CHUNK, n - i * CHUNK);
         if (__ballot(!done) != 0ull) {
-            for (int j = 0; j < cnt; j++) {
-                const float4 q0 = chunk[j * NQ + 0];               // xy, conic.x, conic.y
-                const float4 q1 = chunk[j * NQ + 1];               // conic.z, opacity, r, g
-                const float dx = q0.x - pixfx, dy = q0.y - pixfy;
-                const float power = -0.5f * (q0.z * dx * dx + q1.x * dy * dy) - q0.w * dx * dy;
-                const float alpha = fminf(0.99f, q1.y * __expf(power));
-                const float test_T = T * (1.0f - alpha);
-                // negated comparisons keep the reference's behaviour for NaN (forward.cu:556-573: `if (x > 0) continue`)
-                const bool pass = !done && !(power > 0.0f) && !(alpha < 1.0f / 255.0f);
-                const bool contrib = pass && !(test_T < 0.0001f);
-                done = done || (pass && test_T < 0.0001f);
-                const uint64_t cm = __ballot(contrib);
-                if (cm == 0ull) { if (__ballot(!done) == 0ull) break; continue; }
-                const uint32_t contributor = (uint32_t)(i * CHUNK + j + 1);
-                const float aT = contrib ? alpha * T : 0.0f;
-                const float4 q2 = chunk[j * NQ + 2];               // b, ts, ray.x, ray.y
-                C0 += q1.z * aT; C1 += q1.w * aT; C2 += q2.x * aT;
-                const bool before_median = contrib && T > 0.5f;
-                if constexpr (GEO) {
-                    const float4 q3 = chunk[j * NQ + 3];           // view_point, n.x
-                    const float4 q5 = chunk[j * NQ + 5];           // cp4, cp5, n.y, n.z
-                    if constexpr (COORD) {
-                        const float4 q4 = chunk[j * NQ + 4];       // cp0..3
-                        const float c0 = q3.x + q4.x * dx + q4.y * dy;
-                        const float c1 = q3.y + q4.z * dx + q4.w * dy;
-                        const float c2 = q3.z + q5.x * dx + q5.y * dy;
-                        Co0 += c0 * aT; Co1 += c1 * aT; Co2 += c2 * aT;
-                        mC0 = before_median ? c0 : mC0; mC1 = before_median ? c1 : mC1; mC2 = before_median ? c2 : mC2;
-                    }
-                    if constexpr (DEPTH) {
-                        const float t = q2.y + (q2.z * dx + q2.w * dy);
-                        Depth += t * aT;
-                        mDepth = before_median ? t : mDepth;
-                    }
-                    if constexpr (NORMAL) { N0 += q3.w * aT; N1 += q5.z * aT; N2 += q5.w * aT; }
-                    max_contributor = before_median ? contributor : max_contributor;
+            bool wave_finished = false;
+            for (int sw = 0; sw < 4 && !wave_finished; sw++) {
+                uint64_t bits = quad_bits[wid][sw];                // wave-uniform
+                bits = uniform64(bits);
+                if (bits == 0ull) continue;
+                int j = sw * 64 + __builtin_ctzll(bits);
+                bits &= bits - 1;
+                float4 q0 = chunk[j * NQ + 0], q1 = chunk[j * NQ + 1];
+                while (true) {
+                    // prefetch the next splat of this wave's list
+                    const bool more = bits != 0ull;
+                    const int jn = more ? sw * 64 + __builtin_ctzll(bits) : j;
+                    bits &= bits - 1;
+                    const float4 nq0 = chunk[jn * NQ + 0], nq1 = chunk[jn * NQ + 1];
+
+                    const float dx = q0.x - pixfx, dy = q0.y - pixfy;
+                    const float power = gauss_power(q0.z, q0.w, q1.x, dx, dy);
+                    const float alpha = fminf(0.99f, q1.y * __expf(power));
+                    const float test_T = T * (1.0f - alpha);
+                    // negated comparisons keep the reference's behaviour for NaN (forward.cu:556-573: `if (x > 0) continue`)
+                    const bool pass = !done && !(power > 0.0f) && !(alpha < 1.0f / 255.0f);
+                    const bool contrib = pass && !(test_T < 0.0001f);
+                    done = done || (pass && test_T < 0.0001f);
+                    if (__ballot(contrib) != 0ull) {
+                        const uint32_t contributor = (uint32_t)(i * CHUNK + j + 1);
+                        const float aT = contrib ? alpha * T : 0.0f;
+                        const float4 q2 = chunk[j * NQ + 2];               // b, ts, ray.x, ray.y
+                        C0 += q1.z * aT; C1 += q1.w * aT; C2 += q2.x * aT;
+                        const bool before_median = contrib && T > 0.5f;
+                        if constexpr (GEO) {
+                            const float4 q3 = chunk[j * NQ + 3];           // view_point, n.x
+                            const float4 q5 = chunk[j * NQ + 5];           // cp4, cp5, n.y, n.z
+                            if constexpr (COORD) {
+                                const float4 q4 = chunk[j * NQ + 4];       // cp0..3
+                                const float c0 = q3.x + q4.x * dx + q4.y * dy;
+                                const float c1 = q3.y + q4.z * dx + q4.w * dy;
+                                const float c2 = q3.z + q5.x * dx + q5.y * dy;
+                                Co0 += c0 * aT; Co1 += c1 * aT; Co2 += c2 * aT;
+                                mC0 = before_median ? c0 : mC0; mC1 = before_median ? c1 : mC1; mC2 = before_median ? c2 : mC2;
+                            }
+                            if constexpr (DEPTH) {
+                                const float t = q2.y + (q2.z * dx + q2.w * dy);
+                                Depth += t * aT;
+                                mDepth = before_median ? t : mDepth;
+                            }
+                            if constexpr (NORMAL) { N0 += q3.w * aT; N1 += q5.z * aT; N2 += q5.w * aT; }
+                            max_contributor = before_median ? contributor : max_contributor;
+                        }
+                        weight += aT;
+                        T = contrib ? test_T : T;
+                        last_contributor = contrib ? contributor : last_contributor;
+                    } else if (__ballot(!done) == 0ull) { wave_finished = true; break; }
+                    if (!more) break;
+                    j = jn; q0 = nq0; q1 = nq1;
                 }
-                weight += aT;
-                T = contrib ? test_T : T;
-                last_contributor = contrib ? contributor : last_contributor;
             }
         }
         if (lane == 0) wave_done[wid] = (__ballot(!done) == 0ull) ? 1 : 0;

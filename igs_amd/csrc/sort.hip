@@ -15,7 +15,7 @@
 
 __device__ __forceinline__ uint32_t digit_of(uint32_t key, int shift, uint32_t mask) { return (key >> shift) & mask; }
 
-// ---- pass 1: per-block digit histogram, digit-major layout hist[d * nb + b] ----
+// ---- pass 1: per-block digit histogram, block-major layout hist[b * RADIX + d] ----
 __global__ void __launch_bounds__(256)
 radix_hist_kernel(const uint32_t* __restrict__ keys, uint32_t n, uint32_t per_block, int shift, uint32_t mask, uint32_t* __restrict__ hist)
 {
@@ -26,7 +26,7 @@ radix_hist_kernel(const uint32_t* __restrict__ keys, uint32_t n, uint32_t per_bl
     const uint32_t end = min(n, beg + per_block);
     for (uint32_t e = beg + threadIdx.x; e < end; e += 256) atomicAdd(&h[digit_of(keys[e], shift, mask)], 1u);
     __syncthreads();
-    hist[threadIdx.x * gridDim.x + blockIdx.x] = h[threadIdx.x];
+    hist[blockIdx.x * RADIX + threadIdx.x] = h[threadIdx.x];
 }
 
 // ---- single-block exclusive scan (in place) of up to a few 100k uint32; also returns the total in *total if given ----
@@ -63,7 +63,22 @@ radix_scatter_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __res
     __shared__ uint32_t base[RADIX];
     const uint32_t tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const uint64_t lt_mask = (1ull << lane) - 1ull;
-    base[tid] = hist[tid * gridDim.x + blockIdx.x];
+    {   // base[d] = (keys with a smaller digit, all blocks) + (keys with digit d in earlier blocks): every block derives it
+        // from the block-major histogram table itself (coalesced 1 KB rows, L2 resident) -- no separate scan launch
+        uint32_t before = 0, total = 0;
+        const uint32_t nb = gridDim.x;
+        for (uint32_t b = 0; b < nb; b++) { const uint32_t c = hist[b * RADIX + tid]; total += c; before += (b < blockIdx.x) ? c : 0u; }
+        // exclusive scan of `total` over the 256 digits (4 waves)
+        uint32_t v = total;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) { const uint32_t t = __shfl_up(v, off, 64); if (lane >= (uint32_t)off) v += t; }
+        if (lane == 63) base[wid] = v;            // base[0..3] temporarily hold the wave totals
+        __syncthreads();
+        uint32_t woff = 0;
+        for (uint32_t w = 0; w < wid; w++) woff += base[w];
+        __syncthreads();
+        base[tid] = (v - total) + woff + before;
+    }
     const uint32_t beg = blockIdx.x * per_block;
     const uint32_t end = min(n, beg + per_block);
     for (uint32_t sub = beg; sub < end; sub += SORT_TILE) {
@@ -134,7 +149,6 @@ hipError_t radix_sort_pairs(hipStream_t s, uint32_t n, uint32_t* keys_a, uint32_
             const int nbits = (bit_hi - lo) < 8 ? (bit_hi - lo) : 8;
             const uint32_t mask = (1u << nbits) - 1u;
             hipLaunchKernelGGL(radix_hist_kernel, dim3(nb), dim3(256), 0, s, kin, n, per, lo, mask, hist);
-            hipLaunchKernelGGL(exclusive_scan_kernel, dim3(1), dim3(1024), 0, s, hist, (uint32_t)(RADIX * nb), (uint32_t*)nullptr);
             hipLaunchKernelGGL(radix_scatter_kernel, dim3(nb), dim3(256), 0, s, kin, vin, kout, vout, n, per, lo, mask, hist);
             uint32_t* t = kin; kin = kout; kout = t;
             t = vin; vin = vout; vout = t;

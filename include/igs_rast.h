@@ -145,6 +145,14 @@ int igs_rast_debug_dump(void* stream, int P, int R, int width, int height,
                         const char* geom_buffer, const char* binning_buffer, const char* image_buffer,
                         float* rec32, uint32_t* tiles, uint32_t* point_list, uint32_t* ranges, uint32_t* n_contrib);
 
+/* Optional per-stage timing with HIP events recorded on the caller's stream (used by bench.py for the roofline line).
+ * Stage order of the arrays (IGS_RAST_NSTAGES entries): preprocess, depth_sort, scan, emit, tile_sort, ranges,
+ * blend_fwd, memset, blend_bwd, geom_bwd.  igs_rast_profile_read synchronises on the last recorded event; r_sum is the
+ * sum of num_rendered over the forward calls seen, calls their number. */
+#define IGS_RAST_NSTAGES 10
+int igs_rast_profile_enable(int on);
+int igs_rast_profile_read(double* ms_sum, long long* count, double* r_sum, long long* calls, int reset);
+
 /* ---- refine-loop helpers ("next" rows of SURVEY.md 8f: fused loss / fused multi-group Adam) ---- */
 
 /* One Adam step over a flat fp32 parameter span, torch.optim.Adam semantics without weight decay / amsgrad, as
