@@ -122,7 +122,8 @@ blend_fwd_kernel(const BlendFwdArgs a)
                 }
             }
         }
-        if (lane == 0) wave_done[wid] = (__ballot(!done) == 0ull) ? 1 : 0;
+        const bool all_done = __ballot(!done) == 0ull;            // (the ballot must be taken by the whole wave)
+        if (lane == 0) wave_done[wid] = all_done ? 1 : 0;
     }
 
     if (inside) {

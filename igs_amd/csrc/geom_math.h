@@ -4,6 +4,11 @@
 #pragma once
 #include "common.h"
 
+// Per-Gaussian arithmetic decides discrete things (near-plane cull, splat radius, tile rectangle, the depth sort key):
+// keep every multiply and add separately rounded, like the oracle's plain C, so those decisions agree bit for bit far
+// more often than with fused multiply-adds.  (One thread per Gaussian: not where the time goes.)
+#pragma clang fp contract(off)
+
 __device__ __forceinline__ bool near0(float x) { return fabsf(x) <= 0.0000001f; }
 
 __device__ __forceinline__ float hyp(float a, float b) {   // auxiliary.h:200-214
