@@ -14,7 +14,7 @@ _vp, _i, _f = C.c_void_p, C.c_int, C.c_float
 
 EXPORTS = ["igs_rast_version", "igs_rast_last_error", "igs_rast_forward", "igs_rast_backward_workspace_bytes",
            "igs_rast_backward", "igs_rast_mark_visible", "igs_rast_debug_dump",
-           "igs_rast_profile_enable", "igs_rast_profile_read", "igs_adam_step", "igs_l1_loss_fwd_bwd"]
+           "igs_rast_profile_enable", "igs_rast_profile_read", "igs_adam_step", "igs_l1_loss_fwd_bwd", "igs_activate_fwd", "igs_activate_bwd"]
 
 STAGES = ["preprocess", "depth_sort", "scan", "emit", "tile_sort", "ranges", "blend_fwd", "memset", "blend_bwd", "geom_bwd"]
 
@@ -54,6 +54,10 @@ def lib():
         L.igs_adam_step.argtypes = [_vp, C.c_size_t, _vp, _vp, _vp, _vp, _f, _f, _f, _f, _f, _f]
         L.igs_l1_loss_fwd_bwd.restype = _i
         L.igs_l1_loss_fwd_bwd.argtypes = [_vp, C.c_size_t, _vp, _vp, _vp, _vp, _f]
+        L.igs_activate_fwd.restype = _i
+        L.igs_activate_fwd.argtypes = [_vp, _i] + [_vp] * 6
+        L.igs_activate_bwd.restype = _i
+        L.igs_activate_bwd.argtypes = [_vp, _i] + [_vp] * 9
     _LIB = L
     return L
 

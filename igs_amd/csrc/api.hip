@@ -230,8 +230,7 @@ extern "C" int igs_rast_backward(
         return fail(IGS_RAST_E_INVALID, "igs_rast_backward: NULL scratch buffer");
     if (!means3D || !alphas || !viewmatrix || !projmatrix || !campos || !background || !radii || !normalmap)
         return fail(IGS_RAST_E_INVALID, "igs_rast_backward: NULL required input");
-    if (!dL_dpix || !dL_dpix_coord || !dL_dpix_mcoord || !dL_dpix_depth || !dL_dpix_mdepth || !dL_dalphas || !dL_dpixel_normals)
-        return fail(IGS_RAST_E_INVALID, "igs_rast_backward: NULL upstream gradient");
+    // any of the seven upstream gradients may be NULL = "all zeros" (an output that did not take part in the loss)
     if (!dL_dmean2D || !dL_dcolor || !dL_dopacity || !dL_dmean3D || !dL_dcov3D || !dL_dscale || !dL_drot || (M > 0 && !dL_dsh))
         return fail(IGS_RAST_E_INVALID, "igs_rast_backward: NULL output");
 

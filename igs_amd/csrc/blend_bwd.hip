@@ -38,7 +38,8 @@ blend_bwd_kernel(const BlendBwdArgs a)
     __shared__ int wave_max[4];
     __shared__ __attribute__((aligned(16))) float red[4][GA_USED * RED_STRIDE];
 
-    const uint32_t tile = xcd_remap(blockIdx.x, gridDim.x);
+    uint32_t tile;
+    if (!tile_for_block(blockIdx.x, a.gx, a.gy, tile)) return;
     const uint32_t tx = tile % a.gx, ty = tile / a.gx;
     const uint32_t tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const uint32_t px = tx * TILE + (wid & 1) * 8 + (lane & 7);
@@ -61,26 +62,27 @@ blend_bwd_kernel(const BlendBwdArgs a)
     if (last_contributor > 0) {
         const float w_final = a.alphas[pix];
         T_final = 1.0f - w_final;
-        gp0 = a.dL_dpix[pix]; gp1 = a.dL_dpix[HW + pix]; gp2 = a.dL_dpix[2 * HW + pix];
-        g_alpha = a.dL_dalpha[pix];
+        if (a.dL_dpix) { gp0 = a.dL_dpix[pix]; gp1 = a.dL_dpix[HW + pix]; gp2 = a.dL_dpix[2 * HW + pix]; }
+        if (a.dL_dalpha) g_alpha = a.dL_dalpha[pix];
         bg_dot = a.bg[0] * gp0 + a.bg[1] * gp1 + a.bg[2] * gp2;
         if constexpr (GEO) {
             const float ww = w_final * w_final;
             const float pnx = (pixfx - a.W / 2.f) / a.fx, pny = (pixfy - a.H / 2.f) / a.fy;
             const float ln = sqrtf(pnx * pnx + pny * pny + 1);
             if constexpr (COORD) {
-                const float w0 = a.dL_dcoord[pix], w1 = a.dL_dcoord[HW + pix], w2 = a.dL_dcoord[2 * HW + pix];
+                float w0 = 0.f, w1 = 0.f, w2 = 0.f;
+                if (a.dL_dcoord) { w0 = a.dL_dcoord[pix]; w1 = a.dL_dcoord[HW + pix]; w2 = a.dL_dcoord[2 * HW + pix]; }
                 g_alpha -= w0 * a.accum_coord[pix] / ww;
                 g_alpha -= w1 * a.accum_coord[HW + pix] / ww;
                 g_alpha -= w2 * a.accum_coord[2 * HW + pix] / ww;
                 gc0 = w0 / w_final; gc1 = w1 / w_final; gc2 = w2 / w_final;
-                gm0 = a.dL_dmcoord[pix]; gm1 = a.dL_dmcoord[HW + pix]; gm2 = a.dL_dmcoord[2 * HW + pix];
+                if (a.dL_dmcoord) { gm0 = a.dL_dmcoord[pix]; gm1 = a.dL_dmcoord[HW + pix]; gm2 = a.dL_dmcoord[2 * HW + pix]; }
             }
             if constexpr (DEPTH) {
-                const float wd = a.dL_ddepth[pix];
+                const float wd = a.dL_ddepth ? a.dL_ddepth[pix] : 0.f;
                 g_alpha -= wd * a.accum_depth[pix] / ww;
                 g_t = wd / w_final / ln;
-                g_mt = a.dL_dmdepth[pix] / ln;
+                g_mt = a.dL_dmdepth ? a.dL_dmdepth[pix] / ln : 0.f;
             }
             if constexpr (NORMAL) {
                 const float d0 = a.dL_dnormal[pix], d1 = a.dL_dnormal[HW + pix], d2 = a.dL_dnormal[2 * HW + pix];
@@ -229,10 +231,19 @@ blend_bwd_kernel(const BlendBwdArgs a)
 
 hipError_t launch_blend_bwd(hipStream_t s, const BlendBwdArgs& a, bool coord, bool depth)
 {
-    const dim3 grid(a.gx * a.gy), block(256);
-    if (coord && depth) hipLaunchKernelGGL((blend_bwd_kernel<true, true, true>), grid, block, 0, s, a);
-    else if (coord) hipLaunchKernelGGL((blend_bwd_kernel<true, false, true>), grid, block, 0, s, a);
-    else if (depth) hipLaunchKernelGGL((blend_bwd_kernel<false, true, true>), grid, block, 0, s, a);
-    else hipLaunchKernelGGL((blend_bwd_kernel<false, false, false>), grid, block, 0, s, a);
+    const dim3 grid(tile_grid_blocks(a.gx, a.gy)), block(256);
+    // The reference instantiates (COORD, DEPTH, NORMAL) from require_coord / require_depth alone (backward.cu:1153-1160).
+    // A branch whose upstream gradients are all absent (NULL = zero: the output did not take part in the loss, which is
+    // the case for IGS's refine loop, whose loss only sees the colour image) contributes exact zeros everywhere, so the
+    // cheaper instance without it gives the same result.
+    const bool C = coord && (a.dL_dcoord || a.dL_dmcoord);
+    const bool D = depth && (a.dL_ddepth || a.dL_dmdepth);
+    const bool N = (coord || depth) && a.dL_dnormal;
+#define LAUNCH(c, d, n) hipLaunchKernelGGL((blend_bwd_kernel<c, d, n>), grid, block, 0, s, a)
+    if (C) { if (D) { if (N) LAUNCH(true, true, true); else LAUNCH(true, true, false); }
+             else   { if (N) LAUNCH(true, false, true); else LAUNCH(true, false, false); } }
+    else   { if (D) { if (N) LAUNCH(false, true, true); else LAUNCH(false, true, false); }
+             else   { if (N) LAUNCH(false, false, true); else LAUNCH(false, false, false); } }
+#undef LAUNCH
     return hipGetLastError();
 }

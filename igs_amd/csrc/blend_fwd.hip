@@ -21,7 +21,8 @@ blend_fwd_kernel(const BlendFwdArgs a)
     __shared__ uint64_t quad_bits[4][4];                // [quad][staging wave]
     __shared__ int wave_done[4];
 
-    const uint32_t tile = xcd_remap(blockIdx.x, gridDim.x);
+    uint32_t tile;
+    if (!tile_for_block(blockIdx.x, a.gx, a.gy, tile)) return;
     const uint32_t tx = tile % a.gx, ty = tile / a.gx;
     const uint32_t tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const uint32_t px = tx * TILE + (wid & 1) * 8 + (lane & 7);
@@ -88,7 +89,7 @@ blend_fwd_kernel(const BlendFwdArgs a)
                     const bool pass = !done && !(power > 0.0f) && !(alpha < 1.0f / 255.0f);
                     const bool contrib = pass && !(test_T < 0.0001f);
                     done = done || (pass && test_T < 0.0001f);
-                    if (__ballot(contrib) != 0ull) {
+                    {   // straight-line accumulate: after the per-quad culling nearly every splat that gets here contributes
                         const uint32_t contributor = (uint32_t)(i * CHUNK + j + 1);
                         const float aT = contrib ? alpha * T : 0.0f;
                         const float4 q2 = chunk[j * NQ + 2];               // b, ts, ray.x, ray.y
@@ -116,7 +117,8 @@ blend_fwd_kernel(const BlendFwdArgs a)
                         weight += aT;
                         T = contrib ? test_T : T;
                         last_contributor = contrib ? contributor : last_contributor;
-                    } else if (__ballot(!done) == 0ull) { wave_finished = true; break; }
+                    }
+                    if (__ballot(!done) == 0ull) { wave_finished = true; break; }
                     if (!more) break;
                     j = jn; q0 = nq0; q1 = nq1;
                 }
@@ -173,7 +175,7 @@ blend_fwd_kernel(const BlendFwdArgs a)
 
 hipError_t launch_blend_fwd(hipStream_t s, const BlendFwdArgs& a, bool coord, bool depth)
 {
-    const dim3 grid(a.gx * a.gy), block(256);
+    const dim3 grid(tile_grid_blocks(a.gx, a.gy)), block(256);
     // dispatch of forward.cu:732-739: NORMAL is on whenever COORD or DEPTH is
     if (coord && depth) hipLaunchKernelGGL((blend_fwd_kernel<true, true, true>), grid, block, 0, s, a);
     else if (coord) hipLaunchKernelGGL((blend_fwd_kernel<true, false, true>), grid, block, 0, s, a);

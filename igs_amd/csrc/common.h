@@ -188,7 +188,19 @@ __device__ __forceinline__ void get_rect(float px, float py, int max_radius, int
     x1 = min(gx, max(0, (int)((px + r + (float)TILE - 1.0f) / (float)TILE)));
     y1 = min(gy, max(0, (int)((py + r + (float)TILE - 1.0f) / (float)TILE)));
 }
-// XCD-aware bijective remap: blocks b, b+8, .. share an XCD (round-robin dispatch), give each XCD a contiguous band of tiles
+// XCD-aware tile assignment.  Workgroups are dealt round-robin over the 8 XCDs (b % 8 labels the XCD group; speed only,
+// never correctness).  XCD group x renders the tile ROWS x, x+8, x+16, ...: horizontally adjacent tiles (which share most
+// of their splats) run on one L2, and every XCD samples the whole image height, so a dense band of the image does not
+// land on a single XCD.  The grid is 8 * ceil(gy/8) * gx workgroups; the few that map past the last row exit at once.
+__device__ __forceinline__ bool tile_for_block(uint32_t b, uint32_t gx, uint32_t gy, uint32_t& tile) {
+    const uint32_t xcd = b & 7u, k = b >> 3;
+    const uint32_t row = xcd + 8u * (k / gx), col = k % gx;
+    tile = row * gx + col;
+    return row < gy;
+}
+static inline uint32_t tile_grid_blocks(uint32_t gx, uint32_t gy) { return 8u * ((gy + 7u) / 8u) * gx; }
+
+// XCD-aware bijective remap (contiguous bands; kept for comparison): blocks b, b+8, .. share an XCD (round-robin dispatch), give each XCD a contiguous band of tiles
 __device__ __forceinline__ uint32_t xcd_remap(uint32_t b, uint32_t n) {
     uint32_t q = n / 8, r = n % 8, xcd = b % 8, k = b / 8;
     uint32_t base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;

@@ -50,12 +50,22 @@ extern "C" int igs_adam_step(void* stream, size_t n, float* param, const float* 
 
 // L1: loss_sum += sum |pred - gt| ; grad = sign(pred - gt) * scale        (mean => scale = upstream / n)
 __global__ void __launch_bounds__(256)
-l1_kernel(size_t n, const float* __restrict__ pred, const float* __restrict__ gt, float* __restrict__ grad, float* __restrict__ loss_sum, float scale)
+l1_kernel(size_t n4, size_t n, const float* __restrict__ pred, const float* __restrict__ gt, float* __restrict__ grad, float* __restrict__ loss_sum, float scale)
 {
     __shared__ float ws[4];
     const size_t stride = (size_t)gridDim.x * 256;
     float acc = 0.f;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+        const float4 a = ((const float4*)pred)[i], b = ((const float4*)gt)[i];
+        float4 g;
+        float d;
+        d = a.x - b.x; acc += fabsf(d); g.x = d > 0.f ? scale : (d < 0.f ? -scale : 0.f);
+        d = a.y - b.y; acc += fabsf(d); g.y = d > 0.f ? scale : (d < 0.f ? -scale : 0.f);
+        d = a.z - b.z; acc += fabsf(d); g.z = d > 0.f ? scale : (d < 0.f ? -scale : 0.f);
+        d = a.w - b.w; acc += fabsf(d); g.w = d > 0.f ? scale : (d < 0.f ? -scale : 0.f);
+        ((float4*)grad)[i] = g;
+    }
+    for (size_t i = n4 * 4 + (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
         const float d = pred[i] - gt[i];
         acc += fabsf(d);
         grad[i] = d > 0.f ? scale : (d < 0.f ? -scale : 0.f);
@@ -71,8 +81,62 @@ extern "C" int igs_l1_loss_fwd_bwd(void* stream, size_t n, const float* pred, co
 {
     if (n == 0) return 0;
     if (!pred || !gt || !grad || !loss_sum) return IGS_RAST_E_INVALID;
-    size_t blocks = (n + 255) / 256;
+    const bool aligned = (((uintptr_t)pred | (uintptr_t)gt | (uintptr_t)grad) & 15) == 0;
+    const size_t n4 = aligned ? n / 4 : 0;
+    size_t blocks = (n / 4 + 255) / 256;
     if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(l1_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, n, pred, gt, grad, loss_sum, scale);
+    if (blocks == 0) blocks = 1;
+    hipLaunchKernelGGL(l1_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, n4, n, pred, gt, grad, loss_sum, scale);
+    return hipGetLastError() == hipSuccess ? 0 : IGS_RAST_E_HIP;
+}
+
+// ---- fused activations of the refine loop (igs/models/gaussian_model.py:90-127: sigmoid / exp / F.normalize) ----
+__global__ void __launch_bounds__(256)
+activate_fwd_kernel(int P, const float* __restrict__ logit, const float* __restrict__ log_scale, const float* __restrict__ rot,
+                    float* __restrict__ opacity, float* __restrict__ scale, float* __restrict__ rot_n)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= P) return;
+    opacity[i] = 1.0f / (1.0f + expf(-logit[i]));
+#pragma unroll
+    for (int k = 0; k < 3; k++) scale[3 * i + k] = expf(log_scale[3 * i + k]);
+    const float q0 = rot[4 * i], q1 = rot[4 * i + 1], q2 = rot[4 * i + 2], q3 = rot[4 * i + 3];
+    const float inv = 1.0f / fmaxf(sqrtf(q0 * q0 + q1 * q1 + q2 * q2 + q3 * q3), 1e-12f);       // F.normalize eps
+    rot_n[4 * i] = q0 * inv; rot_n[4 * i + 1] = q1 * inv; rot_n[4 * i + 2] = q2 * inv; rot_n[4 * i + 3] = q3 * inv;
+}
+__global__ void __launch_bounds__(256)
+activate_bwd_kernel(int P, const float* __restrict__ opacity, const float* __restrict__ scale, const float* __restrict__ rot,
+                    const float* __restrict__ d_opacity, const float* __restrict__ d_scale, const float* __restrict__ d_rot,
+                    float* __restrict__ g_logit, float* __restrict__ g_log_scale, float* __restrict__ g_rot)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= P) return;
+    const float s = opacity[i];
+    g_logit[i] = d_opacity[i] * s * (1.0f - s);
+#pragma unroll
+    for (int k = 0; k < 3; k++) g_log_scale[3 * i + k] = d_scale[3 * i + k] * scale[3 * i + k];
+    const float q0 = rot[4 * i], q1 = rot[4 * i + 1], q2 = rot[4 * i + 2], q3 = rot[4 * i + 3];
+    const float g0 = d_rot[4 * i], g1 = d_rot[4 * i + 1], g2 = d_rot[4 * i + 2], g3 = d_rot[4 * i + 3];
+    const float nrm = fmaxf(sqrtf(q0 * q0 + q1 * q1 + q2 * q2 + q3 * q3), 1e-12f);
+    const float inv = 1.0f / nrm;
+    const float n0 = q0 * inv, n1 = q1 * inv, n2 = q2 * inv, n3 = q3 * inv;
+    const float dt = n0 * g0 + n1 * g1 + n2 * g2 + n3 * g3;
+    g_rot[4 * i] = (g0 - n0 * dt) * inv; g_rot[4 * i + 1] = (g1 - n1 * dt) * inv;
+    g_rot[4 * i + 2] = (g2 - n2 * dt) * inv; g_rot[4 * i + 3] = (g3 - n3 * dt) * inv;
+}
+extern "C" int igs_activate_fwd(void* stream, int P, const float* logit, const float* log_scale, const float* rot, float* opacity,
+                                float* scale, float* rot_n)
+{
+    if (P <= 0) return 0;
+    if (!logit || !log_scale || !rot || !opacity || !scale || !rot_n) return IGS_RAST_E_INVALID;
+    hipLaunchKernelGGL(activate_fwd_kernel, dim3((P + 255) / 256), dim3(256), 0, (hipStream_t)stream, P, logit, log_scale, rot, opacity, scale, rot_n);
+    return hipGetLastError() == hipSuccess ? 0 : IGS_RAST_E_HIP;
+}
+extern "C" int igs_activate_bwd(void* stream, int P, const float* opacity, const float* scale, const float* rot, const float* d_opacity,
+                                const float* d_scale, const float* d_rot, float* g_logit, float* g_log_scale, float* g_rot)
+{
+    if (P <= 0) return 0;
+    if (!opacity || !scale || !rot || !d_opacity || !d_scale || !d_rot || !g_logit || !g_log_scale || !g_rot) return IGS_RAST_E_INVALID;
+    hipLaunchKernelGGL(activate_bwd_kernel, dim3((P + 255) / 256), dim3(256), 0, (hipStream_t)stream, P, opacity, scale, rot, d_opacity, d_scale, d_rot, g_logit, g_log_scale, g_rot);
     return hipGetLastError() == hipSuccess ? 0 : IGS_RAST_E_HIP;
 }

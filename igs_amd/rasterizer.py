@@ -44,17 +44,37 @@ def _prep(t, device, what):
 class _Scratch:
     """uint8 tensor grown on demand by the library (rasterize_points.cu:27-33, resizeFunctional)."""
 
-    def __init__(self, device):
+    def __init__(self, device, persistent=False):
         self.device = device
+        self.persistent = persistent
         self.tensor = torch.empty(0, dtype=torch.uint8, device=device)
         self.cb = _cabi.ALLOC_FN(self._alloc)
 
     def _alloc(self, _user, nbytes):
         try:
-            self.tensor = torch.empty(int(nbytes), dtype=torch.uint8, device=self.device)
+            if self.tensor.numel() < int(nbytes):          # persistent scratch only grows (by 25 % to avoid churn)
+                self.tensor = torch.empty(int(nbytes * (1.25 if self.persistent else 1.0)), dtype=torch.uint8, device=self.device)
             return self.tensor.data_ptr()
         except Exception:  # noqa: BLE001  (an exception must not cross the C frame)
             return None
+
+
+class RasterBuffers:
+    """Reusable output / scratch tensors for callers that render in a loop (the refine loop): one render's outputs are
+    overwritten by the next, so only use it when the previous results are no longer needed."""
+
+    def __init__(self):
+        self.key, self.imgs, self.radii, self.scratch, self.workspace = None, None, None, None, None
+
+    def get(self, P, H, W, dev):
+        key = (P, H, W, dev)
+        if key != self.key:
+            self.key = key
+            self.imgs = torch.zeros((15, H, W), dtype=torch.float32, device=dev)
+            self.radii = torch.zeros((P,), dtype=torch.int32, device=dev)
+            self.scratch = (_Scratch(dev, True), _Scratch(dev, True), _Scratch(dev, True))
+            self.workspace = torch.empty(_cabi.lib().igs_rast_backward_workspace_bytes(P), dtype=torch.uint8, device=dev)
+        return self.imgs, self.radii, self.scratch
 
 
 def _check(rc, what):
@@ -65,10 +85,11 @@ def _check(rc, what):
 
 def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp, viewmatrix,
                         projmatrix, tan_fovx, tan_fovy, kernel_size, image_height, image_width, sh, degree, campos,
-                        prefiltered, require_coord, require_depth, debug):
+                        prefiltered, require_coord, require_depth, debug, buffers=None):
     """`_C.rasterize_gaussians` (RasterizeGaussiansCUDA, DGR/rasterize_points.cu:35-133).
 
-    Returns (num_rendered, color, coord, mcoord, alpha, normal, depth, mdepth, radii, geomBuffer, binningBuffer, imgBuffer)."""
+    Returns (num_rendered, color, coord, mcoord, alpha, normal, depth, mdepth, radii, geomBuffer, binningBuffer, imgBuffer).
+    `buffers` (extension) is a RasterBuffers object whose image / radii / scratch tensors are reused across calls."""
     if means3D.dim() != 2 or means3D.size(1) != 3:
         raise RasterizerError("means3D must have dimensions (num_points, 3)")
     if not means3D.is_cuda:
@@ -85,11 +106,14 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
                                           _prep(projmatrix, dev, "projmatrix"), _prep(campos, dev, "campos"))
         M = sh_c.size(1) if sh_c is not None else 0
         # one allocation for the seven images; every pixel is written by the kernels when P > 0
-        imgs = (torch.empty if P > 0 else torch.zeros)((15, H, W), dtype=torch.float32, device=dev)
+        if buffers is not None:
+            imgs, radii, (geom, binning, img) = buffers.get(P, H, W, dev)
+        else:
+            imgs = (torch.empty if P > 0 else torch.zeros)((15, H, W), dtype=torch.float32, device=dev)
+            radii = torch.empty((P,), dtype=torch.int32, device=dev) if P > 0 else torch.zeros((0,), dtype=torch.int32, device=dev)
+            geom, binning, img = _Scratch(dev), _Scratch(dev), _Scratch(dev)
         color, coord, mcoord = imgs[0:3], imgs[3:6], imgs[6:9]
         depth, mdepth, alpha, normal = imgs[9:10], imgs[10:11], imgs[11:12], imgs[12:15]
-        radii = torch.empty((P,), dtype=torch.int32, device=dev) if P > 0 else torch.zeros((0,), dtype=torch.int32, device=dev)
-        geom, binning, img = _Scratch(dev), _Scratch(dev), _Scratch(dev)
         rendered = 0
         if P != 0:
             stream = torch.cuda.current_stream(dev).cuda_stream
@@ -107,14 +131,17 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
                                  viewmatrix, projmatrix, tan_fovx, tan_fovy, kernel_size, dL_dout_color, dL_dout_coord,
                                  dL_dout_mcoord, dL_dout_depth, dL_dout_mdepth, dL_dout_alpha, dL_dout_normal, normalmap, sh,
                                  degree, campos, geomBuffer, R, binningBuffer, imageBuffer, alphas, require_coord,
-                                 require_depth, debug):
+                                 require_depth, debug, out=None, workspace=None):
     """`_C.rasterize_gaussians_backward` (RasterizeGaussiansBackwardCUDA, DGR/rasterize_points.cu:135-246).
 
-    Returns (dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations)."""
+    Returns (dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations).
+    Extensions over the reference: any upstream gradient may be None (= zeros: the output was not used by the loss);
+    `out` may name preallocated contiguous destination tensors by those eight names (e.g. spans of a flat gradient
+    buffer), `workspace` a reusable uint8 scratch tensor."""
     L = _cabi.lib()
     dev = means3D.device
     P = means3D.size(0)
-    H, W = dL_dout_color.size(1), dL_dout_color.size(2)
+    H, W = alphas.size(-2), alphas.size(-1)
     with torch.cuda.device(dev):
         sh_c = _prep(sh, dev, "shs")
         M = sh_c.size(1) if sh_c is not None else 0
@@ -132,17 +159,24 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
             return t
         dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D = carve(3), carve(3), carve(1), carve(3)
         dL_dcov3D, dL_dscales, dL_drotations = carve(6), carve(3), carve(4)
+        if out:
+            dL_dmeans2D = out.get("means2D", dL_dmeans2D); dL_dcolors = out.get("colors", dL_dcolors)
+            dL_dopacity = out.get("opacity", dL_dopacity); dL_dmeans3D = out.get("means3D", dL_dmeans3D)
+            dL_dcov3D = out.get("cov3D", dL_dcov3D); dL_dsh = out.get("sh", dL_dsh)
+            dL_dscales = out.get("scales", dL_dscales); dL_drotations = out.get("rotations", dL_drotations)
         if P != 0:
             means3D_c = _prep(means3D, dev, "means3D")
             colors_c, scales_c, rotations_c, cov_c = (_prep(colors, dev, "colors_precomp"), _prep(scales, dev, "scales"),
                                                       _prep(rotations, dev, "rotations"), _prep(cov3D_precomp, dev, "cov3D_precomp"))
             bg_c, view_c, proj_c, campos_c = (_prep(background, dev, "bg"), _prep(viewmatrix, dev, "viewmatrix"),
                                               _prep(projmatrix, dev, "projmatrix"), _prep(campos, dev, "campos"))
-            grads = [_prep(g, dev, "grad") for g in (dL_dout_color, dL_dout_coord, dL_dout_mcoord, dL_dout_depth,
-                                                     dL_dout_mdepth, dL_dout_alpha, dL_dout_normal)]
+            grads = [None if g is None else _prep(g, dev, "grad") for g in (dL_dout_color, dL_dout_coord, dL_dout_mcoord,
+                                                                            dL_dout_depth, dL_dout_mdepth, dL_dout_alpha,
+                                                                            dL_dout_normal)]
             alphas_c, normal_c = _prep(alphas, dev, "alphas"), _prep(normalmap, dev, "normalmap")
             radii_c = radii.contiguous()
-            ws = torch.empty(L.igs_rast_backward_workspace_bytes(P), dtype=torch.uint8, device=dev)
+            need = L.igs_rast_backward_workspace_bytes(P)
+            ws = workspace if (workspace is not None and workspace.numel() >= need) else torch.empty(need, dtype=torch.uint8, device=dev)
             stream = torch.cuda.current_stream(dev).cuda_stream
             rc = L.igs_rast_backward(
                 stream, P, int(degree), M, int(R), _ptr(bg_c), W, H, _ptr(means3D_c), _ptr(sh_c), _ptr(colors_c), _ptr(alphas_c),
@@ -237,8 +271,8 @@ def _make_function(clamp_grads):
              alpha) = ctx.saved_tensors
             H, W = raster_settings.image_height, raster_settings.image_width
 
-            def z(g, c):   # autograd hands None for outputs that did not take part in the loss
-                return g if g is not None else torch.zeros((c, H, W), dtype=torch.float32, device=means3D.device)
+            def z(g, c):   # autograd hands None for outputs that did not take part in the loss: NULL = zeros in the C ABI
+                return g
 
             args = (raster_settings.bg, means3D, radii, colors_precomp, scales, rotations, raster_settings.scale_modifier,
                     cov3Ds_precomp, raster_settings.viewmatrix, raster_settings.projmatrix, raster_settings.tanfovx,

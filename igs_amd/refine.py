@@ -20,6 +20,7 @@ import torch
 import torch.nn.functional as F
 
 from . import _cabi
+from . import rasterizer as _rast
 from .rasterizer import GaussianRasterizationSettings, GaussianRasterizer
 
 GROUPS = (("xyz", 3), ("rotation", 4), ("shs", 48), ("opacity", 1), ("scaling", 3))
@@ -141,7 +142,7 @@ class Refiner:
     """One refine step = one view per rank: render, loss, backward, gradient all-reduce (N > 1), Adam."""
 
     def __init__(self, params, cams, gt_images, bg, loss="l1", lambda_l1=0.8, world_size=1, rank=0, seed=0,
-                 render_fn=None, adam_fn=None):
+                 render_fn=None, adam_fn=None, native=True):
         self.params, self.cams, self.gt, self.bg = params, cams, gt_images, bg
         self.loss, self.lambda_l1 = loss, lambda_l1
         self.world_size, self.rank = world_size, rank
@@ -149,6 +150,7 @@ class Refiner:
         self.render_fn = render if render_fn is None else render_fn
         self.adam_fn = params.adam_step if adam_fn is None else adam_fn
         self.l1 = L1Fused(params.device) if loss == "l1" else None
+        self.native = native          # L1 loss: drive the C ABI directly instead of going through autograd
         self.grad_img = None
         self.gen = torch.Generator().manual_seed(seed)      # same seed on every rank -> same view permutation
         self.order = []
@@ -163,11 +165,65 @@ class Refiner:
             picks.append(self.order.pop())
         return picks[self.rank]
 
+    def _native_step(self, cam, gt):
+        """render -> fused L1 -> backward -> activation backward, driving the C ABI directly (no autograd graph): the
+        rasterizer writes dL/dxyz and dL/dsh straight into their spans of the flat gradient buffer."""
+        p = self.params
+        L = _cabi.lib()
+        dev, P = p.device, p.P
+        if not hasattr(self, "_bufs"):
+            self._bufs = _rast.RasterBuffers()
+            self._act = torch.empty(8 * P, dtype=torch.float32, device=dev)       # opacity P | scale 3P | rot 4P
+            self._dact = torch.empty(8 * P, dtype=torch.float32, device=dev)
+            self._tmp = torch.empty(12 * P, dtype=torch.float32, device=dev)      # means2D 3 | colors 3 | cov3D 6
+            self._empty = torch.Tensor([])
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        raw = p.leaves
+        opac, scal, rotn = self._act[:P].view(P, 1), self._act[P:4 * P].view(P, 3), self._act[4 * P:].view(P, 4)
+        rc = L.igs_activate_fwd(stream, P, raw["opacity"].data_ptr(), raw["scaling"].data_ptr(), raw["rotation"].data_ptr(),
+                                opac.data_ptr(), scal.data_ptr(), rotn.data_ptr())
+        assert rc == 0
+        e = self._empty
+        with torch.no_grad():
+            out = _rast.rasterize_gaussians(self.bg, raw["xyz"].detach(), e, opac, scal, rotn, 1.0, e, cam.world_view_transform,
+                                            cam.full_proj_transform, cam.tanfovx, cam.tanfovy, 0.0, cam.height, cam.width,
+                                            raw["shs"].detach(), 3, cam.camera_center, False, True, True, False, buffers=self._bufs)
+            nr, color, coord, mcoord, alpha, normal, depth, mdepth, radii, gb, bb, ib = out
+            if self.grad_img is None or self.grad_img.shape != color.shape:
+                self.grad_img = torch.empty_like(color)
+            self.l1(color, gt, self.grad_img, weight=1.0 / self.world_size)
+            G = p.grad
+            def span(name, shape):
+                o, n = p.spans[name]
+                return G[o:o + n].view(shape)
+            d_op, d_sc, d_rt = self._dact[:P].view(P, 1), self._dact[P:4 * P].view(P, 3), self._dact[4 * P:].view(P, 4)
+            outs = dict(means3D=span("xyz", (P, 3)), sh=span("shs", (P, 16, 3)), opacity=d_op, scales=d_sc, rotations=d_rt,
+                        means2D=self._tmp[:3 * P].view(P, 3), colors=self._tmp[3 * P:6 * P].view(P, 3),
+                        cov3D=self._tmp[6 * P:].view(P, 6))
+            _rast.rasterize_gaussians_backward(self.bg, raw["xyz"].detach(), radii, e, scal, rotn, 1.0, e, cam.world_view_transform,
+                                               cam.full_proj_transform, cam.tanfovx, cam.tanfovy, 0.0, self.grad_img, None, None,
+                                               None, None, None, None, normal, raw["shs"].detach(), 3, cam.camera_center, gb, nr,
+                                               bb, ib, alpha, True, True, False, out=outs, workspace=self._bufs.workspace)
+            rc = L.igs_activate_bwd(stream, P, opac.data_ptr(), scal.data_ptr(), raw["rotation"].data_ptr(), d_op.data_ptr(),
+                                    d_sc.data_ptr(), d_rt.data_ptr(), span("opacity", (P, 1)).data_ptr(),
+                                    span("scaling", (P, 3)).data_ptr(), span("rotation", (P, 4)).data_ptr())
+            assert rc == 0
+        self.last_num_rendered = nr
+        return dict(images_pred=color, radii=radii, visibility_filter=None, viewspace_points=outs["means2D"], alpha=alpha,
+                    depth_pred=depth, normal=normal)
+
     def step(self, view=None):
         p = self.params
         if view is None:
             view = self._next_view()
         cam, gt = self.cams[view], self.gt[view]
+        if self.loss == "l1" and self.native and self.render_fn is render:
+            pkg = self._native_step(cam, gt)
+            if self.world_size > 1:
+                import torch.distributed as dist
+                dist.all_reduce(p.grad, op=dist.ReduceOp.SUM)
+            self.adam_fn()
+            return pkg
         p.zero_grad()
         act = p.activated()
         pkg = self.render_fn(act, cam, self.bg)

@@ -21,6 +21,8 @@
  *     like rasterizer_impl.cu:354); backward performs none;
  *   - image outputs of forward must be zero-filled by the caller when P == 0 (nothing is launched, as in
  *     rasterize_points.cu:90); for P > 0 every pixel of every output is written;
+ *   - any of backward's seven upstream image gradients may be NULL, meaning all zeros (the output did not take part in
+ *     the loss); geometry branches without any upstream gradient are skipped, the result is the same;
  *   - backward writes every element of its eight outputs (no pre-zeroing needed) and uses a caller-provided
  *     workspace of igs_rast_backward_workspace_bytes(P) bytes (contents undefined on entry).
  *
@@ -164,6 +166,13 @@ int igs_adam_step(void* stream, size_t n, float* param, const float* grad, float
 /* Fused L1 loss forward + backward (igs/utils/loss_utils.py:17-18): *loss_sum += sum |pred - gt| (caller zeroes it),
  * grad[i] = sign(pred[i] - gt[i]) * scale. */
 int igs_l1_loss_fwd_bwd(void* stream, size_t n, const float* pred, const float* gt, float* grad, float* loss_sum, float scale);
+
+/* Fused activations applied outside the rasterizer (igs/models/gaussian_model.py:90-127): opacity = sigmoid(logit),
+ * scale = exp(log_scale), rotation = F.normalize(rot) (eps 1e-12); and their backward. */
+int igs_activate_fwd(void* stream, int P, const float* logit, const float* log_scale, const float* rot, float* opacity,
+                     float* scale, float* rot_n);
+int igs_activate_bwd(void* stream, int P, const float* opacity, const float* scale, const float* rot, const float* d_opacity,
+                     const float* d_scale, const float* d_rot, float* g_logit, float* g_log_scale, float* g_rot);
 
 #ifdef __cplusplus
 }

@@ -417,3 +417,41 @@ def test_refine_loop_improves_psnr_and_fused_ops(dev):
     with torch.no_grad():
         p1 = float(psnr(render(params.activated(), cams[0], bg)["images_pred"], gts[0]))
     assert p1 > p0 + 1.0, (p0, p1)
+
+
+def test_native_step_equals_autograd_step_and_null_grads_equal_zero_grads(dev):
+    """(1) The autograd-free refine step (C ABI driven directly, fused activations) produces the gradients of the autograd path.
+    (2) Passing None for unused upstream gradients (what autograd hands over for a colour-only loss) equals passing zeros."""
+    from igs_amd.refine import GaussianParams, Refiner, render
+    from igs_amd.scenes import perturbed_copy
+    raw, cams, bg = cfg1_scene(P=3000, size=128)
+    cams = [cams[0].to(dev)]
+    bg = bg.to(dev)
+    gt_raw = {k: v.to(dev) for k, v in perturbed_copy(raw, sigma=0.03).items()}
+    with torch.no_grad():
+        gts = [render(activate(gt_raw), cams[0], bg)["images_pred"].clone()]
+    pa, pb = GaussianParams(raw, dev), GaussianParams(raw, dev)
+    ra = Refiner(pa, cams, gts, bg, loss="l1", native=True)
+    rb = Refiner(pb, cams, gts, bg, loss="l1", native=False)
+    ra.adam_fn = lambda: None
+    rb.adam_fn = lambda: None
+    ra.step(view=0); rb.step(view=0)
+    for k in pa.leaves:
+        A, B = pa.leaves[k].grad.cpu().numpy(), pb.leaves[k].grad.cpu().numpy()
+        r = rel(A, B)
+        assert np.quantile(r, 0.999) < 2e-3 and np.median(r) < 1e-5, (k, np.quantile(r, 0.999))
+    # (2)
+    a = activate(raw)
+    out, ad, mats = hip_forward(a, cams[0].to("cpu") if False else cfg1_scene(P=3000, size=128)[1][0], bg.cpu(), dev)
+    cam = cfg1_scene(P=3000, size=128)[1][0]
+    from igs_amd import rasterizer as R
+    nr, color, coord, mcoord, alpha, normal, depth, mdepth, radii, gb, bb, ib = out
+    g = torch.randn(color.shape, generator=torch.Generator().manual_seed(1)).to(dev)
+    common = (bg, ad["means3D"], radii, E, ad["scales"], ad["rotations"], 1.0, E, mats[0], mats[1], cam.tanfovx, cam.tanfovy, 0.0)
+    tail = (normal, ad["shs"], 3, mats[2], gb, nr, bb, ib, alpha, True, True, False)
+    z3, z1 = torch.zeros_like(color), torch.zeros_like(alpha)
+    g_zero = R.rasterize_gaussians_backward(*common, g, z3, z3, z1, z1, z1, z3, *tail)
+    g_none = R.rasterize_gaussians_backward(*common, g, None, None, None, None, None, None, *tail)
+    for n, x, y in zip(GNAMES, g_zero, g_none):
+        r = rel(x.cpu().numpy(), y.cpu().numpy())
+        assert np.quantile(r, 0.999) < 1e-3, (n, np.quantile(r, 0.999))

@@ -66,6 +66,8 @@ def test_algorithmic_bytes_formula():
     ab = bench.algorithmic_bytes(2_000_000, 1352, 1014)
     assert ab["blend_fwd"] == 2_000_000 * 100 + 1352 * 1014 * 88 + 8 * 5440       # SURVEY.md 8(d) example: ~0.32 GB
     assert ab["blend_bwd"] == 2_000_000 * 100 + 1352 * 1014 * 104 + 2_000_000 * 100
+    abc = bench.algorithmic_bytes(1000, 256, 256, True, True, False, False, False)
+    assert abc["blend_bwd"] == 1000 * 40 + 256 * 256 * 28 + 1000 * 100 and abc["blend_fwd"] == 1000 * 100 + 256 * 256 * 88 + 8 * 256
     ab0 = bench.algorithmic_bytes(1000, 256, 256, coord=False, depth=False)
     assert ab0["blend_fwd"] == 1000 * 40 + 256 * 256 * 24 + 8 * 256 and ab0["blend_bwd"] == 1000 * 40 + 256 * 256 * 28 + 1000 * 100
 
