@@ -139,8 +139,11 @@ extern "C" int igs_rast_forward(
     fp.view = viewmatrix; fp.proj = projmatrix; fp.campos = cam_pos;
 
     HIP_TRY(hipMemsetAsync(counters, 0, 16, s), "memset counters");
+    uint32_t dnb = 0, dper = 0;
+    sort_geometry((uint32_t)P, &dnb, &dper);
+    HIP_TRY(hipMemsetAsync(ghist, 0, (size_t)256 * SORT_MAX_BLOCKS * 4, s), "memset depth-sort histogram 0");
     prof_mark(s, ST_GAP);
-    HIP_TRY(launch_preprocess_fwd(s, fp, rec, tiles, keys_a, vals_a, radii, counters), "preprocess_fwd launch");
+    HIP_TRY(launch_preprocess_fwd(s, fp, rec, tiles, keys_a, vals_a, radii, counters, ghist, dper), "preprocess_fwd launch");
     DBG_SYNC("preprocess_fwd");
     prof_mark(s, ST_PREPROCESS);
     // instance count: read back while the depth sort runs
@@ -182,7 +185,12 @@ extern "C" int igs_rast_forward(
         uint32_t *ka, *kb, *va, *vb;
         if (passes % 2 == 0) { ka = bkeys_a; va = point_list; kb = bkeys_b; vb = bvals_b; }
         else                 { ka = bkeys_b; va = bvals_b;   kb = bkeys_a; vb = point_list; }
-        HIP_TRY(launch_emit_instances(s, P, gx, gy, order, tiles, blocksum, rec, radii, ka, va), "emit launch");
+        uint32_t tnb = 0, tper = 0;
+        sort_geometry(R, &tnb, &tper);
+        HIP_TRY(hipMemsetAsync(bhist, 0, (size_t)256 * SORT_MAX_BLOCKS * 4, s), "memset tile-sort histogram 0");
+        const uint32_t mask0 = bits >= 8 ? 255u : ((1u << bits) - 1u);
+        HIP_TRY(launch_emit_instances(s, P, gx, gy, order, tiles, blocksum, rec, radii, ka, va, passes ? bhist : nullptr, tper, mask0),
+                "emit launch");
         DBG_SYNC("emit");
         prof_mark(s, ST_EMIT);
         uint32_t *sk = nullptr, *sv = nullptr;

@@ -35,8 +35,9 @@ enum { GA_COLOR = 0, GA_VP = 3, GA_CP = 6, GA_TS = 12, GA_RP = 13, GA_NRM = 15, 
 
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
-#define SORT_ITEMS 16                      // elements per thread per sort sub-tile
-#define SORT_TILE (256 * SORT_ITEMS)       // 4096 elements per block sub-tile
+#define SORT_ITEMS 8                       // elements per thread per sort sub-tile
+#define SORT_TILE (256 * SORT_ITEMS)       // 2048 elements per block sub-tile
+#define SORT_MAX_PASSES 5                  // histogram tables kept per sort (32-bit keys: 4 passes)
 #define SORT_MAX_BLOCKS 256                // one block per CU
 
 struct GeomLayout {          // sizes in bytes, offsets from a 256-byte aligned base
@@ -49,7 +50,7 @@ struct GeomLayout {          // sizes in bytes, offsets from a 256-byte aligned 
         keys_b = o;   o += align_up(P * 4, 256);
         vals_a = o;   o += align_up(P * 4, 256);     // after the depth sort: Gaussian ids in depth order
         vals_b = o;   o += align_up(P * 4, 256);
-        hist = o;     o += align_up((size_t)256 * SORT_MAX_BLOCKS * 4, 256);
+        hist = o;     o += align_up((size_t)SORT_MAX_PASSES * 256 * SORT_MAX_BLOCKS * 4, 256);
         blocksum = o; o += align_up((P / 256 + 2) * 4, 256);   // per-256 block instance counts / offsets (depth order)
         counters = o; o += 256;                                // [0] total instances, [1] prefilter violation flag
         total = o + 256;
@@ -63,7 +64,7 @@ struct BinLayout {
         keys_a = o;     o += align_up(R * 4, 256);
         keys_b = o;     o += align_up(R * 4, 256);
         vals_b = o;     o += align_up(R * 4, 256);
-        hist = o;       o += align_up((size_t)256 * SORT_MAX_BLOCKS * 4, 256);
+        hist = o;       o += align_up((size_t)SORT_MAX_PASSES * 256 * SORT_MAX_BLOCKS * 4, 256);
         total = o + 256;
     }
 };
@@ -91,18 +92,20 @@ struct FwdParams {
 
 // ---- launchers (each returns hipError_t of the launch) ----
 hipError_t launch_preprocess_fwd(hipStream_t s, const FwdParams& p, float* rec, uint32_t* tiles, uint32_t* depth_keys,
-                                 uint32_t* ident, int* radii, uint32_t* counters);
+                                 uint32_t* ident, int* radii, uint32_t* counters, uint32_t* hist0, uint32_t per_block);
+void sort_geometry(uint32_t n, uint32_t* nb, uint32_t* per);
 hipError_t launch_mark_visible(hipStream_t s, int P, const float* means3D, const float* view, uint8_t* present);
 
 // stable LSD radix sort of (key,value) pairs on key bits [bit_lo, bit_hi); result ends in *out_keys/*out_vals
-// (ping-pong between a and b).  `hist` must hold 256*SORT_MAX_BLOCKS uint32.
+// (ping-pong between a and b).  `hist` holds SORT_MAX_PASSES tables of 256*SORT_MAX_BLOCKS uint32, zeroed by the caller
+// except table 0, which the producer of keys_a filled with the first pass's per-block digit counts.
 hipError_t radix_sort_pairs(hipStream_t s, uint32_t n, uint32_t* keys_a, uint32_t* keys_b, uint32_t* vals_a, uint32_t* vals_b,
                             uint32_t* hist, int bit_lo, int bit_hi, uint32_t** out_keys, uint32_t** out_vals);
 hipError_t launch_count_sorted(hipStream_t s, int P, const uint32_t* order, const uint32_t* tiles, uint32_t* blocksum);
 hipError_t launch_scan_blocksums(hipStream_t s, int nblocks, uint32_t* blocksum);
 hipError_t launch_emit_instances(hipStream_t s, int P, int gx, int gy, const uint32_t* order, const uint32_t* tiles,
                                  const uint32_t* blocksum, const float* rec, const int* radii, uint32_t* tile_keys,
-                                 uint32_t* vals);
+                                 uint32_t* vals, uint32_t* hist0, uint32_t per_block, uint32_t mask0);
 hipError_t launch_tile_ranges(hipStream_t s, uint32_t R, const uint32_t* tile_keys, uint32_t* ranges);
 
 struct BlendFwdArgs {

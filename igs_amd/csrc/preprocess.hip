@@ -40,7 +40,8 @@ struct PreArgs { FwdParams p; };
 
 __global__ void __launch_bounds__(256)
 preprocess_fwd_kernel(const PreArgs a, float* __restrict__ rec, uint32_t* __restrict__ tiles, uint32_t* __restrict__ depth_keys,
-                      uint32_t* __restrict__ ident, int* __restrict__ radii, uint32_t* __restrict__ counters)
+                      uint32_t* __restrict__ ident, int* __restrict__ radii, uint32_t* __restrict__ counters,
+                      uint32_t* __restrict__ hist0, uint32_t per_block)
 {
     const FwdParams& p = a.p;
     const int idx = blockIdx.x * 256 + threadIdx.x;
@@ -139,6 +140,7 @@ preprocess_fwd_kernel(const PreArgs a, float* __restrict__ rec, uint32_t* __rest
         tiles[idx] = my_tiles;
         depth_keys[idx] = dkey;
         ident[idx] = (uint32_t)idx;
+        atomicAdd(&hist0[((uint32_t)idx / per_block) * 256u + (dkey & 255u)], 1u);     // first pass of the depth sort
     }
     // total instance count: wave reduction, one atomic per wave that has something to add
     uint32_t v = my_tiles;
@@ -148,10 +150,11 @@ preprocess_fwd_kernel(const PreArgs a, float* __restrict__ rec, uint32_t* __rest
 }
 
 hipError_t launch_preprocess_fwd(hipStream_t s, const FwdParams& p, float* rec, uint32_t* tiles, uint32_t* depth_keys,
-                                 uint32_t* ident, int* radii, uint32_t* counters)
+                                 uint32_t* ident, int* radii, uint32_t* counters, uint32_t* hist0, uint32_t per_block)
 {
     PreArgs a; a.p = p;
-    hipLaunchKernelGGL(preprocess_fwd_kernel, dim3((p.P + 255) / 256), dim3(256), 0, s, a, rec, tiles, depth_keys, ident, radii, counters);
+    hipLaunchKernelGGL(preprocess_fwd_kernel, dim3((p.P + 255) / 256), dim3(256), 0, s, a, rec, tiles, depth_keys, ident, radii, counters,
+                       hist0, per_block);
     return hipGetLastError();
 }
 

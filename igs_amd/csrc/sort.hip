@@ -15,7 +15,44 @@
 
 __device__ __forceinline__ uint32_t digit_of(uint32_t key, int shift, uint32_t mask) { return (key >> shift) & mask; }
 
-// ---- pass 1: per-block digit histogram, block-major layout hist[b * RADIX + d] ----
+// Geometry of one sort: nb blocks, each owning `per` consecutive elements (a multiple of the 2048-element sub-tile).
+void sort_geometry(uint32_t n, uint32_t* nb_out, uint32_t* per_out)
+{
+    uint32_t nb = (n + SORT_TILE - 1) / SORT_TILE;
+    if (nb > SORT_MAX_BLOCKS) nb = SORT_MAX_BLOCKS;
+    if (nb == 0) nb = 1;
+    uint32_t per = (n + nb - 1) / nb;
+    per = (per + SORT_TILE - 1) / SORT_TILE * SORT_TILE;
+    if (per == 0) per = SORT_TILE;
+    nb = (n + per - 1) / per;
+    if (nb == 0) nb = 1;
+    *nb_out = nb; *per_out = per;
+}
+
+// ---- single-block exclusive scan (in place) of up to a few 100k uint32 (used for the per-256 instance counts) ----
+__global__ void __launch_bounds__(1024)
+exclusive_scan_kernel(uint32_t* __restrict__ data, uint32_t n, uint32_t* __restrict__ total)
+{
+    __shared__ uint32_t wave_sums[16];
+    __shared__ uint32_t carry_s;
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const uint32_t per = (n + 1023) / 1024;
+    const uint32_t beg = min(n, tid * per), end = min(n, beg + per);
+    uint32_t sum = 0;
+    for (uint32_t i = beg; i < end; i++) sum += data[i];
+    uint32_t v = sum;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) { uint32_t t = __shfl_up(v, off, 64); if (lane >= (uint32_t)off) v += t; }
+    if (lane == 63) wave_sums[wid] = v;
+    __syncthreads();
+    if (tid == 0) { uint32_t c = 0; for (int w = 0; w < 16; w++) { uint32_t t = wave_sums[w]; wave_sums[w] = c; c += t; } carry_s = c; }
+    __syncthreads();
+    uint32_t run = v - sum + wave_sums[wid];
+    for (uint32_t i = beg; i < end; i++) { uint32_t t = data[i]; data[i] = run; run += t; }
+    if (total && tid == 0) *total = carry_s;
+}
+
+// ---- per-block digit histogram for the passes after the first (LDS atomics absorb low-entropy digits) ----
 __global__ void __launch_bounds__(256)
 radix_hist_kernel(const uint32_t* __restrict__ keys, uint32_t n, uint32_t per_block, int shift, uint32_t mask, uint32_t* __restrict__ hist)
 {
@@ -29,50 +66,45 @@ radix_hist_kernel(const uint32_t* __restrict__ keys, uint32_t n, uint32_t per_bl
     hist[blockIdx.x * RADIX + threadIdx.x] = h[threadIdx.x];
 }
 
-// ---- single-block exclusive scan (in place) of up to a few 100k uint32; also returns the total in *total if given ----
-__global__ void __launch_bounds__(1024)
-exclusive_scan_kernel(uint32_t* __restrict__ data, uint32_t n, uint32_t* __restrict__ total)
-{
-    __shared__ uint32_t wave_sums[16];
-    __shared__ uint32_t carry_s;
-    const uint32_t tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const uint32_t per = (n + 1023) / 1024;
-    const uint32_t beg = min(n, tid * per), end = min(n, beg + per);
-    uint32_t sum = 0;
-    for (uint32_t i = beg; i < end; i++) sum += data[i];
-    // inclusive scan of `sum` across the 1024 threads
-    uint32_t v = sum;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) { uint32_t t = __shfl_up(v, off, 64); if (lane >= (uint32_t)off) v += t; }
-    if (lane == 63) wave_sums[wid] = v;
-    __syncthreads();
-    if (tid == 0) { uint32_t c = 0; for (int w = 0; w < 16; w++) { uint32_t t = wave_sums[w]; wave_sums[w] = c; c += t; } carry_s = c; }
-    __syncthreads();
-    uint32_t run = v - sum + wave_sums[wid];
-    for (uint32_t i = beg; i < end; i++) { uint32_t t = data[i]; data[i] = run; run += t; }
-    if (total && tid == 0) *total = carry_s;
-}
-
-// ---- pass 3: stable scatter ----
+// ---- one stable radix pass ----
+// hist_cur[b * 256 + d] = number of keys with digit d in block b's slice (for the first pass it was accumulated with
+// global atomics by the kernel that PRODUCED the keys -- preprocess / emit --, for later passes by radix_hist_kernel).
+// There is no scan launch: every block derives its digit bases from the table itself, then ranks its keys stably
+// (wave-level match-any + per-wave LDS counters) and scatters.
 __global__ void __launch_bounds__(256)
 radix_scatter_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in, uint32_t* __restrict__ keys_out,
                      uint32_t* __restrict__ vals_out, uint32_t n, uint32_t per_block, int shift, uint32_t mask,
-                     const uint32_t* __restrict__ hist)
+                     const uint32_t* __restrict__ hist_cur)
 {
     __shared__ uint32_t wave_cnt[4][RADIX];
     __shared__ uint32_t base[RADIX];
     const uint32_t tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const uint64_t lt_mask = (1ull << lane) - 1ull;
-    {   // base[d] = (keys with a smaller digit, all blocks) + (keys with digit d in earlier blocks): every block derives it
-        // from the block-major histogram table itself (coalesced 1 KB rows, L2 resident) -- no separate scan launch
-        uint32_t before = 0, total = 0;
-        const uint32_t nb = gridDim.x;
-        for (uint32_t b = 0; b < nb; b++) { const uint32_t c = hist[b * RADIX + tid]; total += c; before += (b < blockIdx.x) ? c : 0u; }
-        // exclusive scan of `total` over the 256 digits (4 waves)
+    {   // base[d] = (keys with a smaller digit, all blocks) + (keys with digit d in earlier blocks)
+        // wave w sums the rows b = w, w+4, ... of the table, 4 digits (16 B) per lane, several rows in flight
+        const uint32_t nb = gridDim.x, me = blockIdx.x;
+        uint4 tot = make_uint4(0, 0, 0, 0), bef = make_uint4(0, 0, 0, 0);
+        const uint4* tab = (const uint4*)hist_cur;
+#pragma unroll 4
+        for (uint32_t b = wid; b < nb; b += 4) {
+            const uint4 c = tab[b * (RADIX / 4) + lane];
+            tot.x += c.x; tot.y += c.y; tot.z += c.z; tot.w += c.w;
+            if (b < me) { bef.x += c.x; bef.y += c.y; bef.z += c.z; bef.w += c.w; }
+        }
+        // wave_cnt[w][0..255] <- totals, base (via a second pass) <- befores
+        ((uint4*)wave_cnt[wid])[lane] = tot;
+        __syncthreads();
+        const uint32_t total = wave_cnt[0][tid] + wave_cnt[1][tid] + wave_cnt[2][tid] + wave_cnt[3][tid];
+        __syncthreads();
+        ((uint4*)wave_cnt[wid])[lane] = bef;
+        __syncthreads();
+        const uint32_t before = wave_cnt[0][tid] + wave_cnt[1][tid] + wave_cnt[2][tid] + wave_cnt[3][tid];
+        // exclusive scan of `total` over the 256 digits
         uint32_t v = total;
 #pragma unroll
         for (int off = 1; off < 64; off <<= 1) { const uint32_t t = __shfl_up(v, off, 64); if (lane >= (uint32_t)off) v += t; }
-        if (lane == 63) base[wid] = v;            // base[0..3] temporarily hold the wave totals
+        __syncthreads();
+        if (lane == 63) base[wid] = v;
         __syncthreads();
         uint32_t woff = 0;
         for (uint32_t w = 0; w < wid; w++) woff += base[w];
@@ -82,6 +114,7 @@ radix_scatter_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __res
     const uint32_t beg = blockIdx.x * per_block;
     const uint32_t end = min(n, beg + per_block);
     for (uint32_t sub = beg; sub < end; sub += SORT_TILE) {
+        __syncthreads();
 #pragma unroll
         for (int w = 0; w < 4; w++) wave_cnt[w][tid] = 0;
         __syncthreads();
@@ -131,25 +164,25 @@ radix_scatter_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __res
                 vals_out[pos] = val[i];
             }
         }
-        __syncthreads();
     }
 }
 
+// hist: SORT_MAX_PASSES tables of RADIX*SORT_MAX_BLOCKS counters; table 0 (zeroed by the caller before the producer ran)
+// already holds the first pass's histogram, filled by the kernel that wrote keys_a.
 hipError_t radix_sort_pairs(hipStream_t s, uint32_t n, uint32_t* keys_a, uint32_t* keys_b, uint32_t* vals_a, uint32_t* vals_b,
                             uint32_t* hist, int bit_lo, int bit_hi, uint32_t** out_keys, uint32_t** out_vals)
 {
     uint32_t *kin = keys_a, *kout = keys_b, *vin = vals_a, *vout = vals_b;
     if (n > 0) {
-        uint32_t nb = (n + SORT_TILE - 1) / SORT_TILE;
-        if (nb > SORT_MAX_BLOCKS) nb = SORT_MAX_BLOCKS;
-        uint32_t per = (n + nb - 1) / nb;
-        per = (per + SORT_TILE - 1) / SORT_TILE * SORT_TILE;
-        nb = (n + per - 1) / per;
-        for (int lo = bit_lo; lo < bit_hi; lo += 8) {
+        uint32_t nb, per;
+        sort_geometry(n, &nb, &per);
+        int pass = 0;
+        for (int lo = bit_lo; lo < bit_hi; lo += 8, pass++) {
             const int nbits = (bit_hi - lo) < 8 ? (bit_hi - lo) : 8;
             const uint32_t mask = (1u << nbits) - 1u;
-            hipLaunchKernelGGL(radix_hist_kernel, dim3(nb), dim3(256), 0, s, kin, n, per, lo, mask, hist);
-            hipLaunchKernelGGL(radix_scatter_kernel, dim3(nb), dim3(256), 0, s, kin, vin, kout, vout, n, per, lo, mask, hist);
+            uint32_t* hcur = hist + (size_t)pass * RADIX * SORT_MAX_BLOCKS;
+            if (pass > 0) hipLaunchKernelGGL(radix_hist_kernel, dim3(nb), dim3(256), 0, s, kin, n, per, lo, mask, hcur);
+            hipLaunchKernelGGL(radix_scatter_kernel, dim3(nb), dim3(256), 0, s, kin, vin, kout, vout, n, per, lo, mask, hcur);
             uint32_t* t = kin; kin = kout; kout = t;
             t = vin; vin = vout; vout = t;
         }
@@ -186,7 +219,8 @@ hipError_t launch_scan_blocksums(hipStream_t s, int nblocks, uint32_t* blocksum)
 __global__ void __launch_bounds__(256)
 emit_instances_kernel(int P, int gx, int gy, const uint32_t* __restrict__ order, const uint32_t* __restrict__ tiles,
                       const uint32_t* __restrict__ blocksum, const float* __restrict__ rec, const int* __restrict__ radii,
-                      uint32_t* __restrict__ tile_keys, uint32_t* __restrict__ vals)
+                      uint32_t* __restrict__ tile_keys, uint32_t* __restrict__ vals, uint32_t* __restrict__ hist0,
+                      uint32_t per_block, uint32_t mask0)
 {
     __shared__ uint32_t incl[256];     // inclusive scan of instance counts
     __shared__ uint32_t gid[256];
@@ -225,16 +259,18 @@ emit_instances_kernel(int P, int gx, int gy, const uint32_t* __restrict__ order,
         const uint32_t local = k - (j ? incl[j - 1] : 0u);
         const int w = rw[j];
         const int ty = ry0[j] + (int)(local / (uint32_t)w), tx = rx0[j] + (int)(local % (uint32_t)w);
-        tile_keys[base + k] = (uint32_t)(ty * gx + tx);
+        const uint32_t tkey = (uint32_t)(ty * gx + tx);
+        tile_keys[base + k] = tkey;
         vals[base + k] = gid[j];
+        if (hist0) atomicAdd(&hist0[((base + k) / per_block) * RADIX + (tkey & mask0)], 1u);      // first radix pass's histogram
     }
 }
 hipError_t launch_emit_instances(hipStream_t s, int P, int gx, int gy, const uint32_t* order, const uint32_t* tiles,
                                  const uint32_t* blocksum, const float* rec, const int* radii, uint32_t* tile_keys,
-                                 uint32_t* vals)
+                                 uint32_t* vals, uint32_t* hist0, uint32_t per_block, uint32_t mask0)
 {
     hipLaunchKernelGGL(emit_instances_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, gx, gy, order, tiles, blocksum, rec,
-                       radii, tile_keys, vals);
+                       radii, tile_keys, vals, hist0, per_block, mask0);
     return hipGetLastError();
 }
 
