@@ -11,7 +11,9 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libigs_rast.so")
 SOURCES = ["api.hip", "preprocess.hip", "sort.hip", "blend_fwd.hip", "blend_bwd.hip", "geom_bwd.hip", "refine_ops.hip"]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-Wno-unused-variable"]
+# -fno-slp-vectorize: on gfx950 v_pk_*_f32 runs at the scalar-f32 rate per element, so SLP packing only adds v_mov shuffles
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-Wno-unused-variable",
+         "-fno-slp-vectorize"]
 
 
 def _hipcc():

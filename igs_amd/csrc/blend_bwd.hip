@@ -107,12 +107,19 @@ blend_bwd_kernel(const BlendBwdArgs a)
     __syncthreads();
     const int n = max(max(wave_max[0], wave_max[1]), max(wave_max[2], wave_max[3]));   // elements [0, n) of the range
     const int rounds = (n + BCHUNK - 1) / BCHUNK;
-    for (int k = 0; k < GA_USED; k++) red[wid][k * RED_STRIDE + lane] = 0.f;
 
     float T = T_final, S = 0.f, Dprev = 0.f, last_alpha = 0.f;
+    const bool has_bg = (a.bg[0] != 0.f) || (a.bg[1] != 0.f) || (a.bg[2] != 0.f);      // wave-uniform
     const float halfW = 0.5f * a.W, halfH = 0.5f * a.H;
     float* myred = red[wid];
-    const int rk = lane & 31, rh = lane >> 5;            // this lane sums row rk, half rh of the transpose buffer
+    constexpr int NROWS = 10 + (COORD ? 9 : 0) + (DEPTH ? 3 : 0) + (NORMAL ? 3 : 0);   // live moments of this instance
+    constexpr int LPR = NROWS <= 16 ? 4 : 2;             // lanes per row of the transpose buffer
+    const int rrow = lane & (64 / LPR - 1), rpart = lane / (64 / LPR);
+    // gacc slot of compact row `lane` (rows are emitted in slot order with the dead groups left out)
+    int slot_of_row = (int)lane;
+    if (!COORD && slot_of_row >= 3) slot_of_row += 9;
+    if (!DEPTH && slot_of_row >= 12) slot_of_row += 3;
+    if (!NORMAL && slot_of_row >= 15) slot_of_row += 3;
 
     for (int i = 0; i < rounds; i++) {
         __syncthreads();
@@ -158,8 +165,9 @@ blend_bwd_kernel(const BlendBwdArgs a)
                 if (__ballot(valid) == 0ull) continue;
 
                 const float4 q2 = chunk[j * NQ + 2];
-                const float one_m = 1.f - alpha;
-                T = valid ? T / one_m : T;
+                // 1/(1-alpha) once (v_rcp_f32, 1 ulp) instead of two IEEE divisions; 1-alpha >= 0.01
+                const float inv_one_m = __builtin_amdgcn_rcpf(1.f - alpha);
+                T = valid ? T * inv_one_m : T;
                 const float w = valid ? alpha * T : 0.f;
                 const bool is_med = valid && ((uint32_t)(eidx + 1) == max_contributor);
 
@@ -185,7 +193,8 @@ blend_bwd_kernel(const BlendBwdArgs a)
                 if constexpr (NORMAL) D += q3.w * gn0 + q5.z * gn1 + q5.w * gn2;
 
                 const float Snew = last_alpha * Dprev + (1.f - last_alpha) * S;
-                const float dL_dopa = (D - Snew) * T + (-T_final / one_m) * bg_dot;
+                float dL_dopa = (D - Snew) * T;
+                if (has_bg) dL_dopa += (-T_final * inv_one_m) * bg_dot;
                 S = valid ? Snew : S;
                 Dprev = valid ? D : Dprev;
                 last_alpha = valid ? alpha : last_alpha;
@@ -195,35 +204,33 @@ blend_bwd_kernel(const BlendBwdArgs a)
                 const float gxa = q0.z * qdx + q0.w * qdy;      // -dL/d(delx) of the Gaussian term
                 const float gya = q1.x * qdy + q0.w * qdx;
 
-                // ---- transpose-reduce over the 64 pixels of the wave: row k of `myred` = the 64 per-lane values of moment k
+                // ---- transpose-reduce over the 64 pixels of the wave: row r of `myred` = the 64 per-lane values of one LIVE
+                // moment (rows are compacted per template instance: 25 with every branch on, 10 for colour-only gradients)
                 float* col = myred + lane;
-                col[0 * RED_STRIDE] = w * gp0; col[1 * RED_STRIDE] = w * gp1; col[2 * RED_STRIDE] = w * gp2;
+                int r = 0;
+                col[(r++) * RED_STRIDE] = w * gp0; col[(r++) * RED_STRIDE] = w * gp1; col[(r++) * RED_STRIDE] = w * gp2;
                 if constexpr (COORD) {
-                    col[3 * RED_STRIDE] = dLc0; col[4 * RED_STRIDE] = dLc1; col[5 * RED_STRIDE] = dLc2;
-                    col[6 * RED_STRIDE] = dLc0 * dx; col[7 * RED_STRIDE] = dLc1 * dx; col[8 * RED_STRIDE] = dLc2 * dx;
-                    col[9 * RED_STRIDE] = dLc0 * dy; col[10 * RED_STRIDE] = dLc1 * dy; col[11 * RED_STRIDE] = dLc2 * dy;
+                    col[(r++) * RED_STRIDE] = dLc0; col[(r++) * RED_STRIDE] = dLc1; col[(r++) * RED_STRIDE] = dLc2;
+                    col[(r++) * RED_STRIDE] = dLc0 * dx; col[(r++) * RED_STRIDE] = dLc1 * dx; col[(r++) * RED_STRIDE] = dLc2 * dx;
+                    col[(r++) * RED_STRIDE] = dLc0 * dy; col[(r++) * RED_STRIDE] = dLc1 * dy; col[(r++) * RED_STRIDE] = dLc2 * dy;
                 }
-                if constexpr (DEPTH) { col[12 * RED_STRIDE] = dLt; col[13 * RED_STRIDE] = dLt * dx; col[14 * RED_STRIDE] = dLt * dy; }
-                if constexpr (NORMAL) { col[15 * RED_STRIDE] = w * gn0; col[16 * RED_STRIDE] = w * gn1; col[17 * RED_STRIDE] = w * gn2; }
-                col[18 * RED_STRIDE] = q; col[19 * RED_STRIDE] = qdx; col[20 * RED_STRIDE] = qdy;
-                col[21 * RED_STRIDE] = qdx * dx; col[22 * RED_STRIDE] = qdx * dy; col[23 * RED_STRIDE] = qdy * dy;
-                col[24 * RED_STRIDE] = fabsf(gxa * halfW) + fabsf(gya * halfH);
-                // rows that are structurally zero in this template instance were zeroed once before the loop
+                if constexpr (DEPTH) { col[(r++) * RED_STRIDE] = dLt; col[(r++) * RED_STRIDE] = dLt * dx; col[(r++) * RED_STRIDE] = dLt * dy; }
+                if constexpr (NORMAL) { col[(r++) * RED_STRIDE] = w * gn0; col[(r++) * RED_STRIDE] = w * gn1; col[(r++) * RED_STRIDE] = w * gn2; }
+                col[(r++) * RED_STRIDE] = q; col[(r++) * RED_STRIDE] = qdx; col[(r++) * RED_STRIDE] = qdy;
+                col[(r++) * RED_STRIDE] = qdx * dx; col[(r++) * RED_STRIDE] = qdx * dy; col[(r++) * RED_STRIDE] = qdy * dy;
+                col[(r++) * RED_STRIDE] = fabsf(gxa * halfW) + fabsf(gya * halfH);
+                // LPR lanes share a row (each sums 64/LPR columns), then LPR partials are combined across lanes
                 float part = 0.f;
-                if (rk < GA_USED) {
-                    const float4* row = (const float4*)(myred + rk * RED_STRIDE + rh * 32);
-                    float4 s0 = row[0], s1 = row[1], s2 = row[2], s3 = row[3], s4 = row[4], s5 = row[5], s6 = row[6], s7 = row[7];
-                    s0.x += s1.x; s0.y += s1.y; s0.z += s1.z; s0.w += s1.w;
-                    s2.x += s3.x; s2.y += s3.y; s2.z += s3.z; s2.w += s3.w;
-                    s4.x += s5.x; s4.y += s5.y; s4.z += s5.z; s4.w += s5.w;
-                    s6.x += s7.x; s6.y += s7.y; s6.z += s7.z; s6.w += s7.w;
-                    s0.x += s2.x; s0.y += s2.y; s0.z += s2.z; s0.w += s2.w;
-                    s4.x += s6.x; s4.y += s6.y; s4.z += s6.z; s4.w += s6.w;
-                    s0.x += s4.x; s0.y += s4.y; s0.z += s4.z; s0.w += s4.w;
-                    part = (s0.x + s0.y) + (s0.z + s0.w);
+                if (rrow < NROWS) {
+                    const float4* row = (const float4*)(myred + rrow * RED_STRIDE + rpart * (64 / LPR));
+                    float4 acc4 = row[0];
+#pragma unroll
+                    for (int k = 1; k < 16 / LPR; k++) { const float4 t4 = row[k]; acc4.x += t4.x; acc4.y += t4.y; acc4.z += t4.z; acc4.w += t4.w; }
+                    part = (acc4.x + acc4.y) + (acc4.z + acc4.w);
                 }
-                const float tot = part + __shfl_xor(part, 32, 64);
-                if (lane < GA_USED) atomicAdd(&a.gacc[(size_t)chunk_id[j] * GACC_F + lane], tot);
+                float tot = part + __shfl_xor(part, 32, 64);
+                if constexpr (LPR == 4) tot += __shfl_xor(tot, 16, 64);
+                if (lane < NROWS) atomicAdd(&a.gacc[(size_t)chunk_id[j] * GACC_F + slot_of_row], tot);
             }
         }
     }

@@ -68,19 +68,12 @@ blend_fwd_kernel(const BlendFwdArgs a)
         if (__ballot(!done) != 0ull) {
             bool wave_finished = false;
             for (int sw = 0; sw < 4 && !wave_finished; sw++) {
-                uint64_t bits = quad_bits[wid][sw];                // wave-uniform
-                bits = uniform64(bits);
-                if (bits == 0ull) continue;
-                int j = sw * 64 + __builtin_ctzll(bits);
-                bits &= bits - 1;
-                float4 q0 = chunk[j * NQ + 0], q1 = chunk[j * NQ + 1];
-                while (true) {
-                    // prefetch the next splat of this wave's list
-                    const bool more = bits != 0ull;
-                    const int jn = more ? sw * 64 + __builtin_ctzll(bits) : j;
+                uint64_t bits = uniform64(quad_bits[wid][sw]);     // wave-uniform
+                while (bits != 0ull) {
+                    const int j = sw * 64 + __builtin_ctzll(bits);
                     bits &= bits - 1;
-                    const float4 nq0 = chunk[jn * NQ + 0], nq1 = chunk[jn * NQ + 1];
-
+                    const float4* r = &chunk[j * NQ];
+                    const float4 q0 = r[0], q1 = r[1], q2 = r[2];
                     const float dx = q0.x - pixfx, dy = q0.y - pixfy;
                     const float power = gauss_power(q0.z, q0.w, q1.x, dx, dy);
                     const float alpha = fminf(0.99f, q1.y * __expf(power));
@@ -89,38 +82,34 @@ blend_fwd_kernel(const BlendFwdArgs a)
                     const bool pass = !done && !(power > 0.0f) && !(alpha < 1.0f / 255.0f);
                     const bool contrib = pass && !(test_T < 0.0001f);
                     done = done || (pass && test_T < 0.0001f);
-                    {   // straight-line accumulate: after the per-quad culling nearly every splat that gets here contributes
-                        const uint32_t contributor = (uint32_t)(i * CHUNK + j + 1);
-                        const float aT = contrib ? alpha * T : 0.0f;
-                        const float4 q2 = chunk[j * NQ + 2];               // b, ts, ray.x, ray.y
-                        C0 += q1.z * aT; C1 += q1.w * aT; C2 += q2.x * aT;
-                        const bool before_median = contrib && T > 0.5f;
-                        if constexpr (GEO) {
-                            const float4 q3 = chunk[j * NQ + 3];           // view_point, n.x
-                            const float4 q5 = chunk[j * NQ + 5];           // cp4, cp5, n.y, n.z
-                            if constexpr (COORD) {
-                                const float4 q4 = chunk[j * NQ + 4];       // cp0..3
-                                const float c0 = q3.x + q4.x * dx + q4.y * dy;
-                                const float c1 = q3.y + q4.z * dx + q4.w * dy;
-                                const float c2 = q3.z + q5.x * dx + q5.y * dy;
-                                Co0 += c0 * aT; Co1 += c1 * aT; Co2 += c2 * aT;
-                                mC0 = before_median ? c0 : mC0; mC1 = before_median ? c1 : mC1; mC2 = before_median ? c2 : mC2;
-                            }
-                            if constexpr (DEPTH) {
-                                const float t = q2.y + (q2.z * dx + q2.w * dy);
-                                Depth += t * aT;
-                                mDepth = before_median ? t : mDepth;
-                            }
-                            if constexpr (NORMAL) { N0 += q3.w * aT; N1 += q5.z * aT; N2 += q5.w * aT; }
-                            max_contributor = before_median ? contributor : max_contributor;
+                    // straight-line accumulate: after the per-quad culling nearly every splat that gets here contributes
+                    const uint32_t contributor = (uint32_t)(i * CHUNK + j + 1);
+                    const float aT = contrib ? alpha * T : 0.0f;
+                    C0 += q1.z * aT; C1 += q1.w * aT; C2 += q2.x * aT;
+                    const bool before_median = contrib && T > 0.5f;
+                    if constexpr (GEO) {
+                        const float4 q3 = r[3];                            // view_point, n.x
+                        const float4 q5 = r[5];                            // cp4, cp5, n.y, n.z
+                        if constexpr (COORD) {
+                            const float4 q4 = r[4];                        // cp0..3
+                            const float c0 = q3.x + q4.x * dx + q4.y * dy;
+                            const float c1 = q3.y + q4.z * dx + q4.w * dy;
+                            const float c2 = q3.z + q5.x * dx + q5.y * dy;
+                            Co0 += c0 * aT; Co1 += c1 * aT; Co2 += c2 * aT;
+                            mC0 = before_median ? c0 : mC0; mC1 = before_median ? c1 : mC1; mC2 = before_median ? c2 : mC2;
                         }
-                        weight += aT;
-                        T = contrib ? test_T : T;
-                        last_contributor = contrib ? contributor : last_contributor;
+                        if constexpr (DEPTH) {
+                            const float t = q2.y + (q2.z * dx + q2.w * dy);
+                            Depth += t * aT;
+                            mDepth = before_median ? t : mDepth;
+                        }
+                        if constexpr (NORMAL) { N0 += q3.w * aT; N1 += q5.z * aT; N2 += q5.w * aT; }
+                        max_contributor = before_median ? contributor : max_contributor;
                     }
+                    weight += aT;
+                    T = contrib ? test_T : T;
+                    last_contributor = contrib ? contributor : last_contributor;
                     if (__ballot(!done) == 0ull) { wave_finished = true; break; }
-                    if (!more) break;
-                    j = jn; q0 = nq0; q1 = nq1;
                 }
             }
         }
