@@ -5,6 +5,7 @@
 #include "../../include/igs_rast.h"
 #include <stdio.h>
 #include <string.h>
+#include <stdlib.h>
 
 static thread_local char g_err[512] = "";
 static int fail(int code, const char* what, hipError_t e = hipSuccess)
@@ -25,7 +26,7 @@ static int ensure_slot()
     HIP_TRY(hipGetDevice(&dev), "hipGetDevice");
     if (g_slot.device == dev && g_slot.pinned) return 0;
     if (g_slot.pinned) { (void)hipHostFree(g_slot.pinned); (void)hipEventDestroy(g_slot.ev); g_slot = HostSlot(); }
-    HIP_TRY(hipHostMalloc((void**)&g_slot.pinned, 64, hipHostMallocDefault), "hipHostMalloc");
+    HIP_TRY(hipHostMalloc((void**)&g_slot.pinned, (COUNTER_SHARDS + 1) * COUNTER_SHARD_STRIDE * 4, hipHostMallocDefault), "hipHostMalloc");
     HIP_TRY(hipEventCreateWithFlags(&g_slot.ev, hipEventDisableTiming), "hipEventCreate");
     g_slot.device = dev;
     return 0;
@@ -136,9 +137,11 @@ extern "C" int igs_rast_forward(
     fp.scale_modifier = scale_modifier; fp.tan_fovx = tan_fovx; fp.tan_fovy = tan_fovy;
     fp.fy = height / (2.0f * tan_fovy); fp.fx = width / (2.0f * tan_fovx);       // rasterizer_impl.cu:288-289
     fp.kernel_size = kernel_size; fp.prefiltered = prefiltered;
+    { const char* e = getenv("IGS_DBG_SKIP"); fp.dbg_skip = e ? atoi(e) : 0; }
     fp.view = viewmatrix; fp.proj = projmatrix; fp.campos = cam_pos;
 
-    HIP_TRY(hipMemsetAsync(counters, 0, 16, s), "memset counters");
+    const size_t counter_bytes = (COUNTER_SHARDS + 1) * COUNTER_SHARD_STRIDE * 4;
+    HIP_TRY(hipMemsetAsync(counters, 0, counter_bytes, s), "memset counters");
     uint32_t dnb = 0, dper = 0;
     sort_geometry((uint32_t)P, &dnb, &dper);
     HIP_TRY(hipMemsetAsync(ghist, 0, (size_t)256 * SORT_MAX_BLOCKS * 4, s), "memset depth-sort histogram 0");
@@ -147,7 +150,7 @@ extern "C" int igs_rast_forward(
     DBG_SYNC("preprocess_fwd");
     prof_mark(s, ST_PREPROCESS);
     // instance count: read back while the depth sort runs
-    HIP_TRY(hipMemcpyAsync(g_slot.pinned, counters, 8, hipMemcpyDeviceToHost, s), "memcpy count");
+    HIP_TRY(hipMemcpyAsync(g_slot.pinned, counters, counter_bytes, hipMemcpyDeviceToHost, s), "memcpy count");
     HIP_TRY(hipEventRecord(g_slot.ev, s), "event record");
     prof_mark(s, ST_GAP);
 
@@ -162,7 +165,10 @@ extern "C" int igs_rast_forward(
     prof_mark(s, ST_SCAN);
 
     HIP_TRY(hipEventSynchronize(g_slot.ev), "event sync");
-    const uint32_t R = g_slot.pinned[0];
+    uint64_t R64 = 0;
+    for (int sh = 0; sh < COUNTER_SHARDS; sh++) R64 += g_slot.pinned[COUNTER_SHARD_STRIDE * (1 + sh)];
+    if (R64 > 0x7FFFFFFFull) return fail(IGS_RAST_E_INVALID, "instance count overflows int");
+    const uint32_t R = (uint32_t)R64;
     if (g_slot.pinned[1]) return fail(IGS_RAST_E_PREFILTER, "Point is filtered although prefiltered is set. This shouldn't happen!");
     if (R > 0x7FFFFFFFu) return fail(IGS_RAST_E_INVALID, "instance count overflows int");
 

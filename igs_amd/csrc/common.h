@@ -35,6 +35,8 @@ enum { GA_COLOR = 0, GA_VP = 3, GA_CP = 6, GA_TS = 12, GA_RP = 13, GA_NRM = 15, 
 
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
+#define COUNTER_SHARDS 64                  // instance-count shards (counters[16*(1+s)]); counters[1] = prefilter flag
+#define COUNTER_SHARD_STRIDE 16            // uint32 per shard = one 64-byte line
 #define SORT_ITEMS 8                       // elements per thread per sort sub-tile
 #define SORT_TILE (256 * SORT_ITEMS)       // 2048 elements per block sub-tile
 #define SORT_MAX_PASSES 5                  // histogram tables kept per sort (32-bit keys: 4 passes)
@@ -52,7 +54,7 @@ struct GeomLayout {          // sizes in bytes, offsets from a 256-byte aligned 
         vals_b = o;   o += align_up(P * 4, 256);
         hist = o;     o += align_up((size_t)SORT_MAX_PASSES * 256 * SORT_MAX_BLOCKS * 4, 256);
         blocksum = o; o += align_up((P / 256 + 2) * 4, 256);   // per-256 block instance counts / offsets (depth order)
-        counters = o; o += 256;                                // [0] total instances, [1] prefilter violation flag
+        counters = o; o += (COUNTER_SHARDS + 1) * COUNTER_SHARD_STRIDE * 4;   // [1] prefilter flag, [16*(1+s)] count shard s
         total = o + 256;
     }
 };
@@ -87,6 +89,7 @@ struct FwdParams {
     const float *means3D, *shs, *colors_precomp, *opacities, *scales, *rotations, *cov3D_precomp;
     float scale_modifier, tan_fovx, tan_fovy, fx, fy, kernel_size;
     int prefiltered;
+    int dbg_skip;                           // experiment switch (IGS_DBG_SKIP), 0 in production
     const float *view, *proj, *campos;      // device pointers (transposed 4x4 matrices, camera centre)
 };
 

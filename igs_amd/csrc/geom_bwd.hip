@@ -79,15 +79,18 @@ geom_bwd_kernel(const GBArgs args)
 {
     const GeomBwdArgs& a = args.a;
     const int idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx >= a.P) return;
+    // dL_dsh rows are staged in LDS ((3M+1)-float padded rows) and written out with coalesced stores at the end
+    extern __shared__ __attribute__((aligned(16))) float dsh_lds[];
+    const int F = 3 * a.M, FS = F + 1;
+    const bool active = idx < a.P;
 
     float3 o_m2d = make_float3(0, 0, 0), o_color = make_float3(0, 0, 0), o_mean = make_float3(0, 0, 0), o_scale = make_float3(0, 0, 0);
     float o_opacity = 0.f, o_cov[6] = { 0, 0, 0, 0, 0, 0 };
     float4 o_rot = make_float4(0, 0, 0, 0);
-    float* dsh = a.M ? a.dL_dsh + (size_t)idx * a.M * 3 : nullptr;
+    float* dsh = a.M ? dsh_lds + threadIdx.x * FS : nullptr;
     bool sh_written = false;
 
-    if (a.radii[idx] > 0) {
+    if (active && a.radii[idx] > 0) {
         const float4* R4 = (const float4*)(a.rec + (size_t)idx * REC_F);
         const float4* G4 = (const float4*)(a.gacc + (size_t)idx * GACC_F);
         const float4 r0 = R4[0], r1 = R4[1], r2 = R4[2], r4 = R4[4], r5 = R4[5], r6 = R4[6], r7 = R4[7];
@@ -122,8 +125,13 @@ geom_bwd_kernel(const GBArgs args)
         const uint32_t clamped = __float_as_uint(r7.z);
 
         // ================= computeCov2DCUDA (backward.cu:145-488) =================
+        // With no plane / depth / normal gradient arriving (e.g. a colour-only loss) every term of the plane-fit backward is an
+        // exact zero: skip the eigen-decomposition and that whole block.
+        const bool need_planes = (Sv0 != 0.f) | (Sv1 != 0.f) | (Sv2 != 0.f) | (Sx0 != 0.f) | (Sx1 != 0.f) | (Sx2 != 0.f)
+                                 | (Sy0 != 0.f) | (Sy1 != 0.f) | (Sy2 != 0.f) | (St != 0.f) | (Stx != 0.f) | (Sty != 0.f)
+                                 | (dL_dnormal.x != 0.f) | (dL_dnormal.y != 0.f) | (dL_dnormal.z != 0.f);
         Cov2DCtx c;
-        cov2d_ctx(c, mean, cov3D, a.view, a.fx, a.fy, a.tan_fovx, a.tan_fovy, a.kernel_size);
+        cov2d_ctx(c, mean, cov3D, a.view, a.fx, a.fy, a.tan_fovx, a.tan_fovy, a.kernel_size, need_planes);
         const float3 t = c.t;
         const float u = c.txtz, v = c.tytz, u2 = u * u, v2 = v * v, uv = u * v;
         const float combined_opacity = dLc_z;          // sic: dL_dconic.w, see header
@@ -351,20 +359,51 @@ geom_bwd_kernel(const GBArgs args)
 #undef X_
         }
     }
-    a.dL_dmean2D[3 * idx] = o_m2d.x; a.dL_dmean2D[3 * idx + 1] = o_m2d.y; a.dL_dmean2D[3 * idx + 2] = o_m2d.z;
-    a.dL_dcolor[3 * idx] = o_color.x; a.dL_dcolor[3 * idx + 1] = o_color.y; a.dL_dcolor[3 * idx + 2] = o_color.z;
-    a.dL_dopacity[idx] = o_opacity;
-    a.dL_dmean3D[3 * idx] = o_mean.x; a.dL_dmean3D[3 * idx + 1] = o_mean.y; a.dL_dmean3D[3 * idx + 2] = o_mean.z;
+    if (active) {
+        a.dL_dmean2D[3 * idx] = o_m2d.x; a.dL_dmean2D[3 * idx + 1] = o_m2d.y; a.dL_dmean2D[3 * idx + 2] = o_m2d.z;
+        a.dL_dcolor[3 * idx] = o_color.x; a.dL_dcolor[3 * idx + 1] = o_color.y; a.dL_dcolor[3 * idx + 2] = o_color.z;
+        a.dL_dopacity[idx] = o_opacity;
+        a.dL_dmean3D[3 * idx] = o_mean.x; a.dL_dmean3D[3 * idx + 1] = o_mean.y; a.dL_dmean3D[3 * idx + 2] = o_mean.z;
 #pragma unroll
-    for (int k = 0; k < 6; k++) a.dL_dcov3D[6 * (size_t)idx + k] = o_cov[k];
-    a.dL_dscale[3 * idx] = o_scale.x; a.dL_dscale[3 * idx + 1] = o_scale.y; a.dL_dscale[3 * idx + 2] = o_scale.z;
-    a.dL_drot[4 * idx] = o_rot.x; a.dL_drot[4 * idx + 1] = o_rot.y; a.dL_drot[4 * idx + 2] = o_rot.z; a.dL_drot[4 * idx + 3] = o_rot.w;
-    if (dsh && !sh_written) for (int k = 0; k < a.M * 3; k++) dsh[k] = 0.f;
+        for (int k = 0; k < 6; k++) a.dL_dcov3D[6 * (size_t)idx + k] = o_cov[k];
+        a.dL_dscale[3 * idx] = o_scale.x; a.dL_dscale[3 * idx + 1] = o_scale.y; a.dL_dscale[3 * idx + 2] = o_scale.z;
+        a.dL_drot[4 * idx] = o_rot.x; a.dL_drot[4 * idx + 1] = o_rot.y; a.dL_drot[4 * idx + 2] = o_rot.z; a.dL_drot[4 * idx + 3] = o_rot.w;
+        if (dsh && !sh_written) for (int k = 0; k < F; k++) dsh[k] = 0.f;
+    }
+    if (a.M) {
+        __syncthreads();
+        const int g0 = blockIdx.x * 256;
+        const int ng = min(256, a.P - g0);
+        float* dst = a.dL_dsh + (size_t)g0 * F;
+        const int total = ng * F;
+        if (((F & 3) == 0) && ((((uintptr_t)dst) & 15) == 0)) {
+            const int total4 = total >> 2;
+            int f = (int)threadIdx.x * 4;
+            int g = f / F, k = f - g * F;
+            const int dg = 1024 / F, dk = 1024 - dg * F;
+            for (int i = threadIdx.x; i < total4; i += 256) {
+                const float* sp = dsh_lds + g * FS + k;
+                ((float4*)dst)[i] = make_float4(sp[0], sp[1], sp[2], sp[3]);
+                g += dg; k += dk;
+                if (k >= F) { k -= F; g++; }
+            }
+        } else {
+            int f = (int)threadIdx.x;
+            int g = f / F, k = f - g * F;
+            const int dg = 256 / F, dk = 256 - dg * F;
+            for (int i = threadIdx.x; i < total; i += 256) {
+                dst[i] = dsh_lds[g * FS + k];
+                g += dg; k += dk;
+                if (k >= F) { k -= F; g++; }
+            }
+        }
+    }
 }
 
 hipError_t launch_geom_bwd(hipStream_t s, const GeomBwdArgs& a)
 {
     GBArgs g; g.a = a;
-    hipLaunchKernelGGL(geom_bwd_kernel, dim3((a.P + 255) / 256), dim3(256), 0, s, g);
+    const size_t lds = a.M ? (size_t)256 * (3 * a.M + 1) * sizeof(float) : 0;
+    hipLaunchKernelGGL(geom_bwd_kernel, dim3((a.P + 255) / 256), dim3(256), lds, s, g);
     return hipGetLastError();
 }

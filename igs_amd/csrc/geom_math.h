@@ -214,7 +214,7 @@ struct Cov2DCtx {
 };
 
 __device__ __forceinline__ void cov2d_ctx(Cov2DCtx& c, float3 mean, const float* cov3D, const float* view, float fx,
-                                          float fy, float tan_fovx, float tan_fovy, float kernel_size) {
+                                          float fy, float tan_fovx, float tan_fovy, float kernel_size, bool with_planes = true) {
     float3 t = xform4x3(mean, view);
     const float limx = 1.3f * tan_fovx, limy = 1.3f * tan_fovy;
     float txtz = t.x / t.z, tytz = t.y / t.z;
@@ -253,6 +253,14 @@ __device__ __forceinline__ void cov2d_ctx(Cov2DCtx& c, float3 mean, const float*
     c.coef = (float)sqrt((double)c.det0 / ((double)c.det1 + 1e-6) + 1e-6);
     c.coef_zero = ((double)c.det0 <= 1e-6) || ((double)c.det1 <= 1e-6);
 
+    if (!with_planes) {
+        // the caller has no use for the plane fit (backward with no plane / normal / depth gradient): skip the eigen-solver
+        c.eig_ok = false; c.min_id = 0; c.evmin = 1.f; c.emin = make_float3(0, 0, 0); c.well = false;
+        c.ev0 = c.ev1 = c.ev2 = 1.f; c.vc0 = c.vc1 = c.vc2 = make_float3(0, 0, 0);
+        c.uvh = make_float3(c.txtz, c.tytz, 1.f); c.uvh_m = c.uvh_mn = make_float3(0, 0, 0);
+        c.degenerate = true;
+        return;
+    }
     // locals (separate allocas), not struct fields: a select between adjacent fields gets turned into a
     // dynamically indexed scratch access by the optimiser
     float l0, l1, l2; float3 w0, w1, w2;

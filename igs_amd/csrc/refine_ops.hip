@@ -74,7 +74,8 @@ l1_kernel(size_t n4, size_t n, const float* __restrict__ pred, const float* __re
     for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
     if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = acc;
     __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(loss_sum, ws[0] + ws[1] + ws[2] + ws[3]);
+    // 64 shards one cache line apart (same-address atomics serialise); the caller sums loss_sum[16*s], s < 64
+    if (threadIdx.x == 0) atomicAdd(&loss_sum[16 * (blockIdx.x & 63)], ws[0] + ws[1] + ws[2] + ws[3]);
 }
 
 extern "C" int igs_l1_loss_fwd_bwd(void* stream, size_t n, const float* pred, const float* gt, float* grad, float* loss_sum, float scale)

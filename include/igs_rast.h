@@ -163,8 +163,9 @@ int igs_rast_profile_read(double* ms_sum, long long* count, double* r_sum, long 
 int igs_adam_step(void* stream, size_t n, float* param, const float* grad, float* exp_avg, float* exp_avg_sq,
                   float lr, float beta1, float beta2, float eps, float bias_correction1, float bias_correction2_sqrt);
 
-/* Fused L1 loss forward + backward (igs/utils/loss_utils.py:17-18): *loss_sum += sum |pred - gt| (caller zeroes it),
- * grad[i] = sign(pred[i] - gt[i]) * scale. */
+/* Fused L1 loss forward + backward (igs/utils/loss_utils.py:17-18): grad[i] = sign(pred[i] - gt[i]) * scale, and
+ * sum |pred - gt| is accumulated into 64 shards loss_sum[16*s], s = 0..63 (1024 floats, zeroed by the caller, summed by
+ * the caller: same-address atomics would serialise). */
 int igs_l1_loss_fwd_bwd(void* stream, size_t n, const float* pred, const float* gt, float* grad, float* loss_sum, float scale);
 
 /* Fused activations applied outside the rasterizer (igs/models/gaussian_model.py:90-127): opacity = sigmoid(logit),

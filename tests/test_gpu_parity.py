@@ -398,7 +398,7 @@ def test_refine_loop_improves_psnr_and_fused_ops(dev):
     gi = torch.empty_like(pred)
     s = L1Fused(dev)(pred, gts[0], gi)
     torch.testing.assert_close(gi, pt.grad, rtol=0, atol=1e-9)
-    torch.testing.assert_close(s / pred.numel(), torch.abs(pred - gts[0]).mean().reshape(1), rtol=1e-4, atol=1e-7)
+    torch.testing.assert_close(s.sum().reshape(1) / pred.numel(), torch.abs(pred - gts[0]).mean().reshape(1), rtol=1e-4, atol=1e-7)
     # fused Adam against torch.optim.Adam on the same gradients
     params = GaussianParams(raw, dev)
     ref_leaves = {k: v.detach().clone().requires_grad_(True) for k, v in params.leaves.items()}
