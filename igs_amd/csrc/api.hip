@@ -85,7 +85,11 @@ extern "C" int igs_rast_version(void) { return IGS_RAST_VERSION; }
 extern "C" const char* igs_rast_last_error(void) { return g_err; }
 extern "C" size_t igs_rast_backward_workspace_bytes(int P) { return (size_t)(P > 0 ? P : 0) * GACC_F * 4 + 512; }
 
-extern "C" int igs_rast_forward(
+// what the previous forward on this host thread saw: sizes the binning buffer before R is known
+struct BinHint { uint32_t last_R = 0, last_max = 0; };
+static thread_local BinHint g_hint;
+
+static int forward_impl(
     void* stream,
     igs_rast_alloc_fn geometry_buffer, void* geometry_user, igs_rast_alloc_fn binning_buffer, void* binning_user,
     igs_rast_alloc_fn image_buffer, void* image_user,
@@ -95,7 +99,8 @@ extern "C" int igs_rast_forward(
     const float* viewmatrix, const float* projmatrix, const float* cam_pos,
     float tan_fovx, float tan_fovy, float kernel_size, int prefiltered,
     float* out_color, float* out_coord, float* out_mcoord, float* out_depth, float* out_mdepth, float* out_alpha,
-    float* out_normal, int* radii, int require_coord, int require_depth, int debug)
+    float* out_normal, int* radii, int require_coord, int require_depth, int debug,
+    bool force_radix, uint64_t min_capacity, bool want_big)
 {
     hipStream_t s = (hipStream_t)stream;
     if (P < 0 || width <= 0 || height <= 0) return fail(IGS_RAST_E_INVALID, "igs_rast_forward: bad sizes");
@@ -137,76 +142,121 @@ extern "C" int igs_rast_forward(
     fp.scale_modifier = scale_modifier; fp.tan_fovx = tan_fovx; fp.tan_fovy = tan_fovy;
     fp.fy = height / (2.0f * tan_fovy); fp.fx = width / (2.0f * tan_fovx);       // rasterizer_impl.cu:288-289
     fp.kernel_size = kernel_size; fp.prefiltered = prefiltered;
-    { const char* e = getenv("IGS_DBG_SKIP"); fp.dbg_skip = e ? atoi(e) : 0; }
     fp.view = viewmatrix; fp.proj = projmatrix; fp.campos = cam_pos;
 
     const size_t counter_bytes = (COUNTER_SHARDS + 1) * COUNTER_SHARD_STRIDE * 4;
-    HIP_TRY(hipMemsetAsync(counters, 0, counter_bytes, s), "memset counters");
-    uint32_t dnb = 0, dper = 0;
-    sort_geometry((uint32_t)P, &dnb, &dper);
-    HIP_TRY(hipMemsetAsync(ghist, 0, (size_t)256 * SORT_MAX_BLOCKS * 4, s), "memset depth-sort histogram 0");
-    prof_mark(s, ST_GAP);
-    HIP_TRY(launch_preprocess_fwd(s, fp, rec, tiles, keys_a, vals_a, radii, counters, ghist, dper), "preprocess_fwd launch");
-    DBG_SYNC("preprocess_fwd");
-    prof_mark(s, ST_PREPROCESS);
-    // instance count: read back while the depth sort runs
-    HIP_TRY(hipMemcpyAsync(g_slot.pinned, counters, counter_bytes, hipMemcpyDeviceToHost, s), "memcpy count");
-    HIP_TRY(hipEventRecord(g_slot.ev, s), "event record");
-    prof_mark(s, ST_GAP);
-
-    uint32_t *dk = nullptr, *order = nullptr;
-    HIP_TRY(radix_sort_pairs(s, (uint32_t)P, keys_a, keys_b, vals_a, vals_b, ghist, 0, 32, &dk, &order), "depth sort launch");
-    DBG_SYNC("depth sort");
-    prof_mark(s, ST_DEPTH_SORT);
-    const int nblk = (P + 255) / 256;
-    HIP_TRY(launch_count_sorted(s, P, order, tiles, blocksum), "count_sorted launch");
-    HIP_TRY(launch_scan_blocksums(s, nblk, blocksum), "scan_blocksums launch");
-    DBG_SYNC("scan");
-    prof_mark(s, ST_SCAN);
-
-    HIP_TRY(hipEventSynchronize(g_slot.ev), "event sync");
-    uint64_t R64 = 0;
-    for (int sh = 0; sh < COUNTER_SHARDS; sh++) R64 += g_slot.pinned[COUNTER_SHARD_STRIDE * (1 + sh)];
-    if (R64 > 0x7FFFFFFFull) return fail(IGS_RAST_E_INVALID, "instance count overflows int");
-    const uint32_t R = (uint32_t)R64;
-    if (g_slot.pinned[1]) return fail(IGS_RAST_E_PREFILTER, "Point is filtered although prefiltered is set. This shouldn't happen!");
-    if (R > 0x7FFFFFFFu) return fail(IGS_RAST_E_INVALID, "instance count overflows int");
-
-    const BinLayout BL(R);
-    char* bbase = binning_buffer(binning_user, BL.total);
-    if (!bbase) return fail(IGS_RAST_E_ALLOC, "binning buffer callback returned NULL");
-    bbase = align_ptr(bbase);
-    uint32_t* point_list = (uint32_t*)(bbase + BL.point_list);
-    uint32_t* bkeys_a = (uint32_t*)(bbase + BL.keys_a); uint32_t* bkeys_b = (uint32_t*)(bbase + BL.keys_b);
-    uint32_t* bvals_b = (uint32_t*)(bbase + BL.vals_b);
-    uint32_t* bhist = (uint32_t*)(bbase + BL.hist);
-
     uint32_t* ranges = (uint32_t*)(ibase + IL.ranges);
-    HIP_TRY(hipMemsetAsync(ranges, 0, Tn * 8, s), "memset ranges");               // rasterizer_impl.cu:383
-    prof_mark(s, ST_GAP);
-    if (R > 0) {
-        const int bits = ceil_log2((uint32_t)Tn);
-        const int passes = (bits + 7) / 8;
-        // arrange the ping-pong so that the sorted ids land in point_list
-        uint32_t *ka, *kb, *va, *vb;
-        if (passes % 2 == 0) { ka = bkeys_a; va = point_list; kb = bkeys_b; vb = bvals_b; }
-        else                 { ka = bkeys_b; va = bvals_b;   kb = bkeys_a; vb = point_list; }
-        uint32_t tnb = 0, tper = 0;
-        sort_geometry(R, &tnb, &tper);
-        HIP_TRY(hipMemsetAsync(bhist, 0, (size_t)256 * SORT_MAX_BLOCKS * 4, s), "memset tile-sort histogram 0");
-        const uint32_t mask0 = bits >= 8 ? 255u : ((1u << bits) - 1u);
-        HIP_TRY(launch_emit_instances(s, P, gx, gy, order, tiles, blocksum, rec, radii, ka, va, passes ? bhist : nullptr, tper, mask0),
-                "emit launch");
-        DBG_SYNC("emit");
+    uint32_t* point_list = nullptr;
+    uint32_t R = 0;
+    bool bucket_pending = false;            // bucket path: the host has not looked at R yet
+    uint32_t bucket_cap = 0; bool bucket_big = false;
+
+    if (!force_radix) {
+        // ---------------- bucket binning (default): nothing below needs the host to know R ----------------
+        uint32_t* tile_count = (uint32_t*)(ibase + IL.tile_count);
+        uint32_t* cursor = (uint32_t*)(ibase + IL.cursor);
+        uint32_t* stats = (uint32_t*)(ibase + IL.stats);
+        HIP_TRY(hipMemsetAsync(counters, 0, counter_bytes, s), "memset counters");
+        HIP_TRY(hipMemsetAsync(tile_count, 0, IL.stats - IL.tile_count, s), "memset tile counters");   // tile_count + cursor
+        prof_mark(s, ST_GAP);
+        HIP_TRY(launch_preprocess_fwd(s, fp, rec, tiles, nullptr, nullptr, radii, counters, nullptr, 0, tile_count), "preprocess_fwd launch");
+        DBG_SYNC("preprocess_fwd");
+        prof_mark(s, ST_PREPROCESS);
+        HIP_TRY(launch_tile_scan(s, (uint32_t)Tn, tile_count, ranges, stats), "tile_scan launch");
+        DBG_SYNC("tile_scan");
+        prof_mark(s, ST_SCAN);
+        HIP_TRY(hipMemcpyAsync(g_slot.pinned, stats, 8, hipMemcpyDeviceToHost, s), "memcpy stats");
+        HIP_TRY(hipMemcpyAsync(g_slot.pinned + 2, counters + 1, 4, hipMemcpyDeviceToHost, s), "memcpy prefilter flag");
+        HIP_TRY(hipEventRecord(g_slot.ev, s), "event record");
+        // capacity guess from the previous call on this thread (the refine loop renders similar views over and over)
+        uint64_t cap = (uint64_t)g_hint.last_R + g_hint.last_R / 4 + 4096;
+        if (cap < (uint64_t)P * 4) cap = (uint64_t)P * 4;
+        if (min_capacity > cap) cap = min_capacity;
+        if (cap > 0x7FFFFFFFull) cap = 0x7FFFFFFFull;
+        bucket_cap = (uint32_t)cap;
+        bucket_big = g_hint.last_max > TILE_SORT_SMALL || want_big;
+        const BucketLayout KL(bucket_cap);
+        char* bbase = binning_buffer(binning_user, KL.total);
+        if (!bbase) return fail(IGS_RAST_E_ALLOC, "binning buffer callback returned NULL");
+        bbase = align_ptr(bbase);
+        point_list = (uint32_t*)(bbase + KL.point_list);
+        uint32_t* bkey = (uint32_t*)(bbase + KL.bkey);
+        uint32_t* bid = (uint32_t*)(bbase + KL.bid);
+        prof_mark(s, ST_GAP);
+        HIP_TRY(launch_bucket_scatter(s, P, gx, gy, tiles, rec, radii, ranges, cursor, bkey, bid, bucket_cap), "bucket_scatter launch");
+        DBG_SYNC("bucket_scatter");
         prof_mark(s, ST_EMIT);
-        uint32_t *sk = nullptr, *sv = nullptr;
-        HIP_TRY(radix_sort_pairs(s, R, ka, kb, va, vb, bhist, 0, bits, &sk, &sv), "tile sort launch");
-        DBG_SYNC("tile sort");
+        HIP_TRY(launch_tile_sort(s, (uint32_t)Tn, ranges, bkey, bid, point_list, bucket_cap, bucket_big), "tile_sort launch");
+        DBG_SYNC("tile_sort");
         prof_mark(s, ST_TILE_SORT);
-        if (sv != point_list) return fail(IGS_RAST_E_INVALID, "internal: sort ping-pong mismatch");
-        HIP_TRY(launch_tile_ranges(s, R, sk, ranges), "tile_ranges launch");
-        DBG_SYNC("tile_ranges");
-        prof_mark(s, ST_RANGES);
+        bucket_pending = true;
+    } else {
+        // ---------------- global radix binning (fallback for tiles denser than TILE_SORT_BIG) ----------------
+        HIP_TRY(hipMemsetAsync(counters, 0, counter_bytes, s), "memset counters");
+        uint32_t dnb = 0, dper = 0;
+        sort_geometry((uint32_t)P, &dnb, &dper);
+        HIP_TRY(hipMemsetAsync(ghist, 0, (size_t)256 * SORT_MAX_BLOCKS * 4, s), "memset depth-sort histogram 0");
+        prof_mark(s, ST_GAP);
+        HIP_TRY(launch_preprocess_fwd(s, fp, rec, tiles, keys_a, vals_a, radii, counters, ghist, dper, nullptr), "preprocess_fwd launch");
+        DBG_SYNC("preprocess_fwd");
+        prof_mark(s, ST_PREPROCESS);
+        // instance count: read back while the depth sort runs
+        HIP_TRY(hipMemcpyAsync(g_slot.pinned, counters, counter_bytes, hipMemcpyDeviceToHost, s), "memcpy count");
+        HIP_TRY(hipEventRecord(g_slot.ev, s), "event record");
+        prof_mark(s, ST_GAP);
+
+        uint32_t *dk = nullptr, *order = nullptr;
+        HIP_TRY(radix_sort_pairs(s, (uint32_t)P, keys_a, keys_b, vals_a, vals_b, ghist, 0, 32, &dk, &order), "depth sort launch");
+        DBG_SYNC("depth sort");
+        prof_mark(s, ST_DEPTH_SORT);
+        const int nblk = (P + 255) / 256;
+        HIP_TRY(launch_count_sorted(s, P, order, tiles, blocksum), "count_sorted launch");
+        HIP_TRY(launch_scan_blocksums(s, nblk, blocksum), "scan_blocksums launch");
+        DBG_SYNC("scan");
+        prof_mark(s, ST_SCAN);
+
+        HIP_TRY(hipEventSynchronize(g_slot.ev), "event sync");
+        uint64_t R64 = 0;
+        for (int sh = 0; sh < COUNTER_SHARDS; sh++) R64 += g_slot.pinned[COUNTER_SHARD_STRIDE * (1 + sh)];
+        if (R64 > 0x7FFFFFFFull) return fail(IGS_RAST_E_INVALID, "instance count overflows int");
+        R = (uint32_t)R64;
+        if (g_slot.pinned[1]) return fail(IGS_RAST_E_PREFILTER, "Point is filtered although prefiltered is set. This shouldn't happen!");
+
+        const BinLayout BL(R);
+        char* bbase = binning_buffer(binning_user, BL.total);
+        if (!bbase) return fail(IGS_RAST_E_ALLOC, "binning buffer callback returned NULL");
+        bbase = align_ptr(bbase);
+        point_list = (uint32_t*)(bbase + BL.point_list);
+        uint32_t* bkeys_a = (uint32_t*)(bbase + BL.keys_a); uint32_t* bkeys_b = (uint32_t*)(bbase + BL.keys_b);
+        uint32_t* bvals_b = (uint32_t*)(bbase + BL.vals_b);
+        uint32_t* bhist = (uint32_t*)(bbase + BL.hist);
+
+        HIP_TRY(hipMemsetAsync(ranges, 0, Tn * 8, s), "memset ranges");               // rasterizer_impl.cu:383
+        prof_mark(s, ST_GAP);
+        if (R > 0) {
+            const int bits = ceil_log2((uint32_t)Tn);
+            const int passes = (bits + 7) / 8;
+            // arrange the ping-pong so that the sorted ids land in point_list
+            uint32_t *ka, *kb, *va, *vb;
+            if (passes % 2 == 0) { ka = bkeys_a; va = point_list; kb = bkeys_b; vb = bvals_b; }
+            else                 { ka = bkeys_b; va = bvals_b;   kb = bkeys_a; vb = point_list; }
+            uint32_t tnb = 0, tper = 0;
+            sort_geometry(R, &tnb, &tper);
+            HIP_TRY(hipMemsetAsync(bhist, 0, (size_t)256 * SORT_MAX_BLOCKS * 4, s), "memset tile-sort histogram 0");
+            const uint32_t mask0 = bits >= 8 ? 255u : ((1u << bits) - 1u);
+            HIP_TRY(launch_emit_instances(s, P, gx, gy, order, tiles, blocksum, rec, radii, ka, va, passes ? bhist : nullptr, tper, mask0),
+                    "emit launch");
+            DBG_SYNC("emit");
+            prof_mark(s, ST_EMIT);
+            uint32_t *sk = nullptr, *sv = nullptr;
+            HIP_TRY(radix_sort_pairs(s, R, ka, kb, va, vb, bhist, 0, bits, &sk, &sv), "tile sort launch");
+            DBG_SYNC("tile sort");
+            prof_mark(s, ST_TILE_SORT);
+            if (sv != point_list) return fail(IGS_RAST_E_INVALID, "internal: sort ping-pong mismatch");
+            HIP_TRY(launch_tile_ranges(s, R, sk, ranges), "tile_ranges launch");
+            DBG_SYNC("tile_ranges");
+            prof_mark(s, ST_RANGES);
+        }
     }
 
     BlendFwdArgs ba;
@@ -217,11 +267,53 @@ extern "C" int igs_rast_forward(
     ba.n_contrib = (uint32_t*)(ibase + IL.n_contrib);
     ba.accum_coord = (float*)(ibase + IL.accum_coord); ba.accum_depth = (float*)(ibase + IL.accum_depth);
     ba.normal_length = (float*)(ibase + IL.normal_length);
+    ba.list_capacity = bucket_pending ? bucket_cap : 0xFFFFFFFFu;
+    ba.max_tile = bucket_pending ? (bucket_big ? (uint32_t)TILE_SORT_BIG : (uint32_t)TILE_SORT_SMALL) : 0xFFFFFFFFu;
     HIP_TRY(launch_blend_fwd(s, ba, require_coord != 0, require_depth != 0), "blend_fwd launch");
     DBG_SYNC("blend_fwd");
     prof_mark(s, ST_BLEND_FWD);
+    if (bucket_pending) {
+        // only now does the host look at R: the whole pipeline above was enqueued without waiting for it
+        HIP_TRY(hipEventSynchronize(g_slot.ev), "event sync");
+        const uint32_t R_dev = g_slot.pinned[0], max_tile = g_slot.pinned[1];
+        if (g_slot.pinned[2]) return fail(IGS_RAST_E_PREFILTER, "Point is filtered although prefiltered is set. This shouldn't happen!");
+        if (R_dev > 0x7FFFFFFFu) return fail(IGS_RAST_E_INVALID, "instance count overflows int");
+        g_hint.last_R = R_dev; g_hint.last_max = max_tile;
+        const uint32_t sortable = bucket_big ? (uint32_t)TILE_SORT_BIG : (uint32_t)TILE_SORT_SMALL;
+        if (R_dev > bucket_cap || max_tile > sortable) {
+            // the guess was too small (or a tile is denser than the launched sort tier): redo with what is now known
+            const bool radix = max_tile > (uint32_t)TILE_SORT_BIG;
+            return forward_impl(stream, geometry_buffer, geometry_user, binning_buffer, binning_user, image_buffer, image_user, P, D, M,
+                                background, width, height, means3D, shs, colors_precomp, opacities, scales, scale_modifier, rotations,
+                                cov3D_precomp, viewmatrix, projmatrix, cam_pos, tan_fovx, tan_fovy, kernel_size, prefiltered, out_color,
+                                out_coord, out_mcoord, out_depth, out_mdepth, out_alpha, out_normal, radii, require_coord, require_depth,
+                                debug, radix, (uint64_t)R_dev + 1024, max_tile > (uint32_t)TILE_SORT_SMALL);
+        }
+        R = R_dev;
+    }
     if (g_prof.on) { g_prof.r_sum += (double)R; g_prof.calls++; }
     return (int)R;
+}
+
+extern "C" int igs_rast_forward(
+    void* stream,
+    igs_rast_alloc_fn geometry_buffer, void* geometry_user, igs_rast_alloc_fn binning_buffer, void* binning_user,
+    igs_rast_alloc_fn image_buffer, void* image_user,
+    int P, int D, int M, const float* background, int width, int height,
+    const float* means3D, const float* shs, const float* colors_precomp, const float* opacities,
+    const float* scales, float scale_modifier, const float* rotations, const float* cov3D_precomp,
+    const float* viewmatrix, const float* projmatrix, const float* cam_pos,
+    float tan_fovx, float tan_fovy, float kernel_size, int prefiltered,
+    float* out_color, float* out_coord, float* out_mcoord, float* out_depth, float* out_mdepth, float* out_alpha,
+    float* out_normal, int* radii, int require_coord, int require_depth, int debug)
+{
+    const char* e = getenv("IGS_BINNING");                    // "radix" forces the global-sort path (tests)
+    const bool radix = e && strcmp(e, "radix") == 0;
+    return forward_impl(stream, geometry_buffer, geometry_user, binning_buffer, binning_user, image_buffer, image_user, P, D, M,
+                        background, width, height, means3D, shs, colors_precomp, opacities, scales, scale_modifier, rotations,
+                        cov3D_precomp, viewmatrix, projmatrix, cam_pos, tan_fovx, tan_fovy, kernel_size, prefiltered, out_color,
+                        out_coord, out_mcoord, out_depth, out_mdepth, out_alpha, out_normal, radii, require_coord, require_depth,
+                        debug, radix, 0, false);
 }
 
 extern "C" int igs_rast_backward(

@@ -32,7 +32,8 @@ blend_fwd_kernel(const BlendFwdArgs a)
     const float tile_x0 = (float)(tx * TILE), tile_y0 = (float)(ty * TILE);
 
     const uint2 range = ((const uint2*)a.ranges)[tile];
-    const int n = (int)(range.y - range.x);
+    int n = (int)(range.y - range.x);
+    if (range.y > a.list_capacity || (uint32_t)n > a.max_tile) n = 0;      // list not valid (see BlendFwdArgs): frame will be redone
     const int rounds = (n + CHUNK - 1) / CHUNK;
 
     bool done = !inside;

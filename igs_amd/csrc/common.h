@@ -70,8 +70,20 @@ struct BinLayout {
         total = o + 256;
     }
 };
+#define TILE_SORT_SMALL 2048                // tiles up to this many instances are sorted with 16 KB of LDS
+#define TILE_SORT_BIG 16384                 // ... up to this many with 128 KB; denser tiles fall back to the global radix path
+struct BucketLayout {
+    size_t point_list, bkey, bid, total;
+    __host__ explicit BucketLayout(size_t cap) {
+        size_t o = 0;
+        point_list = o; o += align_up(cap * 4, 256);   // same offset as BinLayout::point_list (backward only reads this)
+        bkey = o;       o += align_up(cap * 4, 256);
+        bid = o;        o += align_up(cap * 4, 256);
+        total = o + 256;
+    }
+};
 struct ImgLayout {
-    size_t ranges, n_contrib, accum_coord, accum_depth, normal_length, total;
+    size_t ranges, n_contrib, accum_coord, accum_depth, normal_length, tile_count, cursor, stats, total;
     __host__ ImgLayout(size_t HW, size_t T) {
         size_t o = 0;
         ranges = o;        o += align_up(T * 8, 256);
@@ -79,6 +91,9 @@ struct ImgLayout {
         accum_coord = o;   o += align_up(HW * 12, 256);
         accum_depth = o;   o += align_up(HW * 4, 256);
         normal_length = o; o += align_up(HW * 4, 256);
+        tile_count = o;    o += align_up(T * 4, 256);      // bucket binning: instances per tile
+        cursor = o;        o += align_up(T * 4, 256);      // ... fill cursor per tile (adjacent to tile_count: one memset)
+        stats = o;         o += 256;                       // ... [0] R, [1] largest tile
         total = o + 256;
     }
 };
@@ -89,14 +104,19 @@ struct FwdParams {
     const float *means3D, *shs, *colors_precomp, *opacities, *scales, *rotations, *cov3D_precomp;
     float scale_modifier, tan_fovx, tan_fovy, fx, fy, kernel_size;
     int prefiltered;
-    int dbg_skip;                           // experiment switch (IGS_DBG_SKIP), 0 in production
     const float *view, *proj, *campos;      // device pointers (transposed 4x4 matrices, camera centre)
 };
 
 // ---- launchers (each returns hipError_t of the launch) ----
 hipError_t launch_preprocess_fwd(hipStream_t s, const FwdParams& p, float* rec, uint32_t* tiles, uint32_t* depth_keys,
-                                 uint32_t* ident, int* radii, uint32_t* counters, uint32_t* hist0, uint32_t per_block);
+                                 uint32_t* ident, int* radii, uint32_t* counters, uint32_t* hist0, uint32_t per_block,
+                                 uint32_t* tile_count);
 void sort_geometry(uint32_t n, uint32_t* nb, uint32_t* per);
+hipError_t launch_tile_scan(hipStream_t s, uint32_t T, const uint32_t* tile_count, uint32_t* ranges, uint32_t* stats);
+hipError_t launch_bucket_scatter(hipStream_t s, int P, int gx, int gy, const uint32_t* tiles, const float* rec, const int* radii,
+                                 const uint32_t* ranges, uint32_t* cursor, uint32_t* bkey, uint32_t* bid, uint32_t capacity);
+hipError_t launch_tile_sort(hipStream_t s, uint32_t T, const uint32_t* ranges, const uint32_t* bkey, const uint32_t* bid,
+                            uint32_t* point_list, uint32_t capacity, bool big_tiles);
 hipError_t launch_mark_visible(hipStream_t s, int P, const float* means3D, const float* view, uint8_t* present);
 
 // stable LSD radix sort of (key,value) pairs on key bits [bit_lo, bit_hi); result ends in *out_keys/*out_vals
@@ -117,6 +137,8 @@ struct BlendFwdArgs {
     const uint32_t* ranges; const uint32_t* point_list; const float* rec; const float* colors_precomp;
     float *out_color, *out_coord, *out_mcoord, *out_depth, *out_mdepth, *out_alpha, *out_normal;
     uint32_t* n_contrib; float *accum_coord, *accum_depth, *normal_length;
+    uint32_t list_capacity, max_tile;      // optimistic binning: tiles past the capacity / too dense for the launched sort tier are
+                                           // skipped (their list is not valid); the host then redoes the frame
 };
 hipError_t launch_blend_fwd(hipStream_t s, const BlendFwdArgs& a, bool coord, bool depth);
 

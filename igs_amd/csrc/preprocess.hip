@@ -41,7 +41,7 @@ struct PreArgs { FwdParams p; };
 __global__ void __launch_bounds__(256)
 preprocess_fwd_kernel(const PreArgs a, float* __restrict__ rec, uint32_t* __restrict__ tiles, uint32_t* __restrict__ depth_keys,
                       uint32_t* __restrict__ ident, int* __restrict__ radii, uint32_t* __restrict__ counters,
-                      uint32_t* __restrict__ hist0, uint32_t per_block)
+                      uint32_t* __restrict__ hist0, uint32_t per_block, uint32_t* __restrict__ tile_count)
 {
     const FwdParams& p = a.p;
     const int idx = blockIdx.x * 256 + threadIdx.x;
@@ -70,7 +70,7 @@ preprocess_fwd_kernel(const PreArgs a, float* __restrict__ rec, uint32_t* __rest
                 cov3d_from_scale_rot(s, p.scale_modifier, q, cov3D);
             }
             Cov2DCtx c;
-            cov2d_ctx(c, p_orig, cov3D, p.view, p.fx, p.fy, p.tan_fovx, p.tan_fovy, p.kernel_size, (p.dbg_skip & 1) == 0);
+            cov2d_ctx(c, p_orig, cov3D, p.view, p.fx, p.fy, p.tan_fovx, p.tan_fovy, p.kernel_size);
             float cp[6] = { 0, 0, 0, 0, 0, 0 }, rp[2] = { 0, 0 };
             float3 nrm = make_float3(0, 0, 0);
             if (!c.degenerate) {                           // forward.cu:169-262
@@ -116,9 +116,7 @@ preprocess_fwd_kernel(const PreArgs a, float* __restrict__ rec, uint32_t* __rest
             if ((x1 - x0) * (y1 - y0) == 0) break;
             float3 rgb = make_float3(0, 0, 0);
             uint32_t clamped = 0;
-            if (p.dbg_skip & 2) {
-                rgb = make_float3(0.5f, 0.5f, 0.5f);
-            } else if (p.colors_precomp == nullptr) {
+            if (p.colors_precomp == nullptr) {
                 float3 dir = p_orig - make_float3(p.campos[0], p.campos[1], p.campos[2]);
                 const float len = sqrtf(dot3(dir, dir));
                 dir = make_float3(dir.x / len, dir.y / len, dir.z / len);
@@ -128,8 +126,10 @@ preprocess_fwd_kernel(const PreArgs a, float* __restrict__ rec, uint32_t* __rest
             }
             radius = (int)my_radius;
             my_tiles = (uint32_t)((y1 - y0) * (x1 - x0));
+            if (tile_count)                                   // bucket binning: instances per tile
+                for (int ty = y0; ty < y1; ty++)
+                    for (int tx = x0; tx < x1; tx++) atomicAdd(&tile_count[ty * p.gx + tx], 1u);
             dkey = __float_as_uint(p_view.z);
-            if (!(p.dbg_skip & 4)) {
             R4[0] = make_float4(pix, piy, conic.x, conic.y);
             R4[1] = make_float4(conic.z, p.opacities[idx] * coef, rgb.x, rgb.y);
             R4[2] = make_float4(rgb.z, ts, rp[0], rp[1]);
@@ -138,13 +138,14 @@ preprocess_fwd_kernel(const PreArgs a, float* __restrict__ rec, uint32_t* __rest
             R4[5] = make_float4(cp[4], cp[5], nrm.y, nrm.z);
             R4[6] = make_float4(cov3D[0], cov3D[1], cov3D[2], cov3D[3]);
             R4[7] = make_float4(cov3D[4], cov3D[5], __uint_as_float(clamped), __uint_as_float(dkey));
-            }
         } while (0);
         radii[idx] = radius;
         tiles[idx] = my_tiles;
-        depth_keys[idx] = dkey;
-        ident[idx] = (uint32_t)idx;
-        if (!(p.dbg_skip & 8)) atomicAdd(&hist0[((uint32_t)idx / per_block) * 256u + (dkey & 255u)], 1u);     // first pass of the depth sort
+        if (hist0) {                                          // radix binning: keys + first-pass histogram of the depth sort
+            depth_keys[idx] = dkey;
+            ident[idx] = (uint32_t)idx;
+            atomicAdd(&hist0[((uint32_t)idx / per_block) * 256u + (dkey & 255u)], 1u);
+        }
     }
     // total instance count: wave reduction, one atomic per wave that has something to add (sharded, summed on the host)
     uint32_t v = my_tiles;
@@ -155,12 +156,13 @@ preprocess_fwd_kernel(const PreArgs a, float* __restrict__ rec, uint32_t* __rest
 }
 
 hipError_t launch_preprocess_fwd(hipStream_t s, const FwdParams& p, float* rec, uint32_t* tiles, uint32_t* depth_keys,
-                                 uint32_t* ident, int* radii, uint32_t* counters, uint32_t* hist0, uint32_t per_block)
+                                 uint32_t* ident, int* radii, uint32_t* counters, uint32_t* hist0, uint32_t per_block,
+                                 uint32_t* tile_count)
 {
     PreArgs a; a.p = p;
     // (staging the SH rows through LDS was tried here and lost: 50 KB/block costs more occupancy than the strided reads cost)
     hipLaunchKernelGGL(preprocess_fwd_kernel, dim3((p.P + 255) / 256), dim3(256), 0, s, a, rec, tiles, depth_keys, ident, radii, counters,
-                       hist0, per_block);
+                       hist0, per_block, tile_count);
     return hipGetLastError();
 }
 

@@ -294,3 +294,144 @@ hipError_t launch_tile_ranges(hipStream_t s, uint32_t R, const uint32_t* tile_ke
     hipLaunchKernelGGL(tile_ranges_kernel, dim3((R + 255) / 256), dim3(256), 0, s, R, tile_keys, ranges);
     return hipGetLastError();
 }
+
+// =====================================================================================================================
+// Bucket binning (default path).  The (tile, depth) order of the reference's global sort is produced per tile instead:
+//   preprocess counts the instances of every tile (atomics)  ->  tile_scan_kernel turns the counts into [start,end) ranges
+//   ->  bucket_scatter_kernel drops every instance into its tile's range (atomic cursor, arbitrary order)
+//   ->  tile_sort_kernel sorts each tile's range in LDS by the 64-bit key (depth bits << 32 | Gaussian id).
+// That total order is exactly what a stable sort on (tile, depth) yields for instances emitted in Gaussian-index order
+// (rasterizer_impl.cu:70-111,376-381): ties on identical depth bits resolve by Gaussian index.  No pass over all R
+// instances ever touches HBM more than twice, and nothing needs the host to know R before it is launched.
+// =====================================================================================================================
+
+// exclusive scan of the per-tile counts -> ranges[t] = (start, end); stats[0] = R, stats[1] = largest tile
+__global__ void __launch_bounds__(1024)
+tile_scan_kernel(uint32_t T, const uint32_t* __restrict__ tile_count, uint32_t* __restrict__ ranges, uint32_t* __restrict__ stats)
+{
+    __shared__ uint32_t wave_sums[16];
+    __shared__ uint32_t wave_max[16];
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const uint32_t per = (T + 1023) / 1024;
+    const uint32_t beg = min(T, tid * per), end = min(T, beg + per);
+    uint32_t sum = 0, mx = 0;
+    for (uint32_t i = beg; i < end; i++) { const uint32_t c = tile_count[i]; sum += c; mx = max(mx, c); }
+    uint32_t v = sum;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) { uint32_t t = __shfl_up(v, off, 64); if (lane >= (uint32_t)off) v += t; }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, off, 64));
+    if (lane == 63) wave_sums[wid] = v;
+    if (lane == 0) wave_max[wid] = mx;
+    __syncthreads();
+    uint32_t woff = 0, total = 0, gmax = 0;
+    for (uint32_t w = 0; w < 16; w++) { const uint32_t t = wave_sums[w]; if (w < wid) woff += t; total += t; gmax = max(gmax, wave_max[w]); }
+    uint32_t run = v - sum + woff;
+    for (uint32_t i = beg; i < end; i++) { const uint32_t c = tile_count[i]; ranges[2 * i] = run; run += c; ranges[2 * i + 1] = run; }
+    if (tid == 0) { stats[0] = total; stats[1] = gmax; }
+}
+hipError_t launch_tile_scan(hipStream_t s, uint32_t T, const uint32_t* tile_count, uint32_t* ranges, uint32_t* stats)
+{
+    hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, s, T, tile_count, ranges, stats);
+    return hipGetLastError();
+}
+
+// a block of 256 Gaussians (index order) drops its instances into the tile buckets cooperatively
+__global__ void __launch_bounds__(256)
+bucket_scatter_kernel(int P, int gx, int gy, const uint32_t* __restrict__ tiles, const float* __restrict__ rec,
+                      const int* __restrict__ radii, const uint32_t* __restrict__ ranges, uint32_t* __restrict__ cursor,
+                      uint32_t* __restrict__ bkey, uint32_t* __restrict__ bid, uint32_t capacity)
+{
+    __shared__ uint32_t incl[256];
+    __shared__ uint32_t dkey[256];
+    __shared__ int rx0[256], ry0[256], rw[256];
+    __shared__ uint32_t ws[4];
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int g = blockIdx.x * 256 + tid;
+    uint32_t cnt = 0, dk = 0;
+    int x0 = 0, y0 = 0, x1 = 0, y1 = 0;
+    if (g < P) {
+        cnt = tiles[g];
+        if (cnt) {
+            const float* r = rec + (size_t)g * REC_F;
+            get_rect(r[0], r[1], radii[g], gx, gy, x0, y0, x1, y1);
+            dk = __float_as_uint(r[31]);
+        }
+    }
+    uint32_t v = cnt;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) { uint32_t t = __shfl_up(v, off, 64); if (lane >= (uint32_t)off) v += t; }
+    if (lane == 63) ws[wid] = v;
+    __syncthreads();
+    uint32_t woff = 0;
+    for (uint32_t w = 0; w < wid; w++) woff += ws[w];
+    const uint32_t total = ws[0] + ws[1] + ws[2] + ws[3];
+    incl[tid] = v + woff;
+    dkey[tid] = dk; rx0[tid] = x0; ry0[tid] = y0; rw[tid] = x1 - x0;
+    __syncthreads();
+    for (uint32_t k = tid; k < total; k += 256) {
+        uint32_t lo = 0, hi = 255;
+#pragma unroll
+        for (int it = 0; it < 8; it++) { const uint32_t mid = (lo + hi) >> 1; if (incl[mid] > k) hi = mid; else lo = mid + 1; }
+        const uint32_t j = lo;
+        const uint32_t local = k - (j ? incl[j - 1] : 0u);
+        const int w = rw[j];
+        const uint32_t t = (uint32_t)((ry0[j] + (int)(local / (uint32_t)w)) * gx + rx0[j] + (int)(local % (uint32_t)w));
+        const uint32_t pos = ranges[2 * t] + atomicAdd(&cursor[t], 1u);
+        if (pos < capacity) { bkey[pos] = dkey[j]; bid[pos] = (uint32_t)(blockIdx.x * 256 + j); }
+    }
+}
+hipError_t launch_bucket_scatter(hipStream_t s, int P, int gx, int gy, const uint32_t* tiles, const float* rec, const int* radii,
+                                 const uint32_t* ranges, uint32_t* cursor, uint32_t* bkey, uint32_t* bid, uint32_t capacity)
+{
+    hipLaunchKernelGGL(bucket_scatter_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, gx, gy, tiles, rec, radii, ranges, cursor, bkey,
+                       bid, capacity);
+    return hipGetLastError();
+}
+
+// one workgroup per tile: bitonic sort of the tile's (depth bits << 32 | id) keys in LDS, sorted ids -> point_list
+template <int NMAX, int THREADS>
+__global__ void __launch_bounds__(THREADS)
+tile_sort_kernel(const uint32_t* __restrict__ ranges, const uint32_t* __restrict__ bkey, const uint32_t* __restrict__ bid,
+                 uint32_t* __restrict__ point_list, uint32_t nmin, uint32_t capacity)
+{
+    extern __shared__ __attribute__((aligned(16))) uint64_t skeys[];
+    const uint32_t beg = ranges[2 * blockIdx.x], end = ranges[2 * blockIdx.x + 1];
+    const uint32_t n = end - beg;
+    if (n < nmin || n > (uint32_t)NMAX || end > capacity) return;        // another tier's tile, or (to be retried) an overflow
+    if (n == 1) { if (threadIdx.x == 0) point_list[beg] = bid[beg]; return; }
+    uint32_t N = 2;
+    while (N < n) N <<= 1;
+    for (uint32_t i = threadIdx.x; i < N; i += THREADS)
+        skeys[i] = (i < n) ? (((uint64_t)bkey[beg + i] << 32) | (uint64_t)bid[beg + i]) : ~0ull;
+    __syncthreads();
+    for (uint32_t k = 2; k <= N; k <<= 1) {
+        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+            for (uint32_t p = threadIdx.x; p < (N >> 1); p += THREADS) {
+                const uint32_t idx = ((p & ~(j - 1)) << 1) | (p & (j - 1));      // index with bit log2(j) clear
+                const uint32_t par = idx | j;
+                const uint64_t a = skeys[idx], b = skeys[par];
+                const bool up = (idx & k) == 0;
+                if ((a > b) == up) { skeys[idx] = b; skeys[par] = a; }
+            }
+            __syncthreads();
+        }
+    }
+    for (uint32_t i = threadIdx.x; i < n; i += THREADS) point_list[beg + i] = (uint32_t)skeys[i];
+}
+hipError_t launch_tile_sort(hipStream_t s, uint32_t T, const uint32_t* ranges, const uint32_t* bkey, const uint32_t* bid,
+                            uint32_t* point_list, uint32_t capacity, bool big_tiles)
+{
+    hipLaunchKernelGGL((tile_sort_kernel<TILE_SORT_SMALL, 256>), dim3(T), dim3(256), TILE_SORT_SMALL * 8, s, ranges, bkey, bid,
+                       point_list, 1u, capacity);
+    if (big_tiles) {
+        static bool attr_set = false;
+        if (!attr_set) {
+            (void)hipFuncSetAttribute((const void*)tile_sort_kernel<TILE_SORT_BIG, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, TILE_SORT_BIG * 8);
+            attr_set = true;
+        }
+        hipLaunchKernelGGL((tile_sort_kernel<TILE_SORT_BIG, 1024>), dim3(T), dim3(1024), TILE_SORT_BIG * 8, s, ranges, bkey, bid,
+                           point_list, (uint32_t)TILE_SORT_SMALL + 1u, capacity);
+    }
+    return hipGetLastError();
+}

@@ -455,3 +455,24 @@ def test_native_step_equals_autograd_step_and_null_grads_equal_zero_grads(dev):
     for n, x, y in zip(GNAMES, g_zero, g_none):
         r = rel(x.cpu().numpy(), y.cpu().numpy())
         assert np.quantile(r, 0.999) < 1e-3, (n, np.quantile(r, 0.999))
+
+
+def test_bucket_and_radix_binning_agree(dev, monkeypatch):
+    """Default path (per-tile buckets + in-LDS sort) and the global radix-sort path produce the same instance list and images;
+    the first call on a fresh capacity hint also exercises the optimistic-capacity retry (cfg-1 has > 4 instances per Gaussian)."""
+    from igs_amd import rasterizer as R
+    raw, cams, bg = cfg1_scene(P=6000, size=192)
+    cam, a = cams[0], activate(raw)
+    out_b, _, _ = hip_forward(a, cam, bg, dev, debug=False)
+    db = R.debug_dump(6000, out_b[0], cam.width, cam.height, out_b[9], out_b[10], out_b[11])
+    monkeypatch.setenv("IGS_BINNING", "radix")
+    out_r, _, _ = hip_forward(a, cam, bg, dev, debug=False)
+    dr = R.debug_dump(6000, out_r[0], cam.width, cam.height, out_r[9], out_r[10], out_r[11])
+    monkeypatch.delenv("IGS_BINNING")
+    assert out_b[0] == out_r[0]
+    assert torch.equal(db["point_list"], dr["point_list"]) and torch.equal(db["ranges"], dr["ranges"])
+    assert torch.equal(db["n_contrib"], dr["n_contrib"])
+    for i in range(1, 8):
+        assert torch.equal(out_b[i], out_r[i])
+    nr_o, oo, st = oracle_forward(a, cam, bg)
+    np.testing.assert_array_equal(db["point_list"].cpu().numpy().astype(np.uint32), st.intermediates()["point_list"])
