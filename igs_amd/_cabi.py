@@ -8,13 +8,14 @@ import os
 from . import build as _build
 
 _LIB = None
+E_RETRY = -6      # IGS_RAST_E_RETRY
 
 ALLOC_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_size_t)
 _vp, _i, _f = C.c_void_p, C.c_int, C.c_float
 
 EXPORTS = ["igs_rast_version", "igs_rast_last_error", "igs_rast_forward", "igs_rast_backward_workspace_bytes",
-           "igs_rast_backward", "igs_rast_mark_visible", "igs_rast_debug_dump",
-           "igs_rast_profile_enable", "igs_rast_profile_read", "igs_adam_step", "igs_l1_loss_fwd_bwd", "igs_activate_fwd", "igs_activate_bwd"]
+           "igs_rast_forward_async", "igs_rast_forward_finish", "igs_rast_backward", "igs_rast_mark_visible", "igs_rast_debug_dump",
+           "igs_rast_profile_enable", "igs_rast_profile_read", "igs_adam_step", "igs_adam_step_groups", "igs_l1_loss_fwd_bwd", "igs_activate_fwd", "igs_activate_bwd"]
 
 STAGES = ["preprocess", "depth_sort", "scan", "emit", "tile_sort", "ranges", "blend_fwd", "memset", "blend_bwd", "geom_bwd"]
 
@@ -36,6 +37,10 @@ def lib():
     L.igs_rast_forward.restype = _i
     L.igs_rast_forward.argtypes = ([_vp, ALLOC_FN, _vp, ALLOC_FN, _vp, ALLOC_FN, _vp, _i, _i, _i, _vp, _i, _i]
                                    + [_vp] * 5 + [_f, _vp, _vp, _vp, _vp, _vp, _f, _f, _f, _i] + [_vp] * 8 + [_i, _i, _i])
+    L.igs_rast_forward_async.restype = _i
+    L.igs_rast_forward_async.argtypes = L.igs_rast_forward.argtypes
+    L.igs_rast_forward_finish.restype = _i
+    L.igs_rast_forward_finish.argtypes = []
     L.igs_rast_backward_workspace_bytes.restype = C.c_size_t
     L.igs_rast_backward_workspace_bytes.argtypes = [_i]
     L.igs_rast_backward.restype = _i
@@ -52,6 +57,8 @@ def lib():
     if hasattr(L, "igs_adam_step"):
         L.igs_adam_step.restype = _i
         L.igs_adam_step.argtypes = [_vp, C.c_size_t, _vp, _vp, _vp, _vp, _f, _f, _f, _f, _f, _f]
+        L.igs_adam_step_groups.restype = _i
+        L.igs_adam_step_groups.argtypes = [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _f, _f, _f]
         L.igs_l1_loss_fwd_bwd.restype = _i
         L.igs_l1_loss_fwd_bwd.argtypes = [_vp, C.c_size_t, _vp, _vp, _vp, _vp, _f]
         L.igs_activate_fwd.restype = _i

@@ -88,6 +88,10 @@ extern "C" size_t igs_rast_backward_workspace_bytes(int P) { return (size_t)(P >
 // what the previous forward on this host thread saw: sizes the binning buffer before R is known
 struct BinHint { uint32_t last_R = 0, last_max = 0; };
 static thread_local BinHint g_hint;
+// igs_rast_forward_async leaves its host-side check of R to igs_rast_forward_finish
+struct PendingFwd { bool active = false; uint32_t cap = 0; bool big = false; };
+static thread_local PendingFwd g_pending;
+static thread_local bool g_async_request = false;
 
 static int forward_impl(
     void* stream,
@@ -272,6 +276,11 @@ static int forward_impl(
     HIP_TRY(launch_blend_fwd(s, ba, require_coord != 0, require_depth != 0), "blend_fwd launch");
     DBG_SYNC("blend_fwd");
     prof_mark(s, ST_BLEND_FWD);
+    if (bucket_pending && g_async_request) {
+        g_pending.active = true; g_pending.cap = bucket_cap; g_pending.big = bucket_big;
+        if (g_prof.on) g_prof.calls++;
+        return (int)(bucket_cap > 0x7FFFFFFFu ? 0x7FFFFFFF : bucket_cap);     // an upper bound usable as R by backward
+    }
     if (bucket_pending) {
         // only now does the host look at R: the whole pipeline above was enqueued without waiting for it
         HIP_TRY(hipEventSynchronize(g_slot.ev), "event sync");
@@ -314,6 +323,49 @@ extern "C" int igs_rast_forward(
                         cov3D_precomp, viewmatrix, projmatrix, cam_pos, tan_fovx, tan_fovy, kernel_size, prefiltered, out_color,
                         out_coord, out_mcoord, out_depth, out_mdepth, out_alpha, out_normal, radii, require_coord, require_depth,
                         debug, radix, 0, false);
+}
+
+// Asynchronous variant for callers that keep enqueueing work (the native refine step): identical to igs_rast_forward but
+// returns right after the last launch WITHOUT waiting for the instance count; the return value is the capacity of the
+// instance list (an upper bound that igs_rast_backward accepts as R).  igs_rast_forward_finish() then waits for the small
+// read-back (which completed right after the tile scan, long before the blend) and returns the true num_rendered, or
+// IGS_RAST_E_RETRY if the guessed capacity / sort tier was too small: everything enqueued since must then be discarded and
+// the frame redone with igs_rast_forward (the hints are updated, so it will fit).
+extern "C" int igs_rast_forward_async(
+    void* stream,
+    igs_rast_alloc_fn geometry_buffer, void* geometry_user, igs_rast_alloc_fn binning_buffer, void* binning_user,
+    igs_rast_alloc_fn image_buffer, void* image_user,
+    int P, int D, int M, const float* background, int width, int height,
+    const float* means3D, const float* shs, const float* colors_precomp, const float* opacities,
+    const float* scales, float scale_modifier, const float* rotations, const float* cov3D_precomp,
+    const float* viewmatrix, const float* projmatrix, const float* cam_pos,
+    float tan_fovx, float tan_fovy, float kernel_size, int prefiltered,
+    float* out_color, float* out_coord, float* out_mcoord, float* out_depth, float* out_mdepth, float* out_alpha,
+    float* out_normal, int* radii, int require_coord, int require_depth, int debug)
+{
+    g_pending.active = false;
+    g_async_request = true;
+    const int rc = forward_impl(stream, geometry_buffer, geometry_user, binning_buffer, binning_user, image_buffer, image_user, P, D, M,
+                                background, width, height, means3D, shs, colors_precomp, opacities, scales, scale_modifier, rotations,
+                                cov3D_precomp, viewmatrix, projmatrix, cam_pos, tan_fovx, tan_fovy, kernel_size, prefiltered, out_color,
+                                out_coord, out_mcoord, out_depth, out_mdepth, out_alpha, out_normal, radii, require_coord, require_depth,
+                                debug, false, 0, false);
+    g_async_request = false;
+    return rc;
+}
+extern "C" int igs_rast_forward_finish(void)
+{
+    if (!g_pending.active) return fail(IGS_RAST_E_INVALID, "igs_rast_forward_finish: no asynchronous forward pending");
+    g_pending.active = false;
+    HIP_TRY(hipEventSynchronize(g_slot.ev), "event sync");
+    const uint32_t R_dev = g_slot.pinned[0], max_tile = g_slot.pinned[1];
+    if (g_slot.pinned[2]) return fail(IGS_RAST_E_PREFILTER, "Point is filtered although prefiltered is set. This shouldn't happen!");
+    if (R_dev > 0x7FFFFFFFu) return fail(IGS_RAST_E_INVALID, "instance count overflows int");
+    g_hint.last_R = R_dev; g_hint.last_max = max_tile;
+    const uint32_t sortable = g_pending.big ? (uint32_t)TILE_SORT_BIG : (uint32_t)TILE_SORT_SMALL;
+    if (R_dev > g_pending.cap || max_tile > sortable) return fail(IGS_RAST_E_RETRY, "instance-list capacity guess too small: redo the frame");
+    if (g_prof.on) g_prof.r_sum += (double)R_dev;
+    return (int)R_dev;
 }
 
 extern "C" int igs_rast_backward(
@@ -364,7 +416,7 @@ extern "C" int igs_rast_backward(
     ba.normal_length = (const float*)(ibase + IL.normal_length); ba.n_contrib = (const uint32_t*)(ibase + IL.n_contrib);
     ba.dL_dpix = dL_dpix; ba.dL_dcoord = dL_dpix_coord; ba.dL_dmcoord = dL_dpix_mcoord; ba.dL_ddepth = dL_dpix_depth;
     ba.dL_dmdepth = dL_dpix_mdepth; ba.dL_dalpha = dL_dalphas; ba.dL_dnormal = dL_dpixel_normals;
-    ba.gacc = gacc;
+    ba.gacc = gacc; ba.list_capacity = (uint32_t)R;
     if (R > 0) {
         HIP_TRY(launch_blend_bwd(s, ba, require_coord != 0, require_depth != 0), "blend_bwd launch");
         DBG_SYNC("blend_bwd");

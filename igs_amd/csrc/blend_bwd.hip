@@ -52,7 +52,7 @@ blend_bwd_kernel(const BlendBwdArgs a)
 
     const uint2 range = ((const uint2*)a.ranges)[tile];
     // clamped to the tile's list length: a corrupt image buffer must not turn into an out-of-bounds gather
-    int last_contributor = inside ? (int)min(a.n_contrib[pix], range.y - range.x) : 0;
+    int last_contributor = (inside && range.y <= a.list_capacity) ? (int)min(a.n_contrib[pix], range.y - range.x) : 0;
     const uint32_t max_contributor = inside ? a.n_contrib[pix + HW] : 0u;
 
     // ---- per-pixel upstream gradients (backward.cu:732-781); zero for pixels nothing was blended into, whose

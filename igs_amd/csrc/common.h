@@ -149,6 +149,7 @@ struct BlendBwdArgs {
     const float *alphas, *normalmap, *accum_coord, *accum_depth, *normal_length; const uint32_t* n_contrib;
     const float *dL_dpix, *dL_dcoord, *dL_dmcoord, *dL_ddepth, *dL_dmdepth, *dL_dalpha, *dL_dnormal;
     float* gacc;
+    uint32_t list_capacity;                // = R handed to igs_rast_backward (an upper bound after igs_rast_forward_async)
 };
 hipError_t launch_blend_bwd(hipStream_t s, const BlendBwdArgs& a, bool coord, bool depth);
 

@@ -48,6 +48,57 @@ extern "C" int igs_adam_step(void* stream, size_t n, float* param, const float* 
     return hipGetLastError() == hipSuccess ? 0 : IGS_RAST_E_HIP;
 }
 
+struct AdamGroups { int n; size_t off[8]; size_t cnt[8]; float lr_over_bc1[8]; };
+__global__ void __launch_bounds__(256)
+adam_groups_kernel(const AdamGroups G, float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                   float b1, float b2, float eps, float inv_sqrt_bc2)
+{
+    // blockIdx.y = group; grid-stride over the group's span (float4 body when the span is 16-byte aligned)
+    const int k = blockIdx.y;
+    if (k >= G.n) return;
+    const size_t o = G.off[k], n = G.cnt[k];
+    const float lr = G.lr_over_bc1[k];
+    float* pp = p + o; const float* gg = g + o; float* mm = m + o; float* vv = v + o;
+    const bool aligned = (((uintptr_t)pp | (uintptr_t)gg | (uintptr_t)mm | (uintptr_t)vv) & 15) == 0;
+    const size_t n4 = aligned ? n / 4 : 0;
+    const size_t stride = (size_t)gridDim.x * 256;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+        float4 P4 = ((float4*)pp)[i], M4 = ((float4*)mm)[i], V4 = ((float4*)vv)[i];
+        const float4 G4 = ((const float4*)gg)[i];
+        float* a = (float*)&P4; float* b = (float*)&M4; float* c = (float*)&V4; const float* d = (const float*)&G4;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            b[q] = b1 * b[q] + (1.f - b1) * d[q];
+            c[q] = b2 * c[q] + (1.f - b2) * d[q] * d[q];
+            a[q] -= lr * b[q] / (sqrtf(c[q]) * inv_sqrt_bc2 + eps);
+        }
+        ((float4*)pp)[i] = P4; ((float4*)mm)[i] = M4; ((float4*)vv)[i] = V4;
+    }
+    for (size_t i = n4 * 4 + (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+        const float gi = gg[i];
+        const float mi = b1 * mm[i] + (1.f - b1) * gi;
+        const float vi = b2 * vv[i] + (1.f - b2) * gi * gi;
+        mm[i] = mi; vv[i] = vi;
+        pp[i] -= lr * mi / (sqrtf(vi) * inv_sqrt_bc2 + eps);
+    }
+}
+extern "C" int igs_adam_step_groups(void* stream, int ngroups, const size_t* offset, const size_t* count, const float* lr, float* param,
+                                    const float* grad, float* exp_avg, float* exp_avg_sq, float beta1, float beta2, float eps,
+                                    float bias_correction1, float bias_correction2_sqrt)
+{
+    if (ngroups <= 0) return 0;
+    if (ngroups > 8 || !offset || !count || !lr || !param || !grad || !exp_avg || !exp_avg_sq) return IGS_RAST_E_INVALID;
+    AdamGroups G; G.n = ngroups;
+    size_t nmax = 0;
+    for (int k = 0; k < ngroups; k++) { G.off[k] = offset[k]; G.cnt[k] = count[k]; G.lr_over_bc1[k] = lr[k] / bias_correction1; if (count[k] > nmax) nmax = count[k]; }
+    size_t blocks = (nmax / 4 + 255) / 256;
+    if (blocks > 1024) blocks = 1024;
+    if (blocks == 0) blocks = 1;
+    hipLaunchKernelGGL(adam_groups_kernel, dim3((unsigned)blocks, (unsigned)ngroups), dim3(256), 0, (hipStream_t)stream, G, param, grad, exp_avg,
+                       exp_avg_sq, beta1, beta2, eps, 1.0f / bias_correction2_sqrt);
+    return hipGetLastError() == hipSuccess ? 0 : IGS_RAST_E_HIP;
+}
+
 // L1: loss_sum += sum |pred - gt| ; grad = sign(pred - gt) * scale        (mean => scale = upstream / n)
 __global__ void __launch_bounds__(256)
 l1_kernel(size_t n4, size_t n, const float* __restrict__ pred, const float* __restrict__ gt, float* __restrict__ grad, float* __restrict__ loss_sum, float scale)

@@ -85,11 +85,13 @@ def _check(rc, what):
 
 def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp, viewmatrix,
                         projmatrix, tan_fovx, tan_fovy, kernel_size, image_height, image_width, sh, degree, campos,
-                        prefiltered, require_coord, require_depth, debug, buffers=None):
+                        prefiltered, require_coord, require_depth, debug, buffers=None, defer=False):
     """`_C.rasterize_gaussians` (RasterizeGaussiansCUDA, DGR/rasterize_points.cu:35-133).
 
     Returns (num_rendered, color, coord, mcoord, alpha, normal, depth, mdepth, radii, geomBuffer, binningBuffer, imgBuffer).
-    `buffers` (extension) is a RasterBuffers object whose image / radii / scratch tensors are reused across calls."""
+    `buffers` (extension) is a RasterBuffers object whose image / radii / scratch tensors are reused across calls.
+    `defer=True` (extension) does not wait for the instance count: num_rendered is then an upper bound (accepted by
+    rasterize_gaussians_backward) and `rasterize_finish()` must be called before the results are trusted."""
     if means3D.dim() != 2 or means3D.size(1) != 3:
         raise RasterizerError("means3D must have dimensions (num_points, 3)")
     if not means3D.is_cuda:
@@ -117,7 +119,7 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
         rendered = 0
         if P != 0:
             stream = torch.cuda.current_stream(dev).cuda_stream
-            rendered = L.igs_rast_forward(
+            rendered = (L.igs_rast_forward_async if defer else L.igs_rast_forward)(
                 stream, geom.cb, None, binning.cb, None, img.cb, None, P, int(degree), M, _ptr(bg_c), W, H,
                 _ptr(means3D_c), _ptr(sh_c), _ptr(colors_c), _ptr(opacity_c), _ptr(scales_c), float(scale_modifier),
                 _ptr(rotations_c), _ptr(cov_c), _ptr(view_c), _ptr(proj_c), _ptr(campos_c), float(tan_fovx), float(tan_fovy),
@@ -125,6 +127,17 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
                 _ptr(alpha), _ptr(normal), _ptr(radii), int(bool(require_coord)), int(bool(require_depth)), int(bool(debug)))
             _check(rendered, "igs_rast_forward")
     return (rendered, color, coord, mcoord, alpha, normal, depth, mdepth, radii, geom.tensor, binning.tensor, img.tensor)
+
+
+def rasterize_finish():
+    """Completes a `rasterize_gaussians(..., defer=True)`: returns the true num_rendered, or None when the optimistic
+    instance-list capacity was too small -- everything computed from that frame must then be discarded and the frame redone
+    (igs_rast_forward_finish, include/igs_rast.h)."""
+    rc = _cabi.lib().igs_rast_forward_finish()
+    if rc == _cabi.E_RETRY:
+        return None
+    _check(rc, "igs_rast_forward_finish")
+    return rc
 
 
 def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rotations, scale_modifier, cov3D_precomp,

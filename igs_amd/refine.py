@@ -64,21 +64,24 @@ class GaussianParams:
         self.grad.zero_()
 
     def adam_step(self):
-        """torch.optim.Adam semantics, one fused HIP launch per parameter group."""
+        """torch.optim.Adam semantics, all parameter groups in one fused HIP launch."""
         L = _cabi.lib()
         self.step_count += 1
         b1, b2 = self.betas
         bc1 = 1.0 - b1 ** self.step_count
         bc2s = math.sqrt(1.0 - b2 ** self.step_count)
         stream = torch.cuda.current_stream(self.device).cuda_stream
-        es = 4
-        for name, _ in GROUPS:
-            o, n = self.spans[name]
-            rc = L.igs_adam_step(stream, n, self.flat.data_ptr() + o * es, self.grad.data_ptr() + o * es,
-                                 self.exp_avg.data_ptr() + o * es, self.exp_avg_sq.data_ptr() + o * es,
-                                 self.lrs[name], b1, b2, self.eps, bc1, bc2s)
-            if rc != 0:
-                raise RuntimeError("igs_adam_step failed: %d" % rc)
+        if not hasattr(self, "_adam_groups"):
+            import ctypes as C
+            k = len(GROUPS)
+            self._adam_groups = ((C.c_size_t * k)(*[self.spans[n][0] for n, _ in GROUPS]),
+                                 (C.c_size_t * k)(*[self.spans[n][1] for n, _ in GROUPS]),
+                                 (C.c_float * k)(*[self.lrs[n] for n, _ in GROUPS]), k)
+        off, cnt, lrs, k = self._adam_groups
+        rc = L.igs_adam_step_groups(stream, k, off, cnt, lrs, self.flat.data_ptr(), self.grad.data_ptr(), self.exp_avg.data_ptr(),
+                                    self.exp_avg_sq.data_ptr(), b1, b2, self.eps, bc1, bc2s)
+        if rc != 0:
+            raise RuntimeError("igs_adam_step_groups failed: %d" % rc)
 
 
 def render(params_act, cam, bg, sh_degree=3, require_coord=True, require_depth=True, means2D=None, debug=False):
@@ -165,7 +168,7 @@ class Refiner:
             picks.append(self.order.pop())
         return picks[self.rank]
 
-    def _native_step(self, cam, gt):
+    def _native_step(self, cam, gt, defer=True):
         """render -> fused L1 -> backward -> activation backward, driving the C ABI directly (no autograd graph): the
         rasterizer writes dL/dxyz and dL/dsh straight into their spans of the flat gradient buffer."""
         p = self.params
@@ -187,7 +190,8 @@ class Refiner:
         with torch.no_grad():
             out = _rast.rasterize_gaussians(self.bg, raw["xyz"].detach(), e, opac, scal, rotn, 1.0, e, cam.world_view_transform,
                                             cam.full_proj_transform, cam.tanfovx, cam.tanfovy, 0.0, cam.height, cam.width,
-                                            raw["shs"].detach(), 3, cam.camera_center, False, True, True, False, buffers=self._bufs)
+                                            raw["shs"].detach(), 3, cam.camera_center, False, True, True, False, buffers=self._bufs,
+                                            defer=defer)
             nr, color, coord, mcoord, alpha, normal, depth, mdepth, radii, gb, bb, ib = out
             if self.grad_img is None or self.grad_img.shape != color.shape:
                 self.grad_img = torch.empty_like(color)
@@ -208,6 +212,12 @@ class Refiner:
                                     d_sc.data_ptr(), d_rt.data_ptr(), span("opacity", (P, 1)).data_ptr(),
                                     span("scaling", (P, 3)).data_ptr(), span("rotation", (P, 4)).data_ptr())
             assert rc == 0
+        if defer:
+            # the whole frame was enqueued without the host knowing the instance count; look at it now (the 12-byte
+            # read-back finished long ago on the GPU's timeline) and redo the frame in the rare case the list did not fit
+            nr = _rast.rasterize_finish()
+            if nr is None:
+                return self._native_step(cam, gt, defer=False)
         self.last_num_rendered = nr
         return dict(images_pred=color, radii=radii, visibility_filter=None, viewspace_points=outs["means2D"], alpha=alpha,
                     depth_pred=depth, normal=normal)

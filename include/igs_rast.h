@@ -47,6 +47,8 @@ extern "C" {
 #define IGS_RAST_E_PREFILTER (-4)   /* `prefiltered` set but a point was culled (the reference __trap()s, auxiliary.h:172-176) */
 #define IGS_RAST_E_CHANNELS  (-5)   /* reserved: non-RGB without precomputed colours (rasterizer_impl.cu:308-311) */
 
+#define IGS_RAST_E_RETRY     (-6)   /* igs_rast_forward_finish: the optimistic instance-list capacity was too small */
+
 /* Scratch growth callback: make the buffer at least `bytes` long and return its device address
  * (the reference's std::function<char*(size_t)> resizeFunctional, rasterize_points.cu:27-33). */
 typedef char* (*igs_rast_alloc_fn)(void* user, size_t bytes);
@@ -86,6 +88,25 @@ int igs_rast_forward(
     int* radii,                           /* [P] */
     int require_coord, int require_depth,
     int debug);                           /* debug != 0: synchronise and check after every launch (auxiliary.h:404-411) */
+
+/* Asynchronous pair (no reference counterpart; used by the native refine step so the GPU never waits for the host):
+ * igs_rast_forward_async = igs_rast_forward without the final wait for the instance count; it returns the CAPACITY of the
+ * instance list, an upper bound that igs_rast_backward accepts as R.  igs_rast_forward_finish() waits for the 12-byte
+ * read-back (done right after the tile scan) and returns the true num_rendered, or IGS_RAST_E_RETRY when the guessed
+ * capacity / sort tier was too small: whatever was enqueued on top of the frame must then be discarded and the frame
+ * redone with igs_rast_forward. */
+int igs_rast_forward_async(
+    void* stream,
+    igs_rast_alloc_fn geometry_buffer, void* geometry_user, igs_rast_alloc_fn binning_buffer, void* binning_user,
+    igs_rast_alloc_fn image_buffer, void* image_user,
+    int P, int D, int M, const float* background, int width, int height,
+    const float* means3D, const float* shs, const float* colors_precomp, const float* opacities,
+    const float* scales, float scale_modifier, const float* rotations, const float* cov3D_precomp,
+    const float* viewmatrix, const float* projmatrix, const float* cam_pos,
+    float tan_fovx, float tan_fovy, float kernel_size, int prefiltered,
+    float* out_color, float* out_coord, float* out_mcoord, float* out_depth, float* out_mdepth, float* out_alpha,
+    float* out_normal, int* radii, int require_coord, int require_depth, int debug);
+int igs_rast_forward_finish(void);
 
 size_t igs_rast_backward_workspace_bytes(int P);
 
@@ -162,6 +183,11 @@ int igs_rast_profile_read(double* ms_sum, long long* count, double* r_sum, long 
  * bias_correction1 = 1 - beta1^t, bias_correction2_sqrt = sqrt(1 - beta2^t). */
 int igs_adam_step(void* stream, size_t n, float* param, const float* grad, float* exp_avg, float* exp_avg_sq,
                   float lr, float beta1, float beta2, float eps, float bias_correction1, float bias_correction2_sqrt);
+
+/* The same for up to 8 parameter groups in ONE launch: group k covers param[offset[k] .. offset[k]+count[k]) with lr[k]. */
+int igs_adam_step_groups(void* stream, int ngroups, const size_t* offset, const size_t* count, const float* lr, float* param,
+                         const float* grad, float* exp_avg, float* exp_avg_sq, float beta1, float beta2, float eps,
+                         float bias_correction1, float bias_correction2_sqrt);
 
 /* Fused L1 loss forward + backward (igs/utils/loss_utils.py:17-18): grad[i] = sign(pred[i] - gt[i]) * scale, and
  * sum |pred - gt| is accumulated into 64 shards loss_sum[16*s], s = 0..63 (1024 floats, zeroed by the caller, summed by
