@@ -26,12 +26,13 @@ import torch  # noqa: E402
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
 
-def algorithmic_bytes(R, W, H, coord=True, depth=True, bwd_coord=None, bwd_depth=None, bwd_normal=None):
+def algorithmic_bytes(R, W, H, coord=True, depth=True, bwd_coord=None, bwd_depth=None, bwd_normal=None, l1_fused=False):
     """per-launch algorithmic bytes of the two tile-blend kernels.
     forward : R*g + H*W*p + 8*T          g = 40 + 36[coord] + 12[depth] + 12[normal], p = 24 + 36[coord] + 12[depth] + 16[normal]
     backward: R*g + H*W*px + R*100       px = 28 + 48[coord] + 12[depth] + 16[normal]   (104 with every branch on)
     The backward's branches are those of the instance that was launched: with a colour-only loss the geometry gradients
-    are absent and the colour-only instance runs (g = 40, px = 28)."""
+    are absent and the colour-only instance runs (g = 40, px = 28).  With the L1 loss fused in (igs_refine_step) the kernel reads
+    the rendered colour and the ground truth (24 B/px) instead of dL_dpix (12 B/px): px += 12."""
     normal = coord or depth
     g = 40 + 36 * coord + 12 * depth + 12 * normal
     p = 24 + 36 * coord + 12 * depth + 16 * normal
@@ -40,7 +41,7 @@ def algorithmic_bytes(R, W, H, coord=True, depth=True, bwd_coord=None, bwd_depth
     bd = depth if bwd_depth is None else bwd_depth
     bn = (bc or bd) if bwd_normal is None else bwd_normal
     gb = 40 + 36 * bc + 12 * bd + 12 * bn
-    px_bwd = 28 + (36 + 12) * bc + 12 * bd + 16 * bn
+    px_bwd = 28 + (36 + 12) * bc + 12 * bd + 16 * bn + 12 * bool(l1_fused)
     return dict(blend_fwd=R * g + H * W * p + 8 * T, blend_bwd=R * gb + H * W * px_bwd + R * 100)
 
 
@@ -160,7 +161,8 @@ def main():
         if stages and calls:
             R_avg = r_sum / calls
             geo_bwd = args.loss != "l1" and False      # both losses only see the colour image: geometry gradients are absent
-            ab = algorithmic_bytes(R_avg, args.width, args.height, True, True, geo_bwd, geo_bwd, geo_bwd)
+            fused = world == 1 and args.loss == "l1"      # single GPU: igs_refine_step (L1 inside blend_bwd, Adam inside geom_bwd)
+            ab = algorithmic_bytes(R_avg, args.width, args.height, True, True, geo_bwd, geo_bwd, geo_bwd, l1_fused=fused)
             per = {k: (ms / cnt if cnt else 0.0) for k, (ms, cnt) in stages.items()}
             dom = "blend_bwd" if per.get("blend_bwd", 0) >= per.get("blend_fwd", 0) else "blend_fwd"
             ach = ab[dom] / (per[dom] * 1e-3) / 1e9 if per[dom] > 0 else 0.0
@@ -174,7 +176,7 @@ def main():
             out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
                                "algorithmic_bytes_per_launch": ab[dom], "avg_launch_ms": per[dom],
-                               "instance": ("blend_bwd<colour-only gradients>: R*40 + H*W*28 + R*100 bytes" if dom == "blend_bwd"
+                               "instance": ("blend_bwd<colour-only gradients%s>: R*40 + H*W*%d + R*100 bytes" % ((", L1 fused", 40) if fused else ("", 28)) if dom == "blend_bwd"
                                             else "blend_fwd<coord,depth,normal>: R*100 + H*W*88 + 8*T bytes"),
                                "num_rendered_avg": R_avg,
                                "other": {"blend_fwd" if dom == "blend_bwd" else "blend_bwd": {

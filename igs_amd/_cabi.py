@@ -13,9 +13,31 @@ E_RETRY = -6      # IGS_RAST_E_RETRY
 ALLOC_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_size_t)
 _vp, _i, _f = C.c_void_p, C.c_int, C.c_float
 
+class RefineStepArgs(C.Structure):
+    """igs_refine_step_args (include/igs_rast.h)."""
+    _fields_ = [("stream", C.c_void_p),
+                ("geometry_buffer", ALLOC_FN), ("geometry_user", C.c_void_p),
+                ("binning_buffer", ALLOC_FN), ("binning_user", C.c_void_p),
+                ("image_buffer", ALLOC_FN), ("image_user", C.c_void_p),
+                ("workspace", C.c_void_p),
+                ("P", C.c_int), ("D", C.c_int), ("M", C.c_int), ("width", C.c_int), ("height", C.c_int),
+                ("background", C.c_void_p),
+                ("param", C.c_void_p), ("exp_avg", C.c_void_p), ("exp_avg_sq", C.c_void_p),
+                ("off_xyz", C.c_size_t), ("off_rot", C.c_size_t), ("off_sh", C.c_size_t), ("off_opacity", C.c_size_t),
+                ("off_scale", C.c_size_t),
+                ("lr_xyz", C.c_float), ("lr_rot", C.c_float), ("lr_sh", C.c_float), ("lr_opacity", C.c_float), ("lr_scale", C.c_float),
+                ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float),
+                ("step", C.c_int),
+                ("viewmatrix", C.c_void_p), ("projmatrix", C.c_void_p), ("cam_pos", C.c_void_p),
+                ("tan_fovx", C.c_float), ("tan_fovy", C.c_float),
+                ("gt", C.c_void_p), ("loss_weight", C.c_float),
+                ("out_images", C.c_void_p), ("radii", C.c_void_p), ("dL_dmean2D", C.c_void_p), ("loss_out", C.c_void_p),
+                ("require_coord", C.c_int), ("require_depth", C.c_int)]
+
+
 EXPORTS = ["igs_rast_version", "igs_rast_last_error", "igs_rast_forward", "igs_rast_backward_workspace_bytes",
-           "igs_rast_forward_async", "igs_rast_forward_finish", "igs_rast_backward", "igs_rast_mark_visible", "igs_rast_debug_dump",
-           "igs_rast_profile_enable", "igs_rast_profile_read", "igs_adam_step", "igs_adam_step_groups", "igs_l1_loss_fwd_bwd", "igs_activate_fwd", "igs_activate_bwd"]
+           "igs_rast_forward_async", "igs_rast_forward_finish", "igs_rast_set_slab_hint", "igs_rast_get_slab_hint", "igs_rast_backward", "igs_rast_mark_visible", "igs_rast_debug_dump",
+           "igs_rast_profile_enable", "igs_rast_profile_read", "igs_adam_step", "igs_adam_step_groups", "igs_refine_step", "igs_l1_loss_fwd_bwd", "igs_activate_fwd", "igs_activate_bwd"]
 
 STAGES = ["preprocess", "depth_sort", "scan", "emit", "tile_sort", "ranges", "blend_fwd", "memset", "blend_bwd", "geom_bwd"]
 
@@ -41,6 +63,10 @@ def lib():
     L.igs_rast_forward_async.argtypes = L.igs_rast_forward.argtypes
     L.igs_rast_forward_finish.restype = _i
     L.igs_rast_forward_finish.argtypes = []
+    L.igs_rast_set_slab_hint.restype = None
+    L.igs_rast_set_slab_hint.argtypes = [C.c_uint]
+    L.igs_rast_get_slab_hint.restype = C.c_uint
+    L.igs_rast_get_slab_hint.argtypes = []
     L.igs_rast_backward_workspace_bytes.restype = C.c_size_t
     L.igs_rast_backward_workspace_bytes.argtypes = [_i]
     L.igs_rast_backward.restype = _i
@@ -59,6 +85,8 @@ def lib():
         L.igs_adam_step.argtypes = [_vp, C.c_size_t, _vp, _vp, _vp, _vp, _f, _f, _f, _f, _f, _f]
         L.igs_adam_step_groups.restype = _i
         L.igs_adam_step_groups.argtypes = [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _f, _f, _f]
+        L.igs_refine_step.restype = _i
+        L.igs_refine_step.argtypes = [C.POINTER(RefineStepArgs)]
         L.igs_l1_loss_fwd_bwd.restype = _i
         L.igs_l1_loss_fwd_bwd.argtypes = [_vp, C.c_size_t, _vp, _vp, _vp, _vp, _f]
         L.igs_activate_fwd.restype = _i

@@ -2,6 +2,7 @@
 // Counterpart of CudaRasterizer::Rasterizer::{forward,backward,markVisible}
 // (DGR/cuda_rasterizer/rasterizer_impl.cu:176-188, 254-425, 429-571).
 #include "common.h"
+#include <math.h>
 #include "../../include/igs_rast.h"
 #include <stdio.h>
 #include <string.h>
@@ -18,7 +19,7 @@ static int fail(int code, const char* what, hipError_t e = hipSuccess)
 #define DBG_SYNC(what) do { if (debug) { hipError_t e_ = hipStreamSynchronize(s); if (e_ != hipSuccess) return fail(IGS_RAST_E_HIP, what, e_); } } while (0)
 
 // pinned 4-byte read-back slot + event, one per host thread and device
-struct HostSlot { int device = -1; uint32_t* pinned = nullptr; hipEvent_t ev = nullptr; };
+struct HostSlot { int device = -1; uint32_t* pinned = nullptr; uint32_t* pinned_dev = nullptr; hipEvent_t ev = nullptr; };
 static thread_local HostSlot g_slot;
 static int ensure_slot()
 {
@@ -27,6 +28,7 @@ static int ensure_slot()
     if (g_slot.device == dev && g_slot.pinned) return 0;
     if (g_slot.pinned) { (void)hipHostFree(g_slot.pinned); (void)hipEventDestroy(g_slot.ev); g_slot = HostSlot(); }
     HIP_TRY(hipHostMalloc((void**)&g_slot.pinned, (COUNTER_SHARDS + 1) * COUNTER_SHARD_STRIDE * 4, hipHostMallocDefault), "hipHostMalloc");
+    HIP_TRY(hipHostGetDevicePointer((void**)&g_slot.pinned_dev, g_slot.pinned, 0), "hipHostGetDevicePointer");
     HIP_TRY(hipEventCreateWithFlags(&g_slot.ev, hipEventDisableTiming), "hipEventCreate");
     g_slot.device = dev;
     return 0;
@@ -83,15 +85,23 @@ extern "C" int igs_rast_profile_read(double* ms_sum, long long* count, double* r
 
 extern "C" int igs_rast_version(void) { return IGS_RAST_VERSION; }
 extern "C" const char* igs_rast_last_error(void) { return g_err; }
-extern "C" size_t igs_rast_backward_workspace_bytes(int P) { return (size_t)(P > 0 ? P : 0) * GACC_F * 4 + 512; }
+// workspace = 256-byte aligned { gacc[P][32] floats | 64 loss shards one cache line apart (refine step) }
+static inline size_t ws_gacc_bytes(int P) { return ((size_t)(P > 0 ? P : 0) * GACC_F * 4 + 255) & ~(size_t)255; }
+#define WS_LOSS_BYTES 4096
+extern "C" size_t igs_rast_backward_workspace_bytes(int P) { return ws_gacc_bytes(P) + WS_LOSS_BYTES + 512; }
 
 // what the previous forward on this host thread saw: sizes the binning buffer before R is known
-struct BinHint { uint32_t last_R = 0, last_max = 0; };
+struct BinHint { uint32_t slab = 0; };              // instance slots per tile used by the last frames (0 = default)
+#define SLAB_MAX_BYTES (8ull << 30)                 // beyond this much slab scratch the global-sort path is used
 static thread_local BinHint g_hint;
 // igs_rast_forward_async leaves its host-side check of R to igs_rast_forward_finish
-struct PendingFwd { bool active = false; uint32_t cap = 0; bool big = false; };
+struct PendingFwd { bool active = false; uint32_t slab = 0; };
 static thread_local PendingFwd g_pending;
 static thread_local bool g_async_request = false;
+static thread_local bool g_raw_activations = false;       // set by igs_refine_step around its forward
+// where the last slab-binned forward left its device-side validity words (refine step guards)
+struct LastFwd { const uint32_t* overflow = nullptr; const uint32_t* prefilter = nullptr; };
+static thread_local LastFwd g_last_fwd;
 
 static int forward_impl(
     void* stream,
@@ -104,7 +114,7 @@ static int forward_impl(
     float tan_fovx, float tan_fovy, float kernel_size, int prefiltered,
     float* out_color, float* out_coord, float* out_mcoord, float* out_depth, float* out_mdepth, float* out_alpha,
     float* out_normal, int* radii, int require_coord, int require_depth, int debug,
-    bool force_radix, uint64_t min_capacity, bool want_big)
+    bool force_radix, uint64_t min_capacity)
 {
     hipStream_t s = (hipStream_t)stream;
     if (P < 0 || width <= 0 || height <= 0) return fail(IGS_RAST_E_INVALID, "igs_rast_forward: bad sizes");
@@ -147,52 +157,52 @@ static int forward_impl(
     fp.fy = height / (2.0f * tan_fovy); fp.fx = width / (2.0f * tan_fovx);       // rasterizer_impl.cu:288-289
     fp.kernel_size = kernel_size; fp.prefiltered = prefiltered;
     fp.view = viewmatrix; fp.proj = projmatrix; fp.campos = cam_pos;
+    fp.raw_activations = g_raw_activations ? 1 : 0;
+    g_last_fwd = LastFwd();
 
     const size_t counter_bytes = (COUNTER_SHARDS + 1) * COUNTER_SHARD_STRIDE * 4;
     uint32_t* ranges = (uint32_t*)(ibase + IL.ranges);
     uint32_t* point_list = nullptr;
     uint32_t R = 0;
     bool bucket_pending = false;            // bucket path: the host has not looked at R yet
-    uint32_t bucket_cap = 0; bool bucket_big = false;
+    uint32_t bucket_cap = 0;                // slab size of this call
+    const uint32_t* slab_stats = nullptr;
 
     if (!force_radix) {
-        // ---------------- bucket binning (default): nothing below needs the host to know R ----------------
+        // ---------------- slab binning (default): nothing below needs the host to know R ----------------
         uint32_t* tile_count = (uint32_t*)(ibase + IL.tile_count);
-        uint32_t* cursor = (uint32_t*)(ibase + IL.cursor);
         uint32_t* stats = (uint32_t*)(ibase + IL.stats);
-        HIP_TRY(hipMemsetAsync(counters, 0, counter_bytes, s), "memset counters");
-        HIP_TRY(hipMemsetAsync(tile_count, 0, IL.stats - IL.tile_count, s), "memset tile counters");   // tile_count + cursor
-        prof_mark(s, ST_GAP);
-        HIP_TRY(launch_preprocess_fwd(s, fp, rec, tiles, nullptr, nullptr, radii, counters, nullptr, 0, tile_count), "preprocess_fwd launch");
-        DBG_SYNC("preprocess_fwd");
-        prof_mark(s, ST_PREPROCESS);
-        HIP_TRY(launch_tile_scan(s, (uint32_t)Tn, tile_count, ranges, stats), "tile_scan launch");
-        DBG_SYNC("tile_scan");
-        prof_mark(s, ST_SCAN);
-        HIP_TRY(hipMemcpyAsync(g_slot.pinned, stats, 8, hipMemcpyDeviceToHost, s), "memcpy stats");
-        HIP_TRY(hipMemcpyAsync(g_slot.pinned + 2, counters + 1, 4, hipMemcpyDeviceToHost, s), "memcpy prefilter flag");
-        HIP_TRY(hipEventRecord(g_slot.ev, s), "event record");
-        // capacity guess from the previous call on this thread (the refine loop renders similar views over and over)
-        uint64_t cap = (uint64_t)g_hint.last_R + g_hint.last_R / 4 + 4096;
-        if (cap < (uint64_t)P * 4) cap = (uint64_t)P * 4;
-        if (min_capacity > cap) cap = min_capacity;
-        if (cap > 0x7FFFFFFFull) cap = 0x7FFFFFFFull;
-        bucket_cap = (uint32_t)cap;
-        bucket_big = g_hint.last_max > TILE_SORT_SMALL || want_big;
-        const BucketLayout KL(bucket_cap);
+        // slab size: sticky per thread, grown when a frame overflowed (the refine loop renders similar views over and over)
+        uint64_t slab = g_hint.slab ? g_hint.slab : 1024;
+        if (min_capacity > slab) slab = (min_capacity + 255) / 256 * 256;
+        if (slab > TILE_SORT_BIG) slab = TILE_SORT_BIG;
+        if (Tn * slab > 0x7FFFFFFFull || Tn * slab * 12 > SLAB_MAX_BYTES) {
+            // slabs would not fit the 32-bit list positions / a sane scratch size: global sort instead
+            return forward_impl(stream, geometry_buffer, geometry_user, binning_buffer, binning_user, image_buffer, image_user, P, D, M,
+                                background, width, height, means3D, shs, colors_precomp, opacities, scales, scale_modifier, rotations,
+                                cov3D_precomp, viewmatrix, projmatrix, cam_pos, tan_fovx, tan_fovy, kernel_size, prefiltered, out_color,
+                                out_coord, out_mcoord, out_depth, out_mdepth, out_alpha, out_normal, radii, require_coord, require_depth,
+                                debug, true, 0);
+        }
+        bucket_cap = (uint32_t)slab;
+        const SlabLayout KL(Tn, slab);
         char* bbase = binning_buffer(binning_user, KL.total);
         if (!bbase) return fail(IGS_RAST_E_ALLOC, "binning buffer callback returned NULL");
         bbase = align_ptr(bbase);
         point_list = (uint32_t*)(bbase + KL.point_list);
-        uint32_t* bkey = (uint32_t*)(bbase + KL.bkey);
-        uint32_t* bid = (uint32_t*)(bbase + KL.bid);
+        uint64_t* pairs = (uint64_t*)(bbase + KL.pairs);
+        counters = (uint32_t*)(ibase + IL.counters);
+        HIP_TRY(hipMemsetAsync(tile_count, 0, IL.zero_end - IL.tile_count, s), "memset tile counters");   // tile_count + stats + counters
         prof_mark(s, ST_GAP);
-        HIP_TRY(launch_bucket_scatter(s, P, gx, gy, tiles, rec, radii, ranges, cursor, bkey, bid, bucket_cap), "bucket_scatter launch");
-        DBG_SYNC("bucket_scatter");
-        prof_mark(s, ST_EMIT);
-        HIP_TRY(launch_tile_sort(s, (uint32_t)Tn, ranges, bkey, bid, point_list, bucket_cap, bucket_big), "tile_sort launch");
+        HIP_TRY(launch_preprocess_fwd(s, fp, rec, tiles, nullptr, nullptr, radii, counters, nullptr, 0, tile_count, pairs, bucket_cap),
+                "preprocess_fwd launch");
+        DBG_SYNC("preprocess_fwd");
+        prof_mark(s, ST_PREPROCESS);
+        HIP_TRY(launch_tile_sort(s, (uint32_t)Tn, tile_count, pairs, point_list, ranges, bucket_cap, stats, counters), "tile_sort launch");
         DBG_SYNC("tile_sort");
         prof_mark(s, ST_TILE_SORT);
+        slab_stats = stats;
+        g_last_fwd.overflow = stats + 1; g_last_fwd.prefilter = counters + 1;
         bucket_pending = true;
     } else {
         // ---------------- global radix binning (fallback for tiles denser than TILE_SORT_BIG) ----------------
@@ -201,7 +211,7 @@ static int forward_impl(
         sort_geometry((uint32_t)P, &dnb, &dper);
         HIP_TRY(hipMemsetAsync(ghist, 0, (size_t)256 * SORT_MAX_BLOCKS * 4, s), "memset depth-sort histogram 0");
         prof_mark(s, ST_GAP);
-        HIP_TRY(launch_preprocess_fwd(s, fp, rec, tiles, keys_a, vals_a, radii, counters, ghist, dper, nullptr), "preprocess_fwd launch");
+        HIP_TRY(launch_preprocess_fwd(s, fp, rec, tiles, keys_a, vals_a, radii, counters, ghist, dper, nullptr, nullptr, 0), "preprocess_fwd launch");
         DBG_SYNC("preprocess_fwd");
         prof_mark(s, ST_PREPROCESS);
         // instance count: read back while the depth sort runs
@@ -271,32 +281,32 @@ static int forward_impl(
     ba.n_contrib = (uint32_t*)(ibase + IL.n_contrib);
     ba.accum_coord = (float*)(ibase + IL.accum_coord); ba.accum_depth = (float*)(ibase + IL.accum_depth);
     ba.normal_length = (float*)(ibase + IL.normal_length);
-    ba.list_capacity = bucket_pending ? bucket_cap : 0xFFFFFFFFu;
-    ba.max_tile = bucket_pending ? (bucket_big ? (uint32_t)TILE_SORT_BIG : (uint32_t)TILE_SORT_SMALL) : 0xFFFFFFFFu;
+    ba.stats_src = slab_stats; ba.flag_src = counters + 1; ba.host_dst = bucket_pending ? g_slot.pinned_dev : nullptr;
     HIP_TRY(launch_blend_fwd(s, ba, require_coord != 0, require_depth != 0), "blend_fwd launch");
     DBG_SYNC("blend_fwd");
     prof_mark(s, ST_BLEND_FWD);
+    if (bucket_pending) HIP_TRY(hipEventRecord(g_slot.ev, s), "event record");
     if (bucket_pending && g_async_request) {
-        g_pending.active = true; g_pending.cap = bucket_cap; g_pending.big = bucket_big;
+        g_pending.active = true; g_pending.slab = bucket_cap;
         if (g_prof.on) g_prof.calls++;
-        return (int)(bucket_cap > 0x7FFFFFFFu ? 0x7FFFFFFF : bucket_cap);     // an upper bound usable as R by backward
+        return 0x7FFFFFFF;                       // "unknown yet": an upper bound that igs_rast_backward accepts as R
     }
     if (bucket_pending) {
         // only now does the host look at R: the whole pipeline above was enqueued without waiting for it
         HIP_TRY(hipEventSynchronize(g_slot.ev), "event sync");
-        const uint32_t R_dev = g_slot.pinned[0], max_tile = g_slot.pinned[1];
+        const uint32_t R_dev = g_slot.pinned[0], overflow = g_slot.pinned[1];
         if (g_slot.pinned[2]) return fail(IGS_RAST_E_PREFILTER, "Point is filtered although prefiltered is set. This shouldn't happen!");
         if (R_dev > 0x7FFFFFFFu) return fail(IGS_RAST_E_INVALID, "instance count overflows int");
-        g_hint.last_R = R_dev; g_hint.last_max = max_tile;
-        const uint32_t sortable = bucket_big ? (uint32_t)TILE_SORT_BIG : (uint32_t)TILE_SORT_SMALL;
-        if (R_dev > bucket_cap || max_tile > sortable) {
-            // the guess was too small (or a tile is denser than the launched sort tier): redo with what is now known
-            const bool radix = max_tile > (uint32_t)TILE_SORT_BIG;
+        if (overflow) {
+            // a tile holds more instances than its slab (overflow = the largest such tile): redo with what is now known
+            const bool radix = overflow > (uint32_t)TILE_SORT_BIG;
+            const uint64_t want = ((uint64_t)overflow + overflow / 4 + 255) / 256 * 256;
+            g_hint.slab = (uint32_t)(want > TILE_SORT_BIG ? TILE_SORT_BIG : want);
             return forward_impl(stream, geometry_buffer, geometry_user, binning_buffer, binning_user, image_buffer, image_user, P, D, M,
                                 background, width, height, means3D, shs, colors_precomp, opacities, scales, scale_modifier, rotations,
                                 cov3D_precomp, viewmatrix, projmatrix, cam_pos, tan_fovx, tan_fovy, kernel_size, prefiltered, out_color,
                                 out_coord, out_mcoord, out_depth, out_mdepth, out_alpha, out_normal, radii, require_coord, require_depth,
-                                debug, radix, (uint64_t)R_dev + 1024, max_tile > (uint32_t)TILE_SORT_SMALL);
+                                debug, radix, overflow);
         }
         R = R_dev;
     }
@@ -322,14 +332,14 @@ extern "C" int igs_rast_forward(
                         background, width, height, means3D, shs, colors_precomp, opacities, scales, scale_modifier, rotations,
                         cov3D_precomp, viewmatrix, projmatrix, cam_pos, tan_fovx, tan_fovy, kernel_size, prefiltered, out_color,
                         out_coord, out_mcoord, out_depth, out_mdepth, out_alpha, out_normal, radii, require_coord, require_depth,
-                        debug, radix, 0, false);
+                        debug, radix, 0);
 }
 
 // Asynchronous variant for callers that keep enqueueing work (the native refine step): identical to igs_rast_forward but
-// returns right after the last launch WITHOUT waiting for the instance count; the return value is the capacity of the
-// instance list (an upper bound that igs_rast_backward accepts as R).  igs_rast_forward_finish() then waits for the small
+// returns right after the last launch WITHOUT waiting for the instance count; the return value is INT_MAX ("not known
+// yet", which igs_rast_backward accepts as R).  igs_rast_forward_finish() then waits for the small
 // read-back (which completed right after the tile scan, long before the blend) and returns the true num_rendered, or
-// IGS_RAST_E_RETRY if the guessed capacity / sort tier was too small: everything enqueued since must then be discarded and
+// IGS_RAST_E_RETRY if a tile overflowed its instance slab: everything enqueued since must then be discarded and
 // the frame redone with igs_rast_forward (the hints are updated, so it will fit).
 extern "C" int igs_rast_forward_async(
     void* stream,
@@ -349,7 +359,7 @@ extern "C" int igs_rast_forward_async(
                                 background, width, height, means3D, shs, colors_precomp, opacities, scales, scale_modifier, rotations,
                                 cov3D_precomp, viewmatrix, projmatrix, cam_pos, tan_fovx, tan_fovy, kernel_size, prefiltered, out_color,
                                 out_coord, out_mcoord, out_depth, out_mdepth, out_alpha, out_normal, radii, require_coord, require_depth,
-                                debug, false, 0, false);
+                                debug, false, 0);
     g_async_request = false;
     return rc;
 }
@@ -358,14 +368,99 @@ extern "C" int igs_rast_forward_finish(void)
     if (!g_pending.active) return fail(IGS_RAST_E_INVALID, "igs_rast_forward_finish: no asynchronous forward pending");
     g_pending.active = false;
     HIP_TRY(hipEventSynchronize(g_slot.ev), "event sync");
-    const uint32_t R_dev = g_slot.pinned[0], max_tile = g_slot.pinned[1];
+    const uint32_t R_dev = g_slot.pinned[0], overflow = g_slot.pinned[1];
     if (g_slot.pinned[2]) return fail(IGS_RAST_E_PREFILTER, "Point is filtered although prefiltered is set. This shouldn't happen!");
     if (R_dev > 0x7FFFFFFFu) return fail(IGS_RAST_E_INVALID, "instance count overflows int");
-    g_hint.last_R = R_dev; g_hint.last_max = max_tile;
-    const uint32_t sortable = g_pending.big ? (uint32_t)TILE_SORT_BIG : (uint32_t)TILE_SORT_SMALL;
-    if (R_dev > g_pending.cap || max_tile > sortable) return fail(IGS_RAST_E_RETRY, "instance-list capacity guess too small: redo the frame");
+    if (overflow) {
+        const uint64_t want = ((uint64_t)overflow + overflow / 4 + 255) / 256 * 256;
+        g_hint.slab = (uint32_t)(want > TILE_SORT_BIG ? TILE_SORT_BIG : want);       // igs_rast_forward falls back further if needed
+        return fail(IGS_RAST_E_RETRY, "a tile overflowed its instance slab: redo the frame");
+    }
     if (g_prof.on) g_prof.r_sum += (double)R_dev;
     return (int)R_dev;
+}
+
+extern "C" void igs_rast_set_slab_hint(unsigned slots_per_tile) { g_hint.slab = slots_per_tile > TILE_SORT_BIG ? TILE_SORT_BIG : slots_per_tile; }
+extern "C" unsigned igs_rast_get_slab_hint(void) { return g_hint.slab; }
+
+// l1_gt != NULL: L1 loss fused into the blend backward (dL_dpix ignored); fuse != NULL: activation backward + Adam fused into
+// the per-Gaussian backward (no gradient outputs except the optional dL_dmean2D).
+static int backward_impl(
+    void* stream, int P, int D, int M, int R, const float* background, int width, int height,
+    const float* means3D, const float* shs, const float* colors_precomp, const float* alphas,
+    const float* scales, float scale_modifier, const float* rotations, const float* cov3D_precomp,
+    const float* viewmatrix, const float* projmatrix, const float* campos,
+    float tan_fovx, float tan_fovy, float kernel_size, const int* radii, const float* normalmap,
+    const char* geom_buffer, const char* binning_buffer, const char* image_buffer,
+    const float* dL_dpix, const float* dL_dpix_coord, const float* dL_dpix_mcoord, const float* dL_dpix_depth,
+    const float* dL_dpix_mdepth, const float* dL_dalphas, const float* dL_dpixel_normals,
+    void* workspace,
+    float* dL_dmean2D, float* dL_dcolor, float* dL_dopacity, float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh,
+    float* dL_dscale, float* dL_drot, int require_coord, int require_depth, int debug,
+    const float* l1_gt, const float* l1_color, float l1_scale, const RefineFuse* fuse)
+{
+    hipStream_t s = (hipStream_t)stream;
+    if (P < 0 || R < 0 || width <= 0 || height <= 0) return fail(IGS_RAST_E_INVALID, "igs_rast_backward: bad sizes");
+    if (P == 0) return 0;                                       // rasterize_points.cu:195
+    if (!geom_buffer || !image_buffer || (!binning_buffer && R > 0) || !workspace)
+        return fail(IGS_RAST_E_INVALID, "igs_rast_backward: NULL scratch buffer");
+    if (!means3D || !alphas || !viewmatrix || !projmatrix || !campos || !background || !radii || !normalmap)
+        return fail(IGS_RAST_E_INVALID, "igs_rast_backward: NULL required input");
+    // any of the seven upstream gradients may be NULL = "all zeros" (an output that did not take part in the loss)
+    if (!fuse && (!dL_dmean2D || !dL_dcolor || !dL_dopacity || !dL_dmean3D || !dL_dcov3D || !dL_dscale || !dL_drot || (M > 0 && !dL_dsh)))
+        return fail(IGS_RAST_E_INVALID, "igs_rast_backward: NULL output");
+
+    const int gx = (width + TILE - 1) / TILE, gy = (height + TILE - 1) / TILE;
+    const size_t Tn = (size_t)gx * gy, HW = (size_t)width * height;
+    const GeomLayout GL(P);
+    const ImgLayout IL(HW, Tn);
+    const BinLayout BL(R);
+    const char* gbase = align_ptr(geom_buffer);
+    const char* ibase = align_ptr(image_buffer);
+    const char* bbase = binning_buffer ? align_ptr(binning_buffer) : nullptr;
+    float* gacc = (float*)align_ptr((const char*)workspace);
+    const float fy = height / (2.0f * tan_fovy), fx = width / (2.0f * tan_fovx);
+
+    prof_mark(s, ST_GAP);
+    float* loss_shards = (float*)((char*)gacc + ws_gacc_bytes(P));
+    HIP_TRY(hipMemsetAsync(gacc, 0, l1_gt ? ws_gacc_bytes(P) + WS_LOSS_BYTES : (size_t)P * GACC_F * 4, s), "memset gacc");
+    prof_mark(s, ST_MEMSET);
+    BlendBwdArgs ba;
+    ba.W = width; ba.H = height; ba.gx = gx; ba.gy = gy; ba.fx = fx; ba.fy = fy; ba.bg = background;
+    ba.ranges = (const uint32_t*)(ibase + IL.ranges);
+    ba.point_list = bbase ? (const uint32_t*)(bbase + BL.point_list) : nullptr;
+    ba.rec = (const float*)(gbase + GL.rec); ba.colors_precomp = colors_precomp;
+    ba.alphas = alphas; ba.normalmap = normalmap;
+    ba.accum_coord = (const float*)(ibase + IL.accum_coord); ba.accum_depth = (const float*)(ibase + IL.accum_depth);
+    ba.normal_length = (const float*)(ibase + IL.normal_length); ba.n_contrib = (const uint32_t*)(ibase + IL.n_contrib);
+    ba.dL_dpix = dL_dpix; ba.dL_dcoord = dL_dpix_coord; ba.dL_dmcoord = dL_dpix_mcoord; ba.dL_ddepth = dL_dpix_depth;
+    ba.dL_dmdepth = dL_dpix_mdepth; ba.dL_dalpha = dL_dalphas; ba.dL_dnormal = dL_dpixel_normals;
+    ba.gacc = gacc;
+    ba.l1_gt = l1_gt; ba.l1_color = l1_color; ba.l1_scale = l1_scale; ba.l1_loss = loss_shards;
+    if (R > 0) {
+        HIP_TRY(launch_blend_bwd(s, ba, require_coord != 0, require_depth != 0), "blend_bwd launch");
+        DBG_SYNC("blend_bwd");
+        prof_mark(s, ST_BLEND_BWD);
+    }
+    GeomBwdArgs ga;
+    ga.P = P; ga.D = D; ga.M = shs ? M : 0; ga.W = width; ga.H = height;
+    ga.means3D = means3D; ga.shs = shs; ga.scales = scales; ga.rotations = rotations; ga.cov3D_precomp = cov3D_precomp;
+    ga.radii = radii; ga.scale_modifier = scale_modifier; ga.tan_fovx = tan_fovx; ga.tan_fovy = tan_fovy;
+    ga.fx = fx; ga.fy = fy; ga.kernel_size = kernel_size;
+    ga.view = viewmatrix; ga.proj = projmatrix; ga.campos = campos;
+    ga.rec = ba.rec; ga.gacc = gacc;
+    ga.dL_dmean2D = dL_dmean2D; ga.dL_dcolor = dL_dcolor; ga.dL_dopacity = dL_dopacity; ga.dL_dmean3D = dL_dmean3D;
+    ga.dL_dcov3D = dL_dcov3D; ga.dL_dsh = dL_dsh; ga.dL_dscale = dL_dscale; ga.dL_drot = dL_drot;
+    if (fuse) {
+        RefineFuse f = *fuse;
+        f.loss_shards = loss_shards;
+        HIP_TRY(launch_geom_bwd_adam(s, ga, f), "geom_bwd_adam launch");
+    } else {
+        HIP_TRY(launch_geom_bwd(s, ga), "geom_bwd launch");
+    }
+    DBG_SYNC("geom_bwd");
+    prof_mark(s, ST_GEOM_BWD);
+    return 0;
 }
 
 extern "C" int igs_rast_backward(
@@ -381,60 +476,68 @@ extern "C" int igs_rast_backward(
     float* dL_dmean2D, float* dL_dcolor, float* dL_dopacity, float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh,
     float* dL_dscale, float* dL_drot, int require_coord, int require_depth, int debug)
 {
-    hipStream_t s = (hipStream_t)stream;
-    if (P < 0 || R < 0 || width <= 0 || height <= 0) return fail(IGS_RAST_E_INVALID, "igs_rast_backward: bad sizes");
-    if (P == 0) return 0;                                       // rasterize_points.cu:195
-    if (!geom_buffer || !image_buffer || (!binning_buffer && R > 0) || !workspace)
-        return fail(IGS_RAST_E_INVALID, "igs_rast_backward: NULL scratch buffer");
-    if (!means3D || !alphas || !viewmatrix || !projmatrix || !campos || !background || !radii || !normalmap)
-        return fail(IGS_RAST_E_INVALID, "igs_rast_backward: NULL required input");
-    // any of the seven upstream gradients may be NULL = "all zeros" (an output that did not take part in the loss)
-    if (!dL_dmean2D || !dL_dcolor || !dL_dopacity || !dL_dmean3D || !dL_dcov3D || !dL_dscale || !dL_drot || (M > 0 && !dL_dsh))
-        return fail(IGS_RAST_E_INVALID, "igs_rast_backward: NULL output");
+    return backward_impl(stream, P, D, M, R, background, width, height, means3D, shs, colors_precomp, alphas, scales, scale_modifier,
+                         rotations, cov3D_precomp, viewmatrix, projmatrix, campos, tan_fovx, tan_fovy, kernel_size, radii, normalmap,
+                         geom_buffer, binning_buffer, image_buffer, dL_dpix, dL_dpix_coord, dL_dpix_mcoord, dL_dpix_depth,
+                         dL_dpix_mdepth, dL_dalphas, dL_dpixel_normals, workspace, dL_dmean2D, dL_dcolor, dL_dopacity, dL_dmean3D,
+                         dL_dcov3D, dL_dsh, dL_dscale, dL_drot, require_coord, require_depth, debug, nullptr, nullptr, 0.f, nullptr);
+}
 
-    const int gx = (width + TILE - 1) / TILE, gy = (height + TILE - 1) / TILE;
-    const size_t Tn = (size_t)gx * gy, HW = (size_t)width * height;
-    const GeomLayout GL(P);
-    const ImgLayout IL(HW, Tn);
-    const BinLayout BL(R);
-    const char* gbase = align_ptr(geom_buffer);
-    const char* ibase = align_ptr(image_buffer);
-    const char* bbase = binning_buffer ? align_ptr(binning_buffer) : nullptr;
-    float* gacc = (float*)align_ptr((const char*)workspace);
-    const float fy = height / (2.0f * tan_fovy), fx = width / (2.0f * tan_fovx);
+// ---------------------------------------------------------------------------------------------------------------------
+// One refine iteration on one view, single GPU (infer_batch.py:279-324 with the L1 loss): activations -> render -> L1 ->
+// backward -> Adam, 7 launches, no gradient array in HBM, no host wait before the last launch is enqueued.
+// ---------------------------------------------------------------------------------------------------------------------
+struct ScratchCapture { igs_rast_alloc_fn fn; void* user; char* last; };
+static char* capture_alloc(void* user, size_t n) { ScratchCapture* c = (ScratchCapture*)user; c->last = c->fn(c->user, n); return c->last; }
 
-    prof_mark(s, ST_GAP);
-    HIP_TRY(hipMemsetAsync(gacc, 0, (size_t)P * GACC_F * 4, s), "memset gacc");
-    prof_mark(s, ST_MEMSET);
-    BlendBwdArgs ba;
-    ba.W = width; ba.H = height; ba.gx = gx; ba.gy = gy; ba.fx = fx; ba.fy = fy; ba.bg = background;
-    ba.ranges = (const uint32_t*)(ibase + IL.ranges);
-    ba.point_list = bbase ? (const uint32_t*)(bbase + BL.point_list) : nullptr;
-    ba.rec = (const float*)(gbase + GL.rec); ba.colors_precomp = colors_precomp;
-    ba.alphas = alphas; ba.normalmap = normalmap;
-    ba.accum_coord = (const float*)(ibase + IL.accum_coord); ba.accum_depth = (const float*)(ibase + IL.accum_depth);
-    ba.normal_length = (const float*)(ibase + IL.normal_length); ba.n_contrib = (const uint32_t*)(ibase + IL.n_contrib);
-    ba.dL_dpix = dL_dpix; ba.dL_dcoord = dL_dpix_coord; ba.dL_dmcoord = dL_dpix_mcoord; ba.dL_ddepth = dL_dpix_depth;
-    ba.dL_dmdepth = dL_dpix_mdepth; ba.dL_dalpha = dL_dalphas; ba.dL_dnormal = dL_dpixel_normals;
-    ba.gacc = gacc; ba.list_capacity = (uint32_t)R;
-    if (R > 0) {
-        HIP_TRY(launch_blend_bwd(s, ba, require_coord != 0, require_depth != 0), "blend_bwd launch");
-        DBG_SYNC("blend_bwd");
-        prof_mark(s, ST_BLEND_BWD);
+extern "C" int igs_refine_step(const igs_refine_step_args* a)
+{
+    if (!a) return fail(IGS_RAST_E_INVALID, "igs_refine_step: NULL args");
+    if (a->P <= 0 || a->M <= 0 || a->width <= 0 || a->height <= 0 || a->step < 1)
+        return fail(IGS_RAST_E_INVALID, "igs_refine_step: bad sizes");
+    if (!a->param || !a->exp_avg || !a->exp_avg_sq || !a->gt || !a->out_images || !a->radii || !a->workspace || !a->background)
+        return fail(IGS_RAST_E_INVALID, "igs_refine_step: NULL pointer");
+    const size_t HW = (size_t)a->width * a->height;
+    float* img = a->out_images;
+    float *color = img, *coord = img + 3 * HW, *mcoord = img + 6 * HW, *depth = img + 9 * HW, *mdepth = img + 10 * HW,
+          *alpha = img + 11 * HW, *normal = img + 12 * HW;
+    const float* xyz = a->param + a->off_xyz; const float* shs = a->param + a->off_sh;
+    const float* opac = a->param + a->off_opacity; const float* scal = a->param + a->off_scale; const float* rotn = a->param + a->off_rot;
+    ScratchCapture cg{ a->geometry_buffer, a->geometry_user, nullptr }, cb{ a->binning_buffer, a->binning_user, nullptr },
+                   ci{ a->image_buffer, a->image_user, nullptr };
+    const double bc1 = 1.0 - pow((double)a->beta1, (double)a->step), bc2 = 1.0 - pow((double)a->beta2, (double)a->step);
+    RefineFuse f;
+    f.param = a->param; f.exp_avg = a->exp_avg; f.exp_avg_sq = a->exp_avg_sq;
+    f.off_xyz = a->off_xyz; f.off_rot = a->off_rot; f.off_sh = a->off_sh; f.off_opacity = a->off_opacity; f.off_scale = a->off_scale;
+    f.lr_xyz = (float)(a->lr_xyz / bc1); f.lr_rot = (float)(a->lr_rot / bc1); f.lr_sh = (float)(a->lr_sh / bc1);
+    f.lr_opacity = (float)(a->lr_opacity / bc1); f.lr_scale = (float)(a->lr_scale / bc1);
+    f.b1 = a->beta1; f.b2 = a->beta2; f.eps = a->eps; f.inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
+    f.loss_shards = nullptr; f.loss_out = a->loss_out; f.loss_scale = a->loss_weight / (float)(3 * HW);
+    const float l1_scale = a->loss_weight / (float)(3 * HW);
+
+    for (int attempt = 0; attempt < 2; attempt++) {
+        g_pending.active = false;
+        g_async_request = attempt == 0;            // second attempt: synchronous forward, which sorts out its scratch sizes itself
+        g_raw_activations = true;
+        const int R = forward_impl(a->stream, capture_alloc, &cg, capture_alloc, &cb, capture_alloc, &ci, a->P, a->D, a->M, a->background,
+                                   a->width, a->height, xyz, shs, nullptr, opac, scal, 1.0f, rotn, nullptr, a->viewmatrix, a->projmatrix,
+                                   a->cam_pos, a->tan_fovx, a->tan_fovy, 0.0f, 0, color, coord, mcoord, depth, mdepth, alpha, normal,
+                                   a->radii, a->require_coord, a->require_depth, 0, false, 0);
+        g_async_request = false; g_raw_activations = false;
+        if (R < 0) return R;
+        f.guard_overflow = g_last_fwd.overflow; f.guard_prefilter = g_last_fwd.prefilter;
+        const int rc = backward_impl(a->stream, a->P, a->D, a->M, R, a->background, a->width, a->height, xyz, shs, nullptr, alpha, scal, 1.0f,
+                                     rotn, nullptr, a->viewmatrix, a->projmatrix, a->cam_pos, a->tan_fovx, a->tan_fovy, 0.0f, a->radii,
+                                     normal, cg.last, cb.last, ci.last, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
+                                     a->workspace, a->dL_dmean2D, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
+                                     a->require_coord, a->require_depth, 0, a->gt, color, l1_scale, &f);
+        if (rc < 0) return rc;
+        if (!g_pending.active) return R;           // synchronous forward: R is already the true count
+        const int Rt = igs_rast_forward_finish();
+        if (Rt != IGS_RAST_E_RETRY) return Rt;     // the true count, or an error
+        // a tile overflowed its slab: the guarded update kernel has done nothing; go again with the enlarged slabs
     }
-    GeomBwdArgs ga;
-    ga.P = P; ga.D = D; ga.M = shs ? M : 0; ga.W = width; ga.H = height;
-    ga.means3D = means3D; ga.shs = shs; ga.scales = scales; ga.rotations = rotations; ga.cov3D_precomp = cov3D_precomp;
-    ga.radii = radii; ga.scale_modifier = scale_modifier; ga.tan_fovx = tan_fovx; ga.tan_fovy = tan_fovy;
-    ga.fx = fx; ga.fy = fy; ga.kernel_size = kernel_size;
-    ga.view = viewmatrix; ga.proj = projmatrix; ga.campos = campos;
-    ga.rec = ba.rec; ga.gacc = gacc;
-    ga.dL_dmean2D = dL_dmean2D; ga.dL_dcolor = dL_dcolor; ga.dL_dopacity = dL_dopacity; ga.dL_dmean3D = dL_dmean3D;
-    ga.dL_dcov3D = dL_dcov3D; ga.dL_dsh = dL_dsh; ga.dL_dscale = dL_dscale; ga.dL_drot = dL_drot;
-    HIP_TRY(launch_geom_bwd(s, ga), "geom_bwd launch");
-    DBG_SYNC("geom_bwd");
-    prof_mark(s, ST_GEOM_BWD);
-    return 0;
+    return fail(IGS_RAST_E_INVALID, "igs_refine_step: internal retry failure");
 }
 
 extern "C" int igs_rast_mark_visible(void* stream, int P, const float* means3D, const float* viewmatrix,
@@ -461,11 +564,13 @@ extern "C" int igs_rast_debug_dump(void* stream, int P, int R, int width, int he
         if (rec32) HIP_TRY(hipMemcpyAsync(rec32, g + GL.rec, (size_t)P * REC_F * 4, hipMemcpyDeviceToDevice, s), "dump rec");
         if (tiles) HIP_TRY(hipMemcpyAsync(tiles, g + GL.tiles, (size_t)P * 4, hipMemcpyDeviceToDevice, s), "dump tiles");
     }
-    if (binning_buffer && R > 0 && point_list)
-        HIP_TRY(hipMemcpyAsync(point_list, align_ptr(binning_buffer) + BL.point_list, (size_t)R * 4, hipMemcpyDeviceToDevice, s), "dump point_list");
     if (image_buffer) {
         const char* i = align_ptr(image_buffer);
-        if (ranges) HIP_TRY(hipMemcpyAsync(ranges, i + IL.ranges, Tn * 8, hipMemcpyDeviceToDevice, s), "dump ranges");
+        // per-tile lists are gathered into the reference's compact layout (identical already on the global-sort path)
+        if (ranges)
+            HIP_TRY(launch_compact_lists(s, (uint32_t)Tn, (const uint32_t*)(i + IL.ranges),
+                                         binning_buffer ? (const uint32_t*)(align_ptr(binning_buffer) + BL.point_list) : nullptr, ranges,
+                                         point_list, (uint32_t)(R > 0 ? R : 0)), "dump lists");
         if (n_contrib) HIP_TRY(hipMemcpyAsync(n_contrib, i + IL.n_contrib, HW * 8, hipMemcpyDeviceToDevice, s), "dump n_contrib");
     }
     return 0;

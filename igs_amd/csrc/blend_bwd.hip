@@ -52,17 +52,32 @@ blend_bwd_kernel(const BlendBwdArgs a)
 
     const uint2 range = ((const uint2*)a.ranges)[tile];
     // clamped to the tile's list length: a corrupt image buffer must not turn into an out-of-bounds gather
-    int last_contributor = (inside && range.y <= a.list_capacity) ? (int)min(a.n_contrib[pix], range.y - range.x) : 0;
+    int last_contributor = inside ? (int)min(a.n_contrib[pix], range.y - range.x) : 0;
     const uint32_t max_contributor = inside ? a.n_contrib[pix + HW] : 0u;
 
     // ---- per-pixel upstream gradients (backward.cu:732-781); zero for pixels nothing was blended into, whose
     //      normalisations would otherwise be 0/0 (the reference never consumes those values either)
     float gp0 = 0, gp1 = 0, gp2 = 0, g_alpha = 0, T_final = 0, bg_dot = 0;
+    if (a.l1_gt) {
+        // fused L1 (loss_utils.py:17 l1_loss + its backward): every pixel of the image counts towards the loss value
+        float acc = 0.f;
+        if (inside) {
+            const float d0 = a.l1_color[pix] - a.l1_gt[pix], d1 = a.l1_color[HW + pix] - a.l1_gt[HW + pix];
+            const float d2 = a.l1_color[2 * HW + pix] - a.l1_gt[2 * HW + pix];
+            acc = fabsf(d0) + fabsf(d1) + fabsf(d2);
+            gp0 = d0 > 0.f ? a.l1_scale : (d0 < 0.f ? -a.l1_scale : 0.f);
+            gp1 = d1 > 0.f ? a.l1_scale : (d1 < 0.f ? -a.l1_scale : 0.f);
+            gp2 = d2 > 0.f ? a.l1_scale : (d2 < 0.f ? -a.l1_scale : 0.f);
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+        if (lane == 0 && acc != 0.f) atomicAdd(&a.l1_loss[16 * ((blockIdx.x * 4 + wid) & 63)], acc);
+    }
     float gc0 = 0, gc1 = 0, gc2 = 0, gm0 = 0, gm1 = 0, gm2 = 0, g_t = 0, g_mt = 0, gn0 = 0, gn1 = 0, gn2 = 0;
     if (last_contributor > 0) {
         const float w_final = a.alphas[pix];
         T_final = 1.0f - w_final;
-        if (a.dL_dpix) { gp0 = a.dL_dpix[pix]; gp1 = a.dL_dpix[HW + pix]; gp2 = a.dL_dpix[2 * HW + pix]; }
+        if (a.dL_dpix && !a.l1_gt) { gp0 = a.dL_dpix[pix]; gp1 = a.dL_dpix[HW + pix]; gp2 = a.dL_dpix[2 * HW + pix]; }
         if (a.dL_dalpha) g_alpha = a.dL_dalpha[pix];
         bg_dot = a.bg[0] * gp0 + a.bg[1] * gp1 + a.bg[2] * gp2;
         if constexpr (GEO) {

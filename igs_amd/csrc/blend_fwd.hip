@@ -21,6 +21,10 @@ blend_fwd_kernel(const BlendFwdArgs a)
     __shared__ uint64_t quad_bits[4][4];                // [quad][staging wave]
     __shared__ int wave_done[4];
 
+    if (blockIdx.x == 0 && threadIdx.x == 0 && a.host_dst) {
+        a.host_dst[0] = a.stats_src[0]; a.host_dst[1] = a.stats_src[1]; a.host_dst[2] = a.flag_src[0];
+        __threadfence_system();
+    }
     uint32_t tile;
     if (!tile_for_block(blockIdx.x, a.gx, a.gy, tile)) return;
     const uint32_t tx = tile % a.gx, ty = tile / a.gx;
@@ -32,8 +36,7 @@ blend_fwd_kernel(const BlendFwdArgs a)
     const float tile_x0 = (float)(tx * TILE), tile_y0 = (float)(ty * TILE);
 
     const uint2 range = ((const uint2*)a.ranges)[tile];
-    int n = (int)(range.y - range.x);
-    if (range.y > a.list_capacity || (uint32_t)n > a.max_tile) n = 0;      // list not valid (see BlendFwdArgs): frame will be redone
+    const int n = (int)(range.y - range.x);      // (a tile that overflowed its slab has an empty range; the frame is then redone)
     const int rounds = (n + CHUNK - 1) / CHUNK;
 
     bool done = !inside;

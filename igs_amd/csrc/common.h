@@ -72,18 +72,20 @@ struct BinLayout {
 };
 #define TILE_SORT_SMALL 2048                // tiles up to this many instances are sorted with 16 KB of LDS
 #define TILE_SORT_BIG 16384                 // ... up to this many with 128 KB; denser tiles fall back to the global radix path
-struct BucketLayout {
-    size_t point_list, bkey, bid, total;
-    __host__ explicit BucketLayout(size_t cap) {
+#define TILE_SORT_WAVE 1024                 // ... and tiles up to this many by a single wave without workgroup barriers
+// Slab binning: every tile owns a fixed-capacity slab of `slab` instance slots, so an instance can be dropped into its tile
+// with ONE atomic (slot = count++) by the kernel that creates it -- no count pass, no scan, no separate scatter.
+struct SlabLayout {
+    size_t point_list, pairs, total;
+    __host__ SlabLayout(size_t T, size_t slab) {
         size_t o = 0;
-        point_list = o; o += align_up(cap * 4, 256);   // same offset as BinLayout::point_list (backward only reads this)
-        bkey = o;       o += align_up(cap * 4, 256);
-        bid = o;        o += align_up(cap * 4, 256);
+        point_list = o; o += align_up(T * slab * 4, 256);   // sorted ids, tile t at [t*slab, t*slab+n) (same offset as BinLayout::point_list)
+        pairs = o;      o += align_up(T * slab * 8, 256);   // unsorted (depth bits << 32 | id)
         total = o + 256;
     }
 };
 struct ImgLayout {
-    size_t ranges, n_contrib, accum_coord, accum_depth, normal_length, tile_count, cursor, stats, total;
+    size_t ranges, n_contrib, accum_coord, accum_depth, normal_length, tile_count, stats, counters, zero_end, total;
     __host__ ImgLayout(size_t HW, size_t T) {
         size_t o = 0;
         ranges = o;        o += align_up(T * 8, 256);
@@ -91,9 +93,10 @@ struct ImgLayout {
         accum_coord = o;   o += align_up(HW * 12, 256);
         accum_depth = o;   o += align_up(HW * 4, 256);
         normal_length = o; o += align_up(HW * 4, 256);
-        tile_count = o;    o += align_up(T * 4, 256);      // bucket binning: instances per tile
-        cursor = o;        o += align_up(T * 4, 256);      // ... fill cursor per tile (adjacent to tile_count: one memset)
-        stats = o;         o += 256;                       // ... [0] R, [1] largest tile
+        tile_count = o;    o += align_up(T * 4, 256);      // slab binning: instances per tile (fill cursor)
+        stats = o;         o += 256;                       // ... [0] R, [1] largest tile that overflowed its slab (0 = none)
+        counters = o;      o += (COUNTER_SHARDS + 1) * COUNTER_SHARD_STRIDE * 4;   // ... instance-count shards; these three are zeroed by one fill
+        zero_end = o;
         total = o + 256;
     }
 };
@@ -105,18 +108,19 @@ struct FwdParams {
     float scale_modifier, tan_fovx, tan_fovy, fx, fy, kernel_size;
     int prefiltered;
     const float *view, *proj, *campos;      // device pointers (transposed 4x4 matrices, camera centre)
+    int raw_activations;                    // refine step: opacities / scales / rotations are the raw optimiser leaves
+                                            // (sigmoid / exp / normalize applied here: gaussian_model.py:90-127)
 };
 
 // ---- launchers (each returns hipError_t of the launch) ----
 hipError_t launch_preprocess_fwd(hipStream_t s, const FwdParams& p, float* rec, uint32_t* tiles, uint32_t* depth_keys,
                                  uint32_t* ident, int* radii, uint32_t* counters, uint32_t* hist0, uint32_t per_block,
-                                 uint32_t* tile_count);
+                                 uint32_t* tile_count, uint64_t* pairs, uint32_t slab);
 void sort_geometry(uint32_t n, uint32_t* nb, uint32_t* per);
-hipError_t launch_tile_scan(hipStream_t s, uint32_t T, const uint32_t* tile_count, uint32_t* ranges, uint32_t* stats);
-hipError_t launch_bucket_scatter(hipStream_t s, int P, int gx, int gy, const uint32_t* tiles, const float* rec, const int* radii,
-                                 const uint32_t* ranges, uint32_t* cursor, uint32_t* bkey, uint32_t* bid, uint32_t capacity);
-hipError_t launch_tile_sort(hipStream_t s, uint32_t T, const uint32_t* ranges, const uint32_t* bkey, const uint32_t* bid,
-                            uint32_t* point_list, uint32_t capacity, bool big_tiles);
+hipError_t launch_tile_sort(hipStream_t s, uint32_t T, const uint32_t* tile_count, const uint64_t* pairs, uint32_t* point_list,
+                            uint32_t* ranges, uint32_t slab, uint32_t* stats, const uint32_t* counters);
+hipError_t launch_compact_lists(hipStream_t s, uint32_t T, const uint32_t* ranges_in, const uint32_t* list_in, uint32_t* ranges_out,
+                                uint32_t* list_out, uint32_t out_capacity);
 hipError_t launch_mark_visible(hipStream_t s, int P, const float* means3D, const float* view, uint8_t* present);
 
 // stable LSD radix sort of (key,value) pairs on key bits [bit_lo, bit_hi); result ends in *out_keys/*out_vals
@@ -137,8 +141,8 @@ struct BlendFwdArgs {
     const uint32_t* ranges; const uint32_t* point_list; const float* rec; const float* colors_precomp;
     float *out_color, *out_coord, *out_mcoord, *out_depth, *out_mdepth, *out_alpha, *out_normal;
     uint32_t* n_contrib; float *accum_coord, *accum_depth, *normal_length;
-    uint32_t list_capacity, max_tile;      // optimistic binning: tiles past the capacity / too dense for the launched sort tier are
-                                           // skipped (their list is not valid); the host then redoes the frame
+    // slab binning: workgroup 0 forwards {R, overflow, prefilter flag} to host-visible memory (no copy kernels on the stream)
+    const uint32_t* stats_src; const uint32_t* flag_src; uint32_t* host_dst;
 };
 hipError_t launch_blend_fwd(hipStream_t s, const BlendFwdArgs& a, bool coord, bool depth);
 
@@ -149,7 +153,8 @@ struct BlendBwdArgs {
     const float *alphas, *normalmap, *accum_coord, *accum_depth, *normal_length; const uint32_t* n_contrib;
     const float *dL_dpix, *dL_dcoord, *dL_dmcoord, *dL_ddepth, *dL_dmdepth, *dL_dalpha, *dL_dnormal;
     float* gacc;
-    uint32_t list_capacity;                // = R handed to igs_rast_backward (an upper bound after igs_rast_forward_async)
+    // refine step: L1 loss fused in -- dL_dpix = l1_scale * sign(l1_color - l1_gt), sum |l1_color - l1_gt| -> 64 shards l1_loss[16*s]
+    const float *l1_color, *l1_gt; float l1_scale; float* l1_loss;
 };
 hipError_t launch_blend_bwd(hipStream_t s, const BlendBwdArgs& a, bool coord, bool depth);
 
@@ -163,10 +168,35 @@ struct GeomBwdArgs {
 };
 hipError_t launch_geom_bwd(hipStream_t s, const GeomBwdArgs& a);
 
+// Single-GPU refine step: the per-Gaussian backward continues through the activations (sigmoid / exp / normalize) and applies
+// the Adam update in place, so no gradient array ever reaches HBM.  means3D / shs / scales / rotations of GeomBwdArgs then
+// point at the RAW leaves inside `param`; only dL_dmean2D (may be NULL) is still written.
+struct RefineFuse {
+    float *param, *exp_avg, *exp_avg_sq;                                   // flat optimiser state
+    size_t off_xyz, off_rot, off_sh, off_opacity, off_scale;               // group offsets (floats) into the three buffers
+    float lr_xyz, lr_rot, lr_sh, lr_opacity, lr_scale;                     // lr / bias_correction1 per group
+    float b1, b2, eps, inv_sqrt_bc2;
+    const uint32_t *guard_overflow, *guard_prefilter;                      // nonzero = the frame is invalid: touch nothing
+    const float* loss_shards; float* loss_out; float loss_scale;           // loss_out[0] = loss_scale * sum of the 64 shards
+};
+hipError_t launch_geom_bwd_adam(hipStream_t s, const GeomBwdArgs& a, const RefineFuse& f);
+
 // ---------------------------------------------------------------------------------------------
 // device helpers
 // ---------------------------------------------------------------------------------------------
 #ifdef __HIPCC__
+// activations of the refine loop (igs/models/gaussian_model.py:90-127), shared by every kernel that applies them
+__device__ __forceinline__ float act_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
+__device__ __forceinline__ float act_exp(float x) { return expf(x); }
+__device__ __forceinline__ float act_inv_norm4(float q0, float q1, float q2, float q3) {          // F.normalize eps
+    return 1.0f / fmaxf(sqrtf(q0 * q0 + q1 * q1 + q2 * q2 + q3 * q3), 1e-12f);
+}
+// torch.optim.Adam (single-tensor form) on one scalar; lr = lr / bias_correction1
+__device__ __forceinline__ void adam_update(float& p, float& m, float& v, float g, float lr, float b1, float b2, float eps, float inv_sqrt_bc2) {
+    m = b1 * m + (1.f - b1) * g;
+    v = b2 * v + (1.f - b2) * g * g;
+    p -= lr * m / (sqrtf(v) * inv_sqrt_bc2 + eps);
+}
 struct M3 { float m[3][3]; };     // standard row-major [row][col]
 
 __device__ __forceinline__ M3 m3_mul(const M3& A, const M3& B) {

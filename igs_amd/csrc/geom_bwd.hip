@@ -72,12 +72,23 @@ __device__ __forceinline__ float3 sh_backward(int deg, int M, const float* __res
     return dnormvdv(dir_orig, dL_ddir);
 }
 
-struct GBArgs { GeomBwdArgs a; };
+struct GBArgs { GeomBwdArgs a; RefineFuse f; };
 
+template <bool FUSED>
 __global__ void __launch_bounds__(256)
 geom_bwd_kernel(const GBArgs args)
 {
     const GeomBwdArgs& a = args.a;
+    const RefineFuse& fz = args.f;
+    if constexpr (FUSED) {
+        if ((fz.guard_overflow && *fz.guard_overflow) || (fz.guard_prefilter && *fz.guard_prefilter)) return;   // frame to be redone
+        if (blockIdx.x == 0 && threadIdx.x < 64 && fz.loss_out) {
+            float v = fz.loss_shards[16 * threadIdx.x];
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+            if (threadIdx.x == 0) fz.loss_out[0] = v * fz.loss_scale;
+        }
+    }
     const int idx = blockIdx.x * 256 + threadIdx.x;
     // dL_dsh rows are staged in LDS ((3M+1)-float padded rows) and written out with coalesced stores at the end
     extern __shared__ __attribute__((aligned(16))) float dsh_lds[];
@@ -330,8 +341,13 @@ geom_bwd_kernel(const GBArgs args)
             sh_written = true;
         }
         if (a.scales) {       // computeCov3D backward (backward.cu:492-555)
-            const float3 sc = make_float3(a.scales[3 * idx], a.scales[3 * idx + 1], a.scales[3 * idx + 2]);
-            const float4 qr = make_float4(a.rotations[4 * idx], a.rotations[4 * idx + 1], a.rotations[4 * idx + 2], a.rotations[4 * idx + 3]);
+            float3 sc = make_float3(a.scales[3 * idx], a.scales[3 * idx + 1], a.scales[3 * idx + 2]);
+            float4 qr = make_float4(a.rotations[4 * idx], a.rotations[4 * idx + 1], a.rotations[4 * idx + 2], a.rotations[4 * idx + 3]);
+            if constexpr (FUSED) {                   // raw leaves -> activated values, exactly as the forward pass did
+                sc = make_float3(act_exp(sc.x), act_exp(sc.y), act_exp(sc.z));
+                const float inv = act_inv_norm4(qr.x, qr.y, qr.z, qr.w);
+                qr = make_float4(qr.x * inv, qr.y * inv, qr.z * inv, qr.w * inv);
+            }
             const float r = qr.x, x = qr.y, y = qr.z, z = qr.w;
             const M3 Rq = quat_rot(qr);
             const float s[3] = { a.scale_modifier * sc.x, a.scale_modifier * sc.y, a.scale_modifier * sc.z };
@@ -360,30 +376,80 @@ geom_bwd_kernel(const GBArgs args)
         }
     }
     if (active) {
-        a.dL_dmean2D[3 * idx] = o_m2d.x; a.dL_dmean2D[3 * idx + 1] = o_m2d.y; a.dL_dmean2D[3 * idx + 2] = o_m2d.z;
-        a.dL_dcolor[3 * idx] = o_color.x; a.dL_dcolor[3 * idx + 1] = o_color.y; a.dL_dcolor[3 * idx + 2] = o_color.z;
-        a.dL_dopacity[idx] = o_opacity;
-        a.dL_dmean3D[3 * idx] = o_mean.x; a.dL_dmean3D[3 * idx + 1] = o_mean.y; a.dL_dmean3D[3 * idx + 2] = o_mean.z;
+        if (!FUSED || a.dL_dmean2D) {
+            a.dL_dmean2D[3 * idx] = o_m2d.x; a.dL_dmean2D[3 * idx + 1] = o_m2d.y; a.dL_dmean2D[3 * idx + 2] = o_m2d.z;
+        }
+        if constexpr (!FUSED) {
+            a.dL_dcolor[3 * idx] = o_color.x; a.dL_dcolor[3 * idx + 1] = o_color.y; a.dL_dcolor[3 * idx + 2] = o_color.z;
+            a.dL_dopacity[idx] = o_opacity;
+            a.dL_dmean3D[3 * idx] = o_mean.x; a.dL_dmean3D[3 * idx + 1] = o_mean.y; a.dL_dmean3D[3 * idx + 2] = o_mean.z;
 #pragma unroll
-        for (int k = 0; k < 6; k++) a.dL_dcov3D[6 * (size_t)idx + k] = o_cov[k];
-        a.dL_dscale[3 * idx] = o_scale.x; a.dL_dscale[3 * idx + 1] = o_scale.y; a.dL_dscale[3 * idx + 2] = o_scale.z;
-        a.dL_drot[4 * idx] = o_rot.x; a.dL_drot[4 * idx + 1] = o_rot.y; a.dL_drot[4 * idx + 2] = o_rot.z; a.dL_drot[4 * idx + 3] = o_rot.w;
+            for (int k = 0; k < 6; k++) a.dL_dcov3D[6 * (size_t)idx + k] = o_cov[k];
+            a.dL_dscale[3 * idx] = o_scale.x; a.dL_dscale[3 * idx + 1] = o_scale.y; a.dL_dscale[3 * idx + 2] = o_scale.z;
+            a.dL_drot[4 * idx] = o_rot.x; a.dL_drot[4 * idx + 1] = o_rot.y; a.dL_drot[4 * idx + 2] = o_rot.z; a.dL_drot[4 * idx + 3] = o_rot.w;
+        } else {
+            // ---- activation backward (gaussian_model.py:90-127) + Adam on this Gaussian's 11 small parameters ----
+            auto upd = [&](size_t off, float g, float lr) {
+                float p = fz.param[off], m = fz.exp_avg[off], v = fz.exp_avg_sq[off];
+                adam_update(p, m, v, g, lr, fz.b1, fz.b2, fz.eps, fz.inv_sqrt_bc2);
+                fz.param[off] = p; fz.exp_avg[off] = m; fz.exp_avg_sq[off] = v;
+            };
+            const float g_xyz[3] = { o_mean.x, o_mean.y, o_mean.z };
+            const float s_op = act_sigmoid(fz.param[fz.off_opacity + idx]);
+            const float g_logit = o_opacity * s_op * (1.0f - s_op);
+            float g_ls[3], g_rot[4];
+            {
+                const float* ls = fz.param + fz.off_scale + 3 * (size_t)idx;
+                const float go[3] = { o_scale.x, o_scale.y, o_scale.z };
+#pragma unroll
+                for (int k = 0; k < 3; k++) g_ls[k] = go[k] * act_exp(ls[k]);
+                const float* rq = fz.param + fz.off_rot + 4 * (size_t)idx;
+                const float q0 = rq[0], q1 = rq[1], q2 = rq[2], q3 = rq[3];
+                const float nrm = fmaxf(sqrtf(q0 * q0 + q1 * q1 + q2 * q2 + q3 * q3), 1e-12f);
+                const float inv = 1.0f / nrm;
+                const float n0 = q0 * inv, n1 = q1 * inv, n2 = q2 * inv, n3 = q3 * inv;
+                const float dt = n0 * o_rot.x + n1 * o_rot.y + n2 * o_rot.z + n3 * o_rot.w;
+                g_rot[0] = (o_rot.x - n0 * dt) * inv; g_rot[1] = (o_rot.y - n1 * dt) * inv;
+                g_rot[2] = (o_rot.z - n2 * dt) * inv; g_rot[3] = (o_rot.w - n3 * dt) * inv;
+            }
+#pragma unroll
+            for (int k = 0; k < 3; k++) upd(fz.off_xyz + 3 * (size_t)idx + k, g_xyz[k], fz.lr_xyz);
+#pragma unroll
+            for (int k = 0; k < 4; k++) upd(fz.off_rot + 4 * (size_t)idx + k, g_rot[k], fz.lr_rot);
+            upd(fz.off_opacity + idx, g_logit, fz.lr_opacity);
+#pragma unroll
+            for (int k = 0; k < 3; k++) upd(fz.off_scale + 3 * (size_t)idx + k, g_ls[k], fz.lr_scale);
+        }
         if (dsh && !sh_written) for (int k = 0; k < F; k++) dsh[k] = 0.f;
     }
     if (a.M) {
         __syncthreads();
         const int g0 = blockIdx.x * 256;
         const int ng = min(256, a.P - g0);
-        float* dst = a.dL_dsh + (size_t)g0 * F;
         const int total = ng * F;
-        if (((F & 3) == 0) && ((((uintptr_t)dst) & 15) == 0)) {
+        float* dst = FUSED ? fz.param + fz.off_sh + (size_t)g0 * F : a.dL_dsh + (size_t)g0 * F;
+        float* dst_m = FUSED ? fz.exp_avg + fz.off_sh + (size_t)g0 * F : nullptr;
+        float* dst_v = FUSED ? fz.exp_avg_sq + fz.off_sh + (size_t)g0 * F : nullptr;
+        bool aligned = ((F & 3) == 0) && ((((uintptr_t)dst) & 15) == 0);
+        if constexpr (FUSED) aligned = aligned && (((((uintptr_t)dst_m) | ((uintptr_t)dst_v)) & 15) == 0);
+        if (aligned) {
             const int total4 = total >> 2;
             int f = (int)threadIdx.x * 4;
             int g = f / F, k = f - g * F;
             const int dg = 1024 / F, dk = 1024 - dg * F;
             for (int i = threadIdx.x; i < total4; i += 256) {
                 const float* sp = dsh_lds + g * FS + k;
-                ((float4*)dst)[i] = make_float4(sp[0], sp[1], sp[2], sp[3]);
+                if constexpr (FUSED) {
+                    // Adam on the SH coefficients of the workgroup's 256 Gaussians: one contiguous, coalesced span of each buffer
+                    float4 P4 = ((float4*)dst)[i], M4 = ((float4*)dst_m)[i], V4 = ((float4*)dst_v)[i];
+                    adam_update(P4.x, M4.x, V4.x, sp[0], fz.lr_sh, fz.b1, fz.b2, fz.eps, fz.inv_sqrt_bc2);
+                    adam_update(P4.y, M4.y, V4.y, sp[1], fz.lr_sh, fz.b1, fz.b2, fz.eps, fz.inv_sqrt_bc2);
+                    adam_update(P4.z, M4.z, V4.z, sp[2], fz.lr_sh, fz.b1, fz.b2, fz.eps, fz.inv_sqrt_bc2);
+                    adam_update(P4.w, M4.w, V4.w, sp[3], fz.lr_sh, fz.b1, fz.b2, fz.eps, fz.inv_sqrt_bc2);
+                    ((float4*)dst)[i] = P4; ((float4*)dst_m)[i] = M4; ((float4*)dst_v)[i] = V4;
+                } else {
+                    ((float4*)dst)[i] = make_float4(sp[0], sp[1], sp[2], sp[3]);
+                }
                 g += dg; k += dk;
                 if (k >= F) { k -= F; g++; }
             }
@@ -392,7 +458,13 @@ geom_bwd_kernel(const GBArgs args)
             int g = f / F, k = f - g * F;
             const int dg = 256 / F, dk = 256 - dg * F;
             for (int i = threadIdx.x; i < total; i += 256) {
-                dst[i] = dsh_lds[g * FS + k];
+                if constexpr (FUSED) {
+                    float p = dst[i], m = dst_m[i], v = dst_v[i];
+                    adam_update(p, m, v, dsh_lds[g * FS + k], fz.lr_sh, fz.b1, fz.b2, fz.eps, fz.inv_sqrt_bc2);
+                    dst[i] = p; dst_m[i] = m; dst_v[i] = v;
+                } else {
+                    dst[i] = dsh_lds[g * FS + k];
+                }
                 g += dg; k += dk;
                 if (k >= F) { k -= F; g++; }
             }
@@ -402,8 +474,15 @@ geom_bwd_kernel(const GBArgs args)
 
 hipError_t launch_geom_bwd(hipStream_t s, const GeomBwdArgs& a)
 {
-    GBArgs g; g.a = a;
+    GBArgs g; g.a = a; g.f = RefineFuse();
     const size_t lds = a.M ? (size_t)256 * (3 * a.M + 1) * sizeof(float) : 0;
-    hipLaunchKernelGGL(geom_bwd_kernel, dim3((a.P + 255) / 256), dim3(256), lds, s, g);
+    hipLaunchKernelGGL(geom_bwd_kernel<false>, dim3((a.P + 255) / 256), dim3(256), lds, s, g);
+    return hipGetLastError();
+}
+hipError_t launch_geom_bwd_adam(hipStream_t s, const GeomBwdArgs& a, const RefineFuse& f)
+{
+    GBArgs g; g.a = a; g.f = f;
+    const size_t lds = a.M ? (size_t)256 * (3 * a.M + 1) * sizeof(float) : 0;
+    hipLaunchKernelGGL(geom_bwd_kernel<true>, dim3((a.P + 255) / 256), dim3(256), lds, s, g);
     return hipGetLastError();
 }

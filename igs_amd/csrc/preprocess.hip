@@ -41,11 +41,17 @@ struct PreArgs { FwdParams p; };
 __global__ void __launch_bounds__(256)
 preprocess_fwd_kernel(const PreArgs a, float* __restrict__ rec, uint32_t* __restrict__ tiles, uint32_t* __restrict__ depth_keys,
                       uint32_t* __restrict__ ident, int* __restrict__ radii, uint32_t* __restrict__ counters,
-                      uint32_t* __restrict__ hist0, uint32_t per_block, uint32_t* __restrict__ tile_count)
+                      uint32_t* __restrict__ hist0, uint32_t per_block, uint32_t* __restrict__ tile_count,
+                      uint64_t* __restrict__ pairs, uint32_t slab)
 {
+    __shared__ uint32_t s_incl[256], s_dkey[256];
+    __shared__ int s_x0[256], s_y0[256], s_w[256];
+    __shared__ uint32_t s_ws[4];
     const FwdParams& p = a.p;
     const int idx = blockIdx.x * 256 + threadIdx.x;
     uint32_t my_tiles = 0;
+    int rect_x0 = 0, rect_y0 = 0, rect_w = 1;
+    uint32_t my_dkey = 0;
     if (idx < p.P) {
         int radius = 0;
         uint32_t dkey = 0xFFFFFFFFu;      // culled Gaussians sort to the end (they own no instances anyway)
@@ -65,8 +71,13 @@ preprocess_fwd_kernel(const PreArgs a, float* __restrict__ rec, uint32_t* __rest
 #pragma unroll
                 for (int k = 0; k < 6; k++) cov3D[k] = p.cov3D_precomp[6 * (size_t)idx + k];
             } else {
-                const float3 s = make_float3(p.scales[3 * idx], p.scales[3 * idx + 1], p.scales[3 * idx + 2]);
-                const float4 q = make_float4(p.rotations[4 * idx], p.rotations[4 * idx + 1], p.rotations[4 * idx + 2], p.rotations[4 * idx + 3]);   // caller arrays: no alignment assumption
+                float3 s = make_float3(p.scales[3 * idx], p.scales[3 * idx + 1], p.scales[3 * idx + 2]);
+                float4 q = make_float4(p.rotations[4 * idx], p.rotations[4 * idx + 1], p.rotations[4 * idx + 2], p.rotations[4 * idx + 3]);   // caller arrays: no alignment assumption
+                if (p.raw_activations) {
+                    s = make_float3(act_exp(s.x), act_exp(s.y), act_exp(s.z));
+                    const float inv = act_inv_norm4(q.x, q.y, q.z, q.w);
+                    q = make_float4(q.x * inv, q.y * inv, q.z * inv, q.w * inv);
+                }
                 cov3d_from_scale_rot(s, p.scale_modifier, q, cov3D);
             }
             Cov2DCtx c;
@@ -126,12 +137,12 @@ preprocess_fwd_kernel(const PreArgs a, float* __restrict__ rec, uint32_t* __rest
             }
             radius = (int)my_radius;
             my_tiles = (uint32_t)((y1 - y0) * (x1 - x0));
-            if (tile_count)                                   // bucket binning: instances per tile
-                for (int ty = y0; ty < y1; ty++)
-                    for (int tx = x0; tx < x1; tx++) atomicAdd(&tile_count[ty * p.gx + tx], 1u);
+            rect_x0 = x0; rect_y0 = y0; rect_w = x1 - x0;
             dkey = __float_as_uint(p_view.z);
+            my_dkey = dkey;
             R4[0] = make_float4(pix, piy, conic.x, conic.y);
-            R4[1] = make_float4(conic.z, p.opacities[idx] * coef, rgb.x, rgb.y);
+            const float opacity = p.raw_activations ? act_sigmoid(p.opacities[idx]) : p.opacities[idx];
+            R4[1] = make_float4(conic.z, opacity * coef, rgb.x, rgb.y);
             R4[2] = make_float4(rgb.z, ts, rp[0], rp[1]);
             R4[3] = make_float4(p_view.x, p_view.y, p_view.z, nrm.x);
             R4[4] = make_float4(cp[0], cp[1], cp[2], cp[3]);
@@ -147,22 +158,60 @@ preprocess_fwd_kernel(const PreArgs a, float* __restrict__ rec, uint32_t* __rest
             atomicAdd(&hist0[((uint32_t)idx / per_block) * 256u + (dkey & 255u)], 1u);
         }
     }
-    // total instance count: wave reduction, one atomic per wave that has something to add (sharded, summed on the host)
+    // total instance count: wave scan, one atomic per wave that has something to add (sharded, summed later)
+    const uint32_t lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     uint32_t v = my_tiles;
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    for (int off = 1; off < 64; off <<= 1) { const uint32_t t = __shfl_up(v, off, 64); if (lane >= (uint32_t)off) v += t; }
     // 64 counter shards, one cache line apart: same-address atomics serialise at ~12 ns each (3128 waves -> 37 us on one word)
-    if ((threadIdx.x & 63) == 0 && v) atomicAdd(&counters[COUNTER_SHARD_STRIDE * (1 + (blockIdx.x & (COUNTER_SHARDS - 1)))], v);
+    if (lane == 63 && v) atomicAdd(&counters[COUNTER_SHARD_STRIDE * (1 + (blockIdx.x & (COUNTER_SHARDS - 1)))], v);
+    if (pairs == nullptr) return;                             // radix binning: instances are emitted after the depth sort
+
+    // ---- slab binning: the workgroup drops its instances into the tile slabs cooperatively (load-balanced over the 256
+    //      threads whatever the individual footprints are): slot = tile_count[t]++ ; pairs[t*slab + slot] = depth<<32 | id
+    if (lane == 63) s_ws[wid] = v;
+    s_dkey[threadIdx.x] = my_dkey; s_x0[threadIdx.x] = rect_x0; s_y0[threadIdx.x] = rect_y0; s_w[threadIdx.x] = rect_w;
+    __syncthreads();
+    uint32_t woff = 0;
+    for (uint32_t w = 0; w < wid; w++) woff += s_ws[w];
+    const uint32_t total = s_ws[0] + s_ws[1] + s_ws[2] + s_ws[3];
+    s_incl[threadIdx.x] = v + woff;
+    __syncthreads();
+    for (uint32_t k0 = 0; k0 < total; k0 += 512) {
+        // two instances per thread and trip, so that two atomic round trips are in flight
+        uint32_t tt[2], key_lo[2], key_hi[2]; bool ok[2];
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            const uint32_t k = k0 + u * 256 + threadIdx.x;
+            ok[u] = k < total;
+            uint32_t lo = 0, hi = 255;
+            if (ok[u]) {
+#pragma unroll
+                for (int it = 0; it < 8; it++) { const uint32_t mid = (lo + hi) >> 1; if (s_incl[mid] > k) hi = mid; else lo = mid + 1; }
+            }
+            const uint32_t j = lo;
+            const uint32_t local = ok[u] ? k - (j ? s_incl[j - 1] : 0u) : 0u;
+            const uint32_t w = (uint32_t)s_w[j];
+            tt[u] = (uint32_t)((s_y0[j] + (int)(local / w)) * p.gx + s_x0[j] + (int)(local % w));
+            key_hi[u] = s_dkey[j]; key_lo[u] = blockIdx.x * 256u + j;
+        }
+        uint32_t slot[2];
+#pragma unroll
+        for (int u = 0; u < 2; u++) slot[u] = ok[u] ? atomicAdd(&tile_count[tt[u]], 1u) : 0xFFFFFFFFu;
+#pragma unroll
+        for (int u = 0; u < 2; u++)
+            if (slot[u] < slab) pairs[(size_t)tt[u] * slab + slot[u]] = ((uint64_t)key_hi[u] << 32) | (uint64_t)key_lo[u];
+    }
 }
 
 hipError_t launch_preprocess_fwd(hipStream_t s, const FwdParams& p, float* rec, uint32_t* tiles, uint32_t* depth_keys,
                                  uint32_t* ident, int* radii, uint32_t* counters, uint32_t* hist0, uint32_t per_block,
-                                 uint32_t* tile_count)
+                                 uint32_t* tile_count, uint64_t* pairs, uint32_t slab)
 {
     PreArgs a; a.p = p;
     // (staging the SH rows through LDS was tried here and lost: 50 KB/block costs more occupancy than the strided reads cost)
     hipLaunchKernelGGL(preprocess_fwd_kernel, dim3((p.P + 255) / 256), dim3(256), 0, s, a, rec, tiles, depth_keys, ident, radii, counters,
-                       hist0, per_block, tile_count);
+                       hist0, per_block, tile_count, pairs, slab);
     return hipGetLastError();
 }
 

@@ -149,11 +149,11 @@ activate_fwd_kernel(int P, const float* __restrict__ logit, const float* __restr
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= P) return;
-    opacity[i] = 1.0f / (1.0f + expf(-logit[i]));
+    opacity[i] = act_sigmoid(logit[i]);
 #pragma unroll
-    for (int k = 0; k < 3; k++) scale[3 * i + k] = expf(log_scale[3 * i + k]);
+    for (int k = 0; k < 3; k++) scale[3 * i + k] = act_exp(log_scale[3 * i + k]);
     const float q0 = rot[4 * i], q1 = rot[4 * i + 1], q2 = rot[4 * i + 2], q3 = rot[4 * i + 3];
-    const float inv = 1.0f / fmaxf(sqrtf(q0 * q0 + q1 * q1 + q2 * q2 + q3 * q3), 1e-12f);       // F.normalize eps
+    const float inv = act_inv_norm4(q0, q1, q2, q3);
     rot_n[4 * i] = q0 * inv; rot_n[4 * i + 1] = q1 * inv; rot_n[4 * i + 2] = q2 * inv; rot_n[4 * i + 3] = q3 * inv;
 }
 __global__ void __launch_bounds__(256)

@@ -296,142 +296,209 @@ hipError_t launch_tile_ranges(hipStream_t s, uint32_t R, const uint32_t* tile_ke
 }
 
 // =====================================================================================================================
-// Bucket binning (default path).  The (tile, depth) order of the reference's global sort is produced per tile instead:
-//   preprocess counts the instances of every tile (atomics)  ->  tile_scan_kernel turns the counts into [start,end) ranges
-//   ->  bucket_scatter_kernel drops every instance into its tile's range (atomic cursor, arbitrary order)
-//   ->  tile_sort_kernel sorts each tile's range in LDS by the 64-bit key (depth bits << 32 | Gaussian id).
+// Slab binning (default path).  The (tile, depth) order of the reference's global sort is produced per tile instead:
+//   preprocess drops every instance into its tile's fixed-capacity slab with one atomic (slot = tile_count[t]++)
+//   ->  tile_sort_kernel sorts each slab in LDS by the 64-bit key (depth bits << 32 | Gaussian id) and writes the tile's range.
 // That total order is exactly what a stable sort on (tile, depth) yields for instances emitted in Gaussian-index order
-// (rasterizer_impl.cu:70-111,376-381): ties on identical depth bits resolve by Gaussian index.  No pass over all R
-// instances ever touches HBM more than twice, and nothing needs the host to know R before it is launched.
+// (rasterizer_impl.cu:70-111,376-381): ties on identical depth bits resolve by Gaussian index.  Every instance crosses HBM
+// once as an 8-byte pair and once as a 4-byte id, and nothing needs the host to know R before it is launched.
 // =====================================================================================================================
 
-// exclusive scan of the per-tile counts -> ranges[t] = (start, end); stats[0] = R, stats[1] = largest tile
+// bitonic network over keys[0..N) by `nthreads` cooperating threads (thread index t); SYNC() separates the stages
+#define BITONIC_SORT(keys, N, t, nthreads, SYNC)                                                        \
+    for (uint32_t bs_k = 2; bs_k <= (N); bs_k <<= 1) {                                                  \
+        for (uint32_t bs_j = bs_k >> 1; bs_j > 0; bs_j >>= 1) {                                         \
+            for (uint32_t bs_p = (t); bs_p < ((N) >> 1); bs_p += (nthreads)) {                          \
+                const uint32_t bs_i = ((bs_p & ~(bs_j - 1)) << 1) | (bs_p & (bs_j - 1));                \
+                const uint32_t bs_q = bs_i | bs_j;                                                      \
+                const uint64_t bs_a = (keys)[bs_i], bs_b = (keys)[bs_q];                                \
+                const bool bs_up = (bs_i & bs_k) == 0;                                                  \
+                if ((bs_a > bs_b) == bs_up) { (keys)[bs_i] = bs_b; (keys)[bs_q] = bs_a; }               \
+            }                                                                                           \
+            SYNC;                                                                                       \
+        }                                                                                               \
+    }
+
+// Bitonic sort of 64*E keys held in registers by one wave: element i = lane*E + r lives in v[r] of `lane`.  Strides below E
+// are register-to-register, strides of E and more are lane exchanges (partner lane = lane ^ stride/E): no LDS, no barriers,
+// every loop bound a compile-time constant.
+template <int E>
+__device__ __forceinline__ void wave_bitonic_sort(uint64_t (&v)[E], uint32_t lane)
+{
+#pragma unroll
+    for (int k = 2; k <= 64 * E; k <<= 1) {
+#pragma unroll
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            if (j >= E) {
+                const int lm = j / E;
+                const bool lower = (lane & (uint32_t)lm) == 0;                    // this element is the lower one of its pair
+#pragma unroll
+                for (int r = 0; r < E; r++) {
+                    const uint32_t i = lane * E + r;
+                    const uint64_t o = __shfl_xor((unsigned long long)v[r], lm, 64);
+                    const bool up = (i & (uint32_t)k) == 0;
+                    const uint64_t lo = v[r] < o ? v[r] : o, hi = v[r] < o ? o : v[r];
+                    v[r] = (lower == up) ? lo : hi;
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < E; r++) {
+                    const int q = r ^ j;
+                    if (q > r) {
+                        const uint32_t i = lane * E + r;
+                        const bool up = (i & (uint32_t)k) == 0;
+                        const uint64_t x = v[r], y = v[q];
+                        const bool sw = (x > y) == up;
+                        v[r] = sw ? y : x; v[q] = sw ? x : y;
+                    }
+                }
+            }
+        }
+    }
+}
+template <int E>
+__device__ __forceinline__ void wave_sort_tile(const uint64_t* __restrict__ src, uint32_t* __restrict__ dst, uint32_t n, uint32_t lane)
+{
+    uint64_t v[E];
+#pragma unroll
+    for (int r = 0; r < E; r++) { const uint32_t i = lane * E + r; v[r] = i < n ? src[i] : ~0ull; }
+    wave_bitonic_sort<E>(v, lane);
+#pragma unroll
+    for (int r = 0; r < E; r++) { const uint32_t i = lane * E + r; if (i < n) dst[i] = (uint32_t)v[r]; }
+}
+
+// A workgroup of 4 waves owns 4 consecutive tiles.  Tiles of up to TILE_SORT_WAVE instances (nearly all of them) are sorted
+// by one wave each in registers; the few denser ones (up to TILE_SORT_SMALL) by the whole workgroup in LDS afterwards.
+// Tiles in (TILE_SORT_SMALL, slab] are left to tile_sort_big_kernel; tiles that overflowed their slab get an empty range and
+// report their size in stats[1] (the host then redoes the frame with larger slabs).
+__global__ void __launch_bounds__(256)
+tile_sort_kernel(uint32_t T, const uint32_t* __restrict__ tile_count, const uint64_t* __restrict__ pairs,
+                 uint32_t* __restrict__ point_list, uint32_t* __restrict__ ranges, uint32_t slab, uint32_t* __restrict__ stats,
+                 const uint32_t* __restrict__ counters)
+{
+    __shared__ __attribute__((aligned(16))) uint64_t skeys[TILE_SORT_SMALL];        // 16 KB, phase 2 only
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    if (blockIdx.x == 0 && wid == 0 && counters) {
+        // R = sum of the preprocess kernel's counter shards
+        uint32_t v = counters[COUNTER_SHARD_STRIDE * (1 + lane)];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+        if (lane == 0) stats[0] = v;
+    }
+    const uint32_t t0 = blockIdx.x * 4;
+    // the four counts of the workgroup, fetched once (lane q of every wave loads tile t0+q)
+    const uint32_t my_cnt = (lane < 4 && t0 + lane < T) ? tile_count[t0 + lane] : 0u;
+    const uint32_t cnt0 = (uint32_t)__shfl((int)my_cnt, 0, 64), cnt1 = (uint32_t)__shfl((int)my_cnt, 1, 64);
+    const uint32_t cnt2 = (uint32_t)__shfl((int)my_cnt, 2, 64), cnt3 = (uint32_t)__shfl((int)my_cnt, 3, 64);
+    // ---- phase 1: one wave per tile
+    {
+        const uint32_t t = t0 + wid;
+        if (t < T) {
+            const uint32_t n_true = wid == 0 ? cnt0 : wid == 1 ? cnt1 : wid == 2 ? cnt2 : cnt3;
+            const size_t base = (size_t)t * slab;
+            if (n_true > slab) {
+                if (lane == 0) { atomicMax(&stats[1], n_true); ranges[2 * t] = (uint32_t)base; ranges[2 * t + 1] = (uint32_t)base; }
+            } else {
+                if (lane == 0 && n_true <= TILE_SORT_SMALL) { ranges[2 * t] = (uint32_t)base; ranges[2 * t + 1] = (uint32_t)(base + n_true); }
+                const uint64_t* src = pairs + base;
+                uint32_t* dst = point_list + base;
+                if (n_true == 0) {}
+                else if (n_true <= 64) wave_sort_tile<1>(src, dst, n_true, lane);
+                else if (n_true <= 128) wave_sort_tile<2>(src, dst, n_true, lane);
+                else if (n_true <= 256) wave_sort_tile<4>(src, dst, n_true, lane);
+                else if (n_true <= 512) wave_sort_tile<8>(src, dst, n_true, lane);
+                else if (n_true <= 1024) wave_sort_tile<16>(src, dst, n_true, lane);
+            }
+        }
+    }
+    // ---- phase 2: the workgroup sorts its tiles of (TILE_SORT_WAVE, TILE_SORT_SMALL] instances one after the other
+    for (uint32_t q = 0; q < 4; q++) {
+        const uint32_t t = t0 + q;
+        if (t >= T) break;
+        const uint32_t n = q == 0 ? cnt0 : q == 1 ? cnt1 : q == 2 ? cnt2 : cnt3;      // block-uniform
+        if (n <= TILE_SORT_WAVE || n > TILE_SORT_SMALL || n > slab) continue;
+        const size_t base = (size_t)t * slab;
+        __syncthreads();                                                   // previous tile done with skeys
+        uint32_t N = 2;
+        while (N < n) N <<= 1;
+        for (uint32_t i = tid; i < N; i += 256) skeys[i] = (i < n) ? pairs[base + i] : ~0ull;
+        __syncthreads();
+        BITONIC_SORT(skeys, N, tid, 256, __syncthreads())
+        for (uint32_t i = tid; i < n; i += 256) point_list[base + i] = (uint32_t)skeys[i];
+    }
+}
+
+// one workgroup per tile of (TILE_SORT_SMALL, TILE_SORT_BIG] instances (only launched when the slabs are that large)
 __global__ void __launch_bounds__(1024)
-tile_scan_kernel(uint32_t T, const uint32_t* __restrict__ tile_count, uint32_t* __restrict__ ranges, uint32_t* __restrict__ stats)
+tile_sort_big_kernel(const uint32_t* __restrict__ tile_count, const uint64_t* __restrict__ pairs, uint32_t* __restrict__ point_list,
+                     uint32_t* __restrict__ ranges, uint32_t slab)
+{
+    extern __shared__ __attribute__((aligned(16))) uint64_t bkeys[];
+    const uint32_t t = blockIdx.x, n = tile_count[t];
+    if (n <= TILE_SORT_SMALL || n > slab || n > TILE_SORT_BIG) return;
+    const size_t base = (size_t)t * slab;
+    uint32_t N = 2;
+    while (N < n) N <<= 1;
+    for (uint32_t i = threadIdx.x; i < N; i += 1024) bkeys[i] = (i < n) ? pairs[base + i] : ~0ull;
+    __syncthreads();
+    BITONIC_SORT(bkeys, N, threadIdx.x, 1024, __syncthreads())
+    for (uint32_t i = threadIdx.x; i < n; i += 1024) point_list[base + i] = (uint32_t)bkeys[i];
+    if (threadIdx.x == 0) { ranges[2 * t] = (uint32_t)base; ranges[2 * t + 1] = (uint32_t)(base + n); }
+}
+
+hipError_t launch_tile_sort(hipStream_t s, uint32_t T, const uint32_t* tile_count, const uint64_t* pairs, uint32_t* point_list,
+                            uint32_t* ranges, uint32_t slab, uint32_t* stats, const uint32_t* counters)
+{
+    hipLaunchKernelGGL(tile_sort_kernel, dim3((T + 3) / 4), dim3(256), 0, s, T, tile_count, pairs, point_list, ranges, slab, stats, counters);
+    if (slab > TILE_SORT_SMALL) {
+        static bool attr_set = false;
+        if (!attr_set) {
+            (void)hipFuncSetAttribute((const void*)tile_sort_big_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, TILE_SORT_BIG * 8);
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(tile_sort_big_kernel, dim3(T), dim3(1024), TILE_SORT_BIG * 8, s, tile_count, pairs, point_list, ranges, slab);
+    }
+    return hipGetLastError();
+}
+
+// ---- debug / test support: gather per-tile lists (slab or compact) into the reference's compact layout --------------------
+__global__ void __launch_bounds__(1024)
+compact_ranges_kernel(uint32_t T, const uint32_t* __restrict__ ranges_in, uint32_t* __restrict__ ranges_out)
 {
     __shared__ uint32_t wave_sums[16];
-    __shared__ uint32_t wave_max[16];
     const uint32_t tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const uint32_t per = (T + 1023) / 1024;
     const uint32_t beg = min(T, tid * per), end = min(T, beg + per);
-    uint32_t sum = 0, mx = 0;
-    for (uint32_t i = beg; i < end; i++) { const uint32_t c = tile_count[i]; sum += c; mx = max(mx, c); }
+    uint32_t sum = 0;
+    for (uint32_t i = beg; i < end; i++) sum += ranges_in[2 * i + 1] - ranges_in[2 * i];
     uint32_t v = sum;
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) { uint32_t t = __shfl_up(v, off, 64); if (lane >= (uint32_t)off) v += t; }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, off, 64));
     if (lane == 63) wave_sums[wid] = v;
-    if (lane == 0) wave_max[wid] = mx;
-    __syncthreads();
-    uint32_t woff = 0, total = 0, gmax = 0;
-    for (uint32_t w = 0; w < 16; w++) { const uint32_t t = wave_sums[w]; if (w < wid) woff += t; total += t; gmax = max(gmax, wave_max[w]); }
-    uint32_t run = v - sum + woff;
-    for (uint32_t i = beg; i < end; i++) { const uint32_t c = tile_count[i]; ranges[2 * i] = run; run += c; ranges[2 * i + 1] = run; }
-    if (tid == 0) { stats[0] = total; stats[1] = gmax; }
-}
-hipError_t launch_tile_scan(hipStream_t s, uint32_t T, const uint32_t* tile_count, uint32_t* ranges, uint32_t* stats)
-{
-    hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, s, T, tile_count, ranges, stats);
-    return hipGetLastError();
-}
-
-// a block of 256 Gaussians (index order) drops its instances into the tile buckets cooperatively
-__global__ void __launch_bounds__(256)
-bucket_scatter_kernel(int P, int gx, int gy, const uint32_t* __restrict__ tiles, const float* __restrict__ rec,
-                      const int* __restrict__ radii, const uint32_t* __restrict__ ranges, uint32_t* __restrict__ cursor,
-                      uint32_t* __restrict__ bkey, uint32_t* __restrict__ bid, uint32_t capacity)
-{
-    __shared__ uint32_t incl[256];
-    __shared__ uint32_t dkey[256];
-    __shared__ int rx0[256], ry0[256], rw[256];
-    __shared__ uint32_t ws[4];
-    const uint32_t tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int g = blockIdx.x * 256 + tid;
-    uint32_t cnt = 0, dk = 0;
-    int x0 = 0, y0 = 0, x1 = 0, y1 = 0;
-    if (g < P) {
-        cnt = tiles[g];
-        if (cnt) {
-            const float* r = rec + (size_t)g * REC_F;
-            get_rect(r[0], r[1], radii[g], gx, gy, x0, y0, x1, y1);
-            dk = __float_as_uint(r[31]);
-        }
-    }
-    uint32_t v = cnt;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) { uint32_t t = __shfl_up(v, off, 64); if (lane >= (uint32_t)off) v += t; }
-    if (lane == 63) ws[wid] = v;
     __syncthreads();
     uint32_t woff = 0;
-    for (uint32_t w = 0; w < wid; w++) woff += ws[w];
-    const uint32_t total = ws[0] + ws[1] + ws[2] + ws[3];
-    incl[tid] = v + woff;
-    dkey[tid] = dk; rx0[tid] = x0; ry0[tid] = y0; rw[tid] = x1 - x0;
-    __syncthreads();
-    for (uint32_t k = tid; k < total; k += 256) {
-        uint32_t lo = 0, hi = 255;
-#pragma unroll
-        for (int it = 0; it < 8; it++) { const uint32_t mid = (lo + hi) >> 1; if (incl[mid] > k) hi = mid; else lo = mid + 1; }
-        const uint32_t j = lo;
-        const uint32_t local = k - (j ? incl[j - 1] : 0u);
-        const int w = rw[j];
-        const uint32_t t = (uint32_t)((ry0[j] + (int)(local / (uint32_t)w)) * gx + rx0[j] + (int)(local % (uint32_t)w));
-        const uint32_t pos = ranges[2 * t] + atomicAdd(&cursor[t], 1u);
-        if (pos < capacity) { bkey[pos] = dkey[j]; bid[pos] = (uint32_t)(blockIdx.x * 256 + j); }
+    for (uint32_t w = 0; w < wid; w++) woff += wave_sums[w];
+    uint32_t run = v - sum + woff;
+    for (uint32_t i = beg; i < end; i++) {
+        const uint32_t c = ranges_in[2 * i + 1] - ranges_in[2 * i];
+        // empty tiles read (0,0) as in the reference (rasterizer_impl.cu:383 zero-fills ranges)
+        ranges_out[2 * i] = c ? run : 0u; run += c; ranges_out[2 * i + 1] = c ? run : 0u;
     }
 }
-hipError_t launch_bucket_scatter(hipStream_t s, int P, int gx, int gy, const uint32_t* tiles, const float* rec, const int* radii,
-                                 const uint32_t* ranges, uint32_t* cursor, uint32_t* bkey, uint32_t* bid, uint32_t capacity)
+__global__ void __launch_bounds__(256)
+compact_lists_kernel(const uint32_t* __restrict__ ranges_in, const uint32_t* __restrict__ ranges_out, const uint32_t* __restrict__ list_in,
+                     uint32_t* __restrict__ list_out, uint32_t out_capacity)
 {
-    hipLaunchKernelGGL(bucket_scatter_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, gx, gy, tiles, rec, radii, ranges, cursor, bkey,
-                       bid, capacity);
-    return hipGetLastError();
+    const uint32_t t = blockIdx.x;
+    const uint32_t src = ranges_in[2 * t], n = ranges_in[2 * t + 1] - src, dst = ranges_out[2 * t];
+    for (uint32_t i = threadIdx.x; i < n; i += 256)
+        if (dst + i < out_capacity) list_out[dst + i] = list_in[src + i];
 }
-
-// one workgroup per tile: bitonic sort of the tile's (depth bits << 32 | id) keys in LDS, sorted ids -> point_list
-template <int NMAX, int THREADS>
-__global__ void __launch_bounds__(THREADS)
-tile_sort_kernel(const uint32_t* __restrict__ ranges, const uint32_t* __restrict__ bkey, const uint32_t* __restrict__ bid,
-                 uint32_t* __restrict__ point_list, uint32_t nmin, uint32_t capacity)
+hipError_t launch_compact_lists(hipStream_t s, uint32_t T, const uint32_t* ranges_in, const uint32_t* list_in, uint32_t* ranges_out,
+                                uint32_t* list_out, uint32_t out_capacity)
 {
-    extern __shared__ __attribute__((aligned(16))) uint64_t skeys[];
-    const uint32_t beg = ranges[2 * blockIdx.x], end = ranges[2 * blockIdx.x + 1];
-    const uint32_t n = end - beg;
-    if (n < nmin || n > (uint32_t)NMAX || end > capacity) return;        // another tier's tile, or (to be retried) an overflow
-    if (n == 1) { if (threadIdx.x == 0) point_list[beg] = bid[beg]; return; }
-    uint32_t N = 2;
-    while (N < n) N <<= 1;
-    for (uint32_t i = threadIdx.x; i < N; i += THREADS)
-        skeys[i] = (i < n) ? (((uint64_t)bkey[beg + i] << 32) | (uint64_t)bid[beg + i]) : ~0ull;
-    __syncthreads();
-    for (uint32_t k = 2; k <= N; k <<= 1) {
-        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-            for (uint32_t p = threadIdx.x; p < (N >> 1); p += THREADS) {
-                const uint32_t idx = ((p & ~(j - 1)) << 1) | (p & (j - 1));      // index with bit log2(j) clear
-                const uint32_t par = idx | j;
-                const uint64_t a = skeys[idx], b = skeys[par];
-                const bool up = (idx & k) == 0;
-                if ((a > b) == up) { skeys[idx] = b; skeys[par] = a; }
-            }
-            __syncthreads();
-        }
-    }
-    for (uint32_t i = threadIdx.x; i < n; i += THREADS) point_list[beg + i] = (uint32_t)skeys[i];
-}
-hipError_t launch_tile_sort(hipStream_t s, uint32_t T, const uint32_t* ranges, const uint32_t* bkey, const uint32_t* bid,
-                            uint32_t* point_list, uint32_t capacity, bool big_tiles)
-{
-    hipLaunchKernelGGL((tile_sort_kernel<TILE_SORT_SMALL, 256>), dim3(T), dim3(256), TILE_SORT_SMALL * 8, s, ranges, bkey, bid,
-                       point_list, 1u, capacity);
-    if (big_tiles) {
-        static bool attr_set = false;
-        if (!attr_set) {
-            (void)hipFuncSetAttribute((const void*)tile_sort_kernel<TILE_SORT_BIG, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, TILE_SORT_BIG * 8);
-            attr_set = true;
-        }
-        hipLaunchKernelGGL((tile_sort_kernel<TILE_SORT_BIG, 1024>), dim3(T), dim3(1024), TILE_SORT_BIG * 8, s, ranges, bkey, bid,
-                           point_list, (uint32_t)TILE_SORT_SMALL + 1u, capacity);
-    }
+    hipLaunchKernelGGL(compact_ranges_kernel, dim3(1), dim3(1024), 0, s, T, ranges_in, ranges_out);
+    if (list_in && list_out && out_capacity)
+        hipLaunchKernelGGL(compact_lists_kernel, dim3(T), dim3(256), 0, s, ranges_in, ranges_out, list_in, list_out, out_capacity);
     return hipGetLastError();
 }

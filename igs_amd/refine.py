@@ -145,7 +145,7 @@ class Refiner:
     """One refine step = one view per rank: render, loss, backward, gradient all-reduce (N > 1), Adam."""
 
     def __init__(self, params, cams, gt_images, bg, loss="l1", lambda_l1=0.8, world_size=1, rank=0, seed=0,
-                 render_fn=None, adam_fn=None, native=True):
+                 render_fn=None, adam_fn=None, native=True, fused=True):
         self.params, self.cams, self.gt, self.bg = params, cams, gt_images, bg
         self.loss, self.lambda_l1 = loss, lambda_l1
         self.world_size, self.rank = world_size, rank
@@ -154,6 +154,7 @@ class Refiner:
         self.adam_fn = params.adam_step if adam_fn is None else adam_fn
         self.l1 = L1Fused(params.device) if loss == "l1" else None
         self.native = native          # L1 loss: drive the C ABI directly instead of going through autograd
+        self.fused = fused            # ... and on a single GPU run the whole iteration as one library call (igs_refine_step)
         self.grad_img = None
         self.gen = torch.Generator().manual_seed(seed)      # same seed on every rank -> same view permutation
         self.order = []
@@ -222,11 +223,56 @@ class Refiner:
         return dict(images_pred=color, radii=radii, visibility_filter=None, viewspace_points=outs["means2D"], alpha=alpha,
                     depth_pred=depth, normal=normal)
 
+    def _fused_step(self, cam, gt):
+        """Single-GPU step entirely inside the library: `igs_refine_step` (include/igs_rast.h) -- activations, render, L1,
+        backward and the Adam update in 7 launches; no gradient array is materialised."""
+        import ctypes as C
+        p = self.params
+        L = _cabi.lib()
+        dev, P = p.device, p.P
+        H, W = int(cam.height), int(cam.width)
+        if not hasattr(self, "_bufs"):
+            self._bufs = _rast.RasterBuffers()
+        imgs, radii, (geom, binning, img) = self._bufs.get(P, H, W, dev)
+        if not hasattr(self, "_fused"):
+            self._fused = dict(m2d=torch.zeros((P, 3), dtype=torch.float32, device=dev),
+                               loss=torch.zeros(1, dtype=torch.float32, device=dev))
+        a = _cabi.RefineStepArgs()
+        a.stream = torch.cuda.current_stream(dev).cuda_stream
+        a.geometry_buffer, a.binning_buffer, a.image_buffer = geom.cb, binning.cb, img.cb
+        a.workspace = self._bufs.workspace.data_ptr()
+        a.P, a.D, a.M, a.width, a.height = P, 3, 16, W, H
+        a.background = self.bg.data_ptr()
+        a.param, a.exp_avg, a.exp_avg_sq = p.flat.data_ptr(), p.exp_avg.data_ptr(), p.exp_avg_sq.data_ptr()
+        a.off_xyz, a.off_rot, a.off_sh = p.spans["xyz"][0], p.spans["rotation"][0], p.spans["shs"][0]
+        a.off_opacity, a.off_scale = p.spans["opacity"][0], p.spans["scaling"][0]
+        a.lr_xyz, a.lr_rot, a.lr_sh = p.lrs["xyz"], p.lrs["rotation"], p.lrs["shs"]
+        a.lr_opacity, a.lr_scale = p.lrs["opacity"], p.lrs["scaling"]
+        a.beta1, a.beta2, a.eps = p.betas[0], p.betas[1], p.eps
+        a.step = p.step_count + 1
+        a.viewmatrix, a.projmatrix = cam.world_view_transform.data_ptr(), cam.full_proj_transform.data_ptr()
+        a.cam_pos = cam.camera_center.data_ptr()
+        a.tan_fovx, a.tan_fovy = cam.tanfovx, cam.tanfovy
+        a.gt, a.loss_weight = gt.data_ptr(), 1.0
+        a.out_images, a.radii = imgs.data_ptr(), radii.data_ptr()
+        a.dL_dmean2D, a.loss_out = self._fused["m2d"].data_ptr(), self._fused["loss"].data_ptr()
+        a.require_coord, a.require_depth = 1, 1
+        with torch.cuda.device(dev):
+            nr = L.igs_refine_step(C.byref(a))
+        _rast._check(nr, "igs_refine_step")
+        p.step_count += 1
+        self.last_num_rendered = nr
+        return dict(images_pred=imgs[0:3], radii=radii, visibility_filter=None, viewspace_points=self._fused["m2d"],
+                    alpha=imgs[11:12], depth_pred=imgs[9:10], normal=imgs[12:15], loss=self._fused["loss"])
+
     def step(self, view=None):
         p = self.params
         if view is None:
             view = self._next_view()
         cam, gt = self.cams[view], self.gt[view]
+        if (self.loss == "l1" and self.native and self.fused and self.render_fn is render and self.world_size == 1
+                and self.adam_fn == p.adam_step):
+            return self._fused_step(cam, gt)
         if self.loss == "l1" and self.native and self.render_fn is render:
             pkg = self._native_step(cam, gt)
             if self.world_size > 1:

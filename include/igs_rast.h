@@ -47,7 +47,7 @@ extern "C" {
 #define IGS_RAST_E_PREFILTER (-4)   /* `prefiltered` set but a point was culled (the reference __trap()s, auxiliary.h:172-176) */
 #define IGS_RAST_E_CHANNELS  (-5)   /* reserved: non-RGB without precomputed colours (rasterizer_impl.cu:308-311) */
 
-#define IGS_RAST_E_RETRY     (-6)   /* igs_rast_forward_finish: the optimistic instance-list capacity was too small */
+#define IGS_RAST_E_RETRY     (-6)   /* igs_rast_forward_finish: a tile overflowed its instance slab: redo the frame */
 
 /* Scratch growth callback: make the buffer at least `bytes` long and return its device address
  * (the reference's std::function<char*(size_t)> resizeFunctional, rasterize_points.cu:27-33). */
@@ -90,10 +90,10 @@ int igs_rast_forward(
     int debug);                           /* debug != 0: synchronise and check after every launch (auxiliary.h:404-411) */
 
 /* Asynchronous pair (no reference counterpart; used by the native refine step so the GPU never waits for the host):
- * igs_rast_forward_async = igs_rast_forward without the final wait for the instance count; it returns the CAPACITY of the
- * instance list, an upper bound that igs_rast_backward accepts as R.  igs_rast_forward_finish() waits for the 12-byte
+ * igs_rast_forward_async = igs_rast_forward without the final wait for the instance count; it returns INT_MAX ("not known
+ * yet"), which igs_rast_backward accepts as R.  igs_rast_forward_finish() waits for the 12-byte
  * read-back (done right after the tile scan) and returns the true num_rendered, or IGS_RAST_E_RETRY when the guessed
- * capacity / sort tier was too small: whatever was enqueued on top of the frame must then be discarded and the frame
+ * per-tile instance slabs were too small: whatever was enqueued on top of the frame must then be discarded and the frame
  * redone with igs_rast_forward. */
 int igs_rast_forward_async(
     void* stream,
@@ -107,6 +107,13 @@ int igs_rast_forward_async(
     float* out_color, float* out_coord, float* out_mcoord, float* out_depth, float* out_mdepth, float* out_alpha,
     float* out_normal, int* radii, int require_coord, int require_depth, int debug);
 int igs_rast_forward_finish(void);
+
+/* Binning scratch tuning (no reference counterpart).  The default path gives every 16x16 tile a slab of `slots_per_tile`
+ * instance slots (12 bytes each) in binningBuffer; a frame in which some tile needs more is redone automatically with larger
+ * slabs (and, beyond 16384 per tile, with the global radix sort), and the size then sticks for the calling thread.  Setting the
+ * hint up front avoids that first redo; 0 restores the default (1024).  get returns the current value. */
+void igs_rast_set_slab_hint(unsigned slots_per_tile);
+unsigned igs_rast_get_slab_hint(void);
 
 size_t igs_rast_backward_workspace_bytes(int P);
 
@@ -188,6 +195,41 @@ int igs_adam_step(void* stream, size_t n, float* param, const float* grad, float
 int igs_adam_step_groups(void* stream, int ngroups, const size_t* offset, const size_t* count, const float* lr, float* param,
                          const float* grad, float* exp_avg, float* exp_avg_sq, float beta1, float beta2, float eps,
                          float bias_correction1, float bias_correction2_sqrt);
+
+/* ---- one whole refine iteration on one view, single GPU --------------------------------------------------------------
+ * Native form of the body of the reference's per-frame refine loop (infer_batch.py:279-324 with the L1 photometric loss,
+ * igs/utils/loss_utils.py:17; activations of igs/models/gaussian_model.py:90-127; torch.optim.Adam of :295-348):
+ *   opacity = sigmoid, scale = exp, rotation = normalize  ->  render  ->  loss = loss_weight * mean|color - gt|
+ *   ->  backward through rasterizer and activations  ->  Adam update of the five parameter groups, in place.
+ * Everything is enqueued on `stream` without a host wait; the gradients never reach HBM (the per-Gaussian backward kernel
+ * applies the update itself).  `param` / `exp_avg` / `exp_avg_sq` are flat fp32 buffers holding the five groups at the given
+ * float offsets: xyz [P][3], rotation [P][4] (raw quaternion), shs [P][M][3], opacity [P] (logit), scale [P][3] (log).
+ * Multi-GPU runs need the gradients for the all-reduce and use igs_rast_forward/backward + igs_adam_step_groups instead.
+ * Returns num_rendered or a negative error code. */
+typedef struct igs_refine_step_args {
+    void* stream;
+    igs_rast_alloc_fn geometry_buffer; void* geometry_user;
+    igs_rast_alloc_fn binning_buffer;  void* binning_user;
+    igs_rast_alloc_fn image_buffer;    void* image_user;
+    void* workspace;                          /* igs_rast_backward_workspace_bytes(P) */
+    int P, D, M, width, height;
+    const float* background;                  /* [3] device */
+    float *param, *exp_avg, *exp_avg_sq;      /* flat optimiser state, device */
+    size_t off_xyz, off_rot, off_sh, off_opacity, off_scale;
+    float lr_xyz, lr_rot, lr_sh, lr_opacity, lr_scale;
+    float beta1, beta2, eps;
+    int step;                                 /* 1-based number of this update (bias correction) */
+    const float *viewmatrix, *projmatrix, *cam_pos;   /* device */
+    float tan_fovx, tan_fovy;
+    const float* gt;                          /* [3][H][W] device */
+    float loss_weight;
+    float* out_images;                        /* [15][H][W]: color 3 | coord 3 | mcoord 3 | depth 1 | mdepth 1 | alpha 1 | normal 3 */
+    int* radii;                               /* [P] */
+    float* dL_dmean2D;                        /* [P][3] view-space gradient (densification statistic) or NULL */
+    float* loss_out;                          /* device, 1 float: the loss value, or NULL */
+    int require_coord, require_depth;
+} igs_refine_step_args;
+int igs_refine_step(const igs_refine_step_args* args);
 
 /* Fused L1 loss forward + backward (igs/utils/loss_utils.py:17-18): grad[i] = sign(pred[i] - gt[i]) * scale, and
  * sum |pred - gt| is accumulated into 64 shards loss_sum[16*s], s = 0..63 (1024 floats, zeroed by the caller, summed by

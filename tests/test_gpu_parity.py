@@ -403,7 +403,7 @@ def test_refine_loop_improves_psnr_and_fused_ops(dev):
     params = GaussianParams(raw, dev)
     ref_leaves = {k: v.detach().clone().requires_grad_(True) for k, v in params.leaves.items()}
     opt = torch.optim.Adam([{"params": [ref_leaves[k]], "lr": params.lrs[k]} for k in ref_leaves], lr=0.0, eps=1e-15)
-    refiner = Refiner(params, cams, gts, bg, loss="l1")
+    refiner = Refiner(params, cams, gts, bg, loss="l1", fused=False)      # (the fused step leaves no gradients to hand to torch)
     p0 = float(psnr(pred, gts[0]))
     for it in range(3):
         refiner.step(view=0)
@@ -412,6 +412,7 @@ def test_refine_loop_improves_psnr_and_fused_ops(dev):
         opt.step()
         for k in ref_leaves:
             torch.testing.assert_close(params.leaves[k].detach(), ref_leaves[k].detach(), rtol=1e-4, atol=2e-6)
+    refiner.fused = True                                   # continue with the single-call step (igs_refine_step)
     for it in range(40):
         refiner.step(view=0)
     with torch.no_grad():
@@ -457,17 +458,27 @@ def test_native_step_equals_autograd_step_and_null_grads_equal_zero_grads(dev):
         assert np.quantile(r, 0.999) < 1e-3, (n, np.quantile(r, 0.999))
 
 
-def test_bucket_and_radix_binning_agree(dev, monkeypatch):
-    """Default path (per-tile buckets + in-LDS sort) and the global radix-sort path produce the same instance list and images;
-    the first call on a fresh capacity hint also exercises the optimistic-capacity retry (cfg-1 has > 4 instances per Gaussian)."""
-    from igs_amd import rasterizer as R
-    raw, cams, bg = cfg1_scene(P=6000, size=192)
+@pytest.mark.parametrize("case", [(6000, 192, 128), (6000, 192, 1024), (12000, 64, 0), (12000, 64, 16384)])
+def test_slab_and_radix_binning_agree(dev, monkeypatch, case):
+    """Default path (per-tile slabs + in-LDS sort) and the global radix-sort path produce the same instance list and images:
+    slabs too small (128 slots -> frame redone), wave-level + workgroup-level sorts (tiles of up to 565 instances), and tiles of
+    > 2048 instances (default slab overflows, then the big-tile kernel; 3660 instances in the densest tile)."""
+    from igs_amd import rasterizer as R, _cabi
+    P, size, hint = case
+    raw, cams, bg = cfg1_scene(P=P, size=size)
     cam, a = cams[0], activate(raw)
-    out_b, _, _ = hip_forward(a, cam, bg, dev, debug=False)
-    db = R.debug_dump(6000, out_b[0], cam.width, cam.height, out_b[9], out_b[10], out_b[11])
+    L = _cabi.lib()
+    try:
+        L.igs_rast_set_slab_hint(hint)
+        out_b, _, _ = hip_forward(a, cam, bg, dev, debug=False)
+        if hint == 128 or hint == 0:
+            assert L.igs_rast_get_slab_hint() > max(hint, 1024 if hint == 0 else 0)      # overflowed and grew
+    finally:
+        L.igs_rast_set_slab_hint(0)
+    db = R.debug_dump(P, out_b[0], cam.width, cam.height, out_b[9], out_b[10], out_b[11])
     monkeypatch.setenv("IGS_BINNING", "radix")
     out_r, _, _ = hip_forward(a, cam, bg, dev, debug=False)
-    dr = R.debug_dump(6000, out_r[0], cam.width, cam.height, out_r[9], out_r[10], out_r[11])
+    dr = R.debug_dump(P, out_r[0], cam.width, cam.height, out_r[9], out_r[10], out_r[11])
     monkeypatch.delenv("IGS_BINNING")
     assert out_b[0] == out_r[0]
     assert torch.equal(db["point_list"], dr["point_list"]) and torch.equal(db["ranges"], dr["ranges"])
@@ -475,16 +486,19 @@ def test_bucket_and_radix_binning_agree(dev, monkeypatch):
     for i in range(1, 8):
         assert torch.equal(out_b[i], out_r[i])
     nr_o, oo, st = oracle_forward(a, cam, bg)
+    assert nr_o == out_b[0]
     np.testing.assert_array_equal(db["point_list"].cpu().numpy().astype(np.uint32), st.intermediates()["point_list"])
+    np.testing.assert_array_equal(db["ranges"].cpu().numpy().astype(np.uint32), st.intermediates()["ranges"])
 
 
-def test_deferred_step_equals_synchronous_step_and_survives_capacity_retry(dev):
+def test_deferred_step_equals_synchronous_step_and_survives_slab_overflow(dev):
     """The refine step that enqueues the whole frame before the host learns the instance count (igs_rast_forward_async /
-    _finish) gives the gradients of the synchronous step (up to the rounding order of float atomics) -- also when the optimistic list capacity was too small
-    (hint reset by a tiny frame first; cfg-1 has far more than 4 instances per Gaussian) and the frame is redone."""
+    _finish) gives the gradients of the synchronous step (up to the rounding order of float atomics) -- also when the per-tile
+    instance slabs were too small (hint forced down to 64 slots; cfg-1 tiles hold hundreds) and the frame is redone."""
     from igs_amd.refine import GaussianParams, Refiner, render
     from igs_amd.scenes import perturbed_copy
-    from igs_amd import rasterizer as R
+    from igs_amd import _cabi
+    L = _cabi.lib()
     raw, cams, bg = cfg1_scene(P=6000, size=192)
     cams = [cams[0].to(dev)]
     bg = bg.to(dev)
@@ -492,23 +506,72 @@ def test_deferred_step_equals_synchronous_step_and_survives_capacity_retry(dev):
     with torch.no_grad():
         gts = [render(activate(gt_raw), cams[0], bg)["images_pred"].clone()]
     grads = []
-    for defer in (False, True, True):
-        # a tiny frame first: the capacity hint of the library drops to its floor (4 instances per Gaussian)
-        tiny, tcams, tbg = cfg1_scene(P=64, size=32)
-        hip_forward(activate(tiny), tcams[0], tbg, dev, debug=False)
-        pa = GaussianParams(raw, dev)
-        ra = Refiner(pa, cams, gts, bg, loss="l1", native=True)
-        ra.adam_fn = lambda: None
-        if not defer:
-            ra._native_step(cams[0], gts[0], defer=False)
-        else:
-            ra.step(view=0)
-        assert ra.last_num_rendered > 4 * 6000            # i.e. the deferred call really overflowed its first guess
-        grads.append(pa.grad.clone())
-        if defer:
-            ra.step(view=0)                                # second call: the hint now fits, no retry
+    try:
+        for defer in (False, True):
+            L.igs_rast_set_slab_hint(64)
+            pa = GaussianParams(raw, dev)
+            ra = Refiner(pa, cams, gts, bg, loss="l1", native=True)
+            ra.adam_fn = lambda: None
+            ra._native_step(cams[0], gts[0], defer=defer)
+            assert L.igs_rast_get_slab_hint() > 64               # i.e. the frame really overflowed and was redone
+            assert ra.last_num_rendered > 64 * 144 // 4
             grads.append(pa.grad.clone())
+            ra._native_step(cams[0], gts[0], defer=defer)         # second call: the slabs now fit, no redo
+            grads.append(pa.grad.clone())
+    finally:
+        L.igs_rast_set_slab_hint(0)
     g0 = grads[0].cpu().numpy()
-    for g in grads[1:]:                                    # float atomics: order-dependent rounding only
+    for g in grads[1:]:                                           # float atomics: order-dependent rounding only
         r = rel(g.cpu().numpy(), g0)
         assert np.quantile(r, 0.999) < 1e-3 and np.median(r) < 1e-6, np.quantile(r, 0.999)
+
+
+def test_fused_refine_step_equals_unfused_step(dev):
+    """igs_refine_step (activations + render + L1 + backward + Adam inside the library, gradients never in HBM) walks the
+    same trajectory as the unfused native step (separate activation / L1 / Adam launches), also through a slab overflow."""
+    from igs_amd.refine import GaussianParams, Refiner, render
+    from igs_amd.scenes import perturbed_copy
+    from igs_amd import _cabi
+    L = _cabi.lib()
+    raw, cams, bg = cfg1_scene(P=6000, size=192)
+    cams = [c.to(dev) for c in cams[:3]]
+    bg = bg.to(dev)
+    gt_raw = {k: v.to(dev) for k, v in perturbed_copy(raw, sigma=0.03).items()}
+    with torch.no_grad():
+        gts = [render(activate(gt_raw), c, bg)["images_pred"].clone() for c in cams]
+    pa, pb = GaussianParams(raw, dev), GaussianParams(raw, dev)
+    ra = Refiner(pa, cams, gts, bg, loss="l1", native=True, fused=True)
+    rb = Refiner(pb, cams, gts, bg, loss="l1", native=True, fused=False)
+    try:
+        L.igs_rast_set_slab_hint(64)                       # first fused step overflows its slabs and must redo cleanly
+        for it in range(4):
+            v = it % len(cams)
+            # both start every step from the same state: Adam turns rounding-level gradient differences (float-atomic order) of
+            # near-zero gradients into +-lr steps, so free-running trajectories drift apart by design
+            pa.flat.copy_(pb.flat); pa.exp_avg.copy_(pb.exp_avg); pa.exp_avg_sq.copy_(pb.exp_avg_sq)
+            pka = ra.step(view=v)
+            if it == 0:
+                assert L.igs_rast_get_slab_hint() > 64
+            pkb = rb.step(view=v)
+            la = float(pka["loss"].item())
+            lb = float(rb.l1.loss_sum.sum().item()) / gts[0].numel()
+            assert abs(la - lb) < 1e-5 * max(1.0, abs(lb)), (la, lb)
+            assert torch.equal(pka["radii"], pkb["radii"])
+            # (activations evaluated inside the preprocess kernel vs in their own kernel: last-ulp differences of the opacity
+            #  can flip a hard alpha threshold on a handful of pixels)
+            dimg = np.abs(pka["images_pred"].cpu().numpy() - pkb["images_pred"].cpu().numpy())
+            assert (dimg > 2e-6).mean() < 2e-4 and dimg.max() < 1e-2, ((dimg > 2e-6).mean(), dimg.max())
+            r = rel(pka["viewspace_points"].cpu().numpy(), pkb["viewspace_points"].cpu().numpy())
+            assert np.quantile(r, 0.99) < 1e-3 and np.median(r) < 1e-5, (np.quantile(r, 0.99), np.median(r))   # saturated scene: 1/T_final noise
+            for name, x, y in (("param", pa.flat, pb.flat), ("exp_avg", pa.exp_avg, pb.exp_avg), ("exp_avg_sq", pa.exp_avg_sq, pb.exp_avg_sq)):
+                x, y = x.cpu().numpy(), y.cpu().numpy()
+                if name == "param":
+                    # |dp| <= lr whatever the gradient: compare against the step size (largest lr is 0.05)
+                    assert np.abs(x - y).max() <= 0.11, (name, np.abs(x - y).max())
+                    assert np.quantile(np.abs(x - y), 0.98) < 2e-6, np.quantile(np.abs(x - y), 0.98)
+                else:
+                    r = rel(x, y)
+                    assert np.quantile(r, 0.98) < 1e-3, (name, np.quantile(r, 0.98))
+    finally:
+        L.igs_rast_set_slab_hint(0)
+    assert pa.step_count == pb.step_count == 4

@@ -1,0 +1,17 @@
+set -e
+cd /tmp && export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT
+O=$R/gpurun_out/prof_r01b
+rm -rf $O && mkdir -p $O
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $R/bench.py --steps 50 --warmup 10 --cpu-views 0 > $O/bench_under_rocprof.log 2>&1
+echo stats done
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/fetch -- python3 $R/tools/prof_run.py 12 > $O/fetch.log 2>&1
+echo fetch done
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/write -- python3 $R/tools/prof_run.py 12 > $O/write.log 2>&1
+echo write done
+rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/sq -- python3 $R/tools/prof_run.py 12 > $O/sq.log 2>&1
+echo sq done
+rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_WAVE_CYCLES SQ_WAIT_INST_ANY --output-format csv -d $O/misc -- python3 $R/tools/prof_run.py 12 > $O/misc.log 2>&1
+echo misc done
+find $O -name "*.db" -delete; find $O -name "*agent_info*" -delete
+du -sh $O
