@@ -82,6 +82,8 @@ def main():
     ap.add_argument("--loss", default="l1", choices=["l1", "l1_ssim"])
     ap.add_argument("--cpu-views", type=int, default=2, help="views timed on the CPU oracle (0 = skip)")
     ap.add_argument("--no-profile", action="store_true", help="do not record per-stage HIP events")
+    ap.add_argument("--profile-every", type=int, default=8,
+                    help="record the per-stage HIP events on every N-th step of the timed region (each event costs stream time)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -122,7 +124,7 @@ def main():
         ref.step()
     torch.cuda.synchronize()
     if not args.no_profile:
-        _cabi.profile_enable(True)
+        _cabi.profile_enable(True, every=max(1, args.profile_every))
         _cabi.profile_read(reset=True)
     barrier()
     torch.cuda.synchronize()

@@ -101,8 +101,9 @@ def last_error():
     return lib().igs_rast_last_error().decode("utf-8", "replace")
 
 
-def profile_enable(on=True):
-    lib().igs_rast_profile_enable(int(bool(on)))
+def profile_enable(on=True, every=1):
+    """Stage marks on every `every`-th frame (an event record costs a few microseconds of stream time)."""
+    lib().igs_rast_profile_enable(int(every) if on else 0)
 
 
 def profile_read(reset=True):

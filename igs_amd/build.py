@@ -45,7 +45,7 @@ def build(force=False, verbose=False):
             continue
         obj = os.path.join(objdir, src.replace(".hip", ".o"))
         objs.append(obj)
-        cmd = [hipcc] + FLAGS + ["-c", path, "-o", obj]
+        cmd = [hipcc] + FLAGS + os.environ.get("IGS_EXTRA_FLAGS", "").split() + ["-c", path, "-o", obj]
         if verbose:
             print(" ".join(cmd))
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))

@@ -41,6 +41,7 @@ enum { ST_PREPROCESS = 0, ST_DEPTH_SORT, ST_SCAN, ST_EMIT, ST_TILE_SORT, ST_RANG
        ST_GEOM_BWD, ST_COUNT, ST_GAP = -1 };
 struct Prof {
     bool on = false;
+    int every = 1; long long frame = 0; bool active = false;     // marks are recorded on every `every`-th frame only
     static const int CAP = 4096;
     hipEvent_t ev[CAP]; int tag[CAP]; int n = 0; bool created = false;
     double ms[ST_COUNT] = {0}; long long cnt[ST_COUNT] = {0}; double r_sum = 0; long long calls = 0;
@@ -61,7 +62,7 @@ static void prof_collect()
 // records "stage `tag` ended here" (tag = ST_GAP: only a start mark)
 static void prof_mark(hipStream_t s, int tag)
 {
-    if (!g_prof.on) return;
+    if (!g_prof.on || !g_prof.active) return;
     if (!g_prof.created) { for (int i = 0; i < Prof::CAP; i++) (void)hipEventCreate(&g_prof.ev[i]); g_prof.created = true; }
     if (g_prof.n >= Prof::CAP - 1) {                // keep the last mark as the start of the next interval
         const hipEvent_t last = g_prof.ev[g_prof.n - 1];
@@ -72,7 +73,15 @@ static void prof_mark(hipStream_t s, int tag)
     }
     (void)hipEventRecord(g_prof.ev[g_prof.n], s); g_prof.tag[g_prof.n] = tag; g_prof.n++;
 }
-extern "C" int igs_rast_profile_enable(int on) { if (!on) prof_collect(); g_prof.on = on != 0; return 0; }
+// on = 0: off; on = N > 0: record stage marks on every N-th frame (an event record costs a few microseconds of stream time:
+// marking every frame slows a 0.35 ms refine step by 10 %, marking every 8th by about 1 %)
+extern "C" int igs_rast_profile_enable(int on)
+{
+    if (!on) prof_collect();
+    g_prof.on = on != 0; g_prof.every = on > 0 ? on : 1; g_prof.frame = 0; g_prof.active = false;
+    return 0;
+}
+static void prof_new_frame() { if (g_prof.on) { g_prof.active = (g_prof.frame % g_prof.every) == 0; g_prof.frame++; } }
 extern "C" int igs_rast_profile_read(double* ms_sum, long long* count, double* r_sum, long long* calls, int reset)
 {
     prof_collect();
@@ -99,6 +108,8 @@ struct PendingFwd { bool active = false; uint32_t slab = 0; };
 static thread_local PendingFwd g_pending;
 static thread_local bool g_async_request = false;
 static thread_local bool g_raw_activations = false;       // set by igs_refine_step around its forward
+static thread_local float* g_zero_gacc = nullptr;         // ... workspace accumulators the forward zero-fills on the side
+static thread_local float* g_zero_loss = nullptr;
 // where the last slab-binned forward left its device-side validity words (refine step guards)
 struct LastFwd { const uint32_t* overflow = nullptr; const uint32_t* prefilter = nullptr; };
 static thread_local LastFwd g_last_fwd;
@@ -158,6 +169,7 @@ static int forward_impl(
     fp.kernel_size = kernel_size; fp.prefiltered = prefiltered;
     fp.view = viewmatrix; fp.proj = projmatrix; fp.campos = cam_pos;
     fp.raw_activations = g_raw_activations ? 1 : 0;
+    fp.zero_gacc = g_zero_gacc; fp.zero_loss = g_zero_loss;
     g_last_fwd = LastFwd();
 
     const size_t counter_bytes = (COUNTER_SHARDS + 1) * COUNTER_SHARD_STRIDE * 4;
@@ -326,6 +338,7 @@ extern "C" int igs_rast_forward(
     float* out_color, float* out_coord, float* out_mcoord, float* out_depth, float* out_mdepth, float* out_alpha,
     float* out_normal, int* radii, int require_coord, int require_depth, int debug)
 {
+    prof_new_frame();
     const char* e = getenv("IGS_BINNING");                    // "radix" forces the global-sort path (tests)
     const bool radix = e && strcmp(e, "radix") == 0;
     return forward_impl(stream, geometry_buffer, geometry_user, binning_buffer, binning_user, image_buffer, image_user, P, D, M,
@@ -353,6 +366,7 @@ extern "C" int igs_rast_forward_async(
     float* out_color, float* out_coord, float* out_mcoord, float* out_depth, float* out_mdepth, float* out_alpha,
     float* out_normal, int* radii, int require_coord, int require_depth, int debug)
 {
+    prof_new_frame();
     g_pending.active = false;
     g_async_request = true;
     const int rc = forward_impl(stream, geometry_buffer, geometry_user, binning_buffer, binning_user, image_buffer, image_user, P, D, M,
@@ -423,7 +437,8 @@ static int backward_impl(
 
     prof_mark(s, ST_GAP);
     float* loss_shards = (float*)((char*)gacc + ws_gacc_bytes(P));
-    HIP_TRY(hipMemsetAsync(gacc, 0, l1_gt ? ws_gacc_bytes(P) + WS_LOSS_BYTES : (size_t)P * GACC_F * 4, s), "memset gacc");
+    if (!(fuse && fuse->prezeroed))                // (igs_refine_step: the forward's preprocess kernel zero-filled the accumulators)
+        HIP_TRY(hipMemsetAsync(gacc, 0, l1_gt ? ws_gacc_bytes(P) + WS_LOSS_BYTES : (size_t)P * GACC_F * 4, s), "memset gacc");
     prof_mark(s, ST_MEMSET);
     BlendBwdArgs ba;
     ba.W = width; ba.H = height; ba.gx = gx; ba.gy = gy; ba.fx = fx; ba.fy = fy; ba.bg = background;
@@ -515,15 +530,19 @@ extern "C" int igs_refine_step(const igs_refine_step_args* a)
     f.loss_shards = nullptr; f.loss_out = a->loss_out; f.loss_scale = a->loss_weight / (float)(3 * HW);
     const float l1_scale = a->loss_weight / (float)(3 * HW);
 
+    prof_new_frame();
     for (int attempt = 0; attempt < 2; attempt++) {
         g_pending.active = false;
+        f.prezeroed = 1;
+        g_zero_gacc = (float*)align_ptr((const char*)a->workspace);
+        g_zero_loss = (float*)((char*)g_zero_gacc + ws_gacc_bytes(a->P));
         g_async_request = attempt == 0;            // second attempt: synchronous forward, which sorts out its scratch sizes itself
         g_raw_activations = true;
         const int R = forward_impl(a->stream, capture_alloc, &cg, capture_alloc, &cb, capture_alloc, &ci, a->P, a->D, a->M, a->background,
                                    a->width, a->height, xyz, shs, nullptr, opac, scal, 1.0f, rotn, nullptr, a->viewmatrix, a->projmatrix,
                                    a->cam_pos, a->tan_fovx, a->tan_fovy, 0.0f, 0, color, coord, mcoord, depth, mdepth, alpha, normal,
                                    a->radii, a->require_coord, a->require_depth, 0, false, 0);
-        g_async_request = false; g_raw_activations = false;
+        g_async_request = false; g_raw_activations = false; g_zero_gacc = nullptr; g_zero_loss = nullptr;
         if (R < 0) return R;
         f.guard_overflow = g_last_fwd.overflow; f.guard_prefilter = g_last_fwd.prefilter;
         const int rc = backward_impl(a->stream, a->P, a->D, a->M, R, a->background, a->width, a->height, xyz, shs, nullptr, alpha, scal, 1.0f,

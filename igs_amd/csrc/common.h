@@ -108,6 +108,7 @@ struct FwdParams {
     float scale_modifier, tan_fovx, tan_fovy, fx, fy, kernel_size;
     int prefiltered;
     const float *view, *proj, *campos;      // device pointers (transposed 4x4 matrices, camera centre)
+    float* zero_gacc; float* zero_loss;     // refine step: backward accumulators to zero-fill on the side (NULL = no)
     int raw_activations;                    // refine step: opacities / scales / rotations are the raw optimiser leaves
                                             // (sigmoid / exp / normalize applied here: gaussian_model.py:90-127)
 };
@@ -178,6 +179,7 @@ struct RefineFuse {
     float b1, b2, eps, inv_sqrt_bc2;
     const uint32_t *guard_overflow, *guard_prefilter;                      // nonzero = the frame is invalid: touch nothing
     const float* loss_shards; float* loss_out; float loss_scale;           // loss_out[0] = loss_scale * sum of the 64 shards
+    int prezeroed;                                                         // the accumulators were zero-filled by the forward
 };
 hipError_t launch_geom_bwd_adam(hipStream_t s, const GeomBwdArgs& a, const RefineFuse& f);
 

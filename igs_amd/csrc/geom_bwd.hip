@@ -74,8 +74,8 @@ __device__ __forceinline__ float3 sh_backward(int deg, int M, const float* __res
 
 struct GBArgs { GeomBwdArgs a; RefineFuse f; };
 
-template <bool FUSED>
-__global__ void __launch_bounds__(256)
+template <bool FUSED, int NT>
+__global__ void __launch_bounds__(NT)
 geom_bwd_kernel(const GBArgs args)
 {
     const GeomBwdArgs& a = args.a;
@@ -89,7 +89,7 @@ geom_bwd_kernel(const GBArgs args)
             if (threadIdx.x == 0) fz.loss_out[0] = v * fz.loss_scale;
         }
     }
-    const int idx = blockIdx.x * 256 + threadIdx.x;
+    const int idx = blockIdx.x * NT + threadIdx.x;
     // dL_dsh rows are staged in LDS ((3M+1)-float padded rows) and written out with coalesced stores at the end
     extern __shared__ __attribute__((aligned(16))) float dsh_lds[];
     const int F = 3 * a.M, FS = F + 1;
@@ -424,8 +424,8 @@ geom_bwd_kernel(const GBArgs args)
     }
     if (a.M) {
         __syncthreads();
-        const int g0 = blockIdx.x * 256;
-        const int ng = min(256, a.P - g0);
+        const int g0 = blockIdx.x * NT;
+        const int ng = min(NT, a.P - g0);
         const int total = ng * F;
         float* dst = FUSED ? fz.param + fz.off_sh + (size_t)g0 * F : a.dL_dsh + (size_t)g0 * F;
         float* dst_m = FUSED ? fz.exp_avg + fz.off_sh + (size_t)g0 * F : nullptr;
@@ -436,11 +436,11 @@ geom_bwd_kernel(const GBArgs args)
             const int total4 = total >> 2;
             int f = (int)threadIdx.x * 4;
             int g = f / F, k = f - g * F;
-            const int dg = 1024 / F, dk = 1024 - dg * F;
-            for (int i = threadIdx.x; i < total4; i += 256) {
+            const int dg = (4 * NT) / F, dk = (4 * NT) - dg * F;
+            for (int i = threadIdx.x; i < total4; i += NT) {
                 const float* sp = dsh_lds + g * FS + k;
                 if constexpr (FUSED) {
-                    // Adam on the SH coefficients of the workgroup's 256 Gaussians: one contiguous, coalesced span of each buffer
+                    // Adam on the SH coefficients of the workgroup's NT Gaussians: one contiguous, coalesced span of each buffer
                     float4 P4 = ((float4*)dst)[i], M4 = ((float4*)dst_m)[i], V4 = ((float4*)dst_v)[i];
                     adam_update(P4.x, M4.x, V4.x, sp[0], fz.lr_sh, fz.b1, fz.b2, fz.eps, fz.inv_sqrt_bc2);
                     adam_update(P4.y, M4.y, V4.y, sp[1], fz.lr_sh, fz.b1, fz.b2, fz.eps, fz.inv_sqrt_bc2);
@@ -456,8 +456,8 @@ geom_bwd_kernel(const GBArgs args)
         } else {
             int f = (int)threadIdx.x;
             int g = f / F, k = f - g * F;
-            const int dg = 256 / F, dk = 256 - dg * F;
-            for (int i = threadIdx.x; i < total; i += 256) {
+            const int dg = NT / F, dk = NT - dg * F;
+            for (int i = threadIdx.x; i < total; i += NT) {
                 if constexpr (FUSED) {
                     float p = dst[i], m = dst_m[i], v = dst_v[i];
                     adam_update(p, m, v, dsh_lds[g * FS + k], fz.lr_sh, fz.b1, fz.b2, fz.eps, fz.inv_sqrt_bc2);
@@ -476,13 +476,19 @@ hipError_t launch_geom_bwd(hipStream_t s, const GeomBwdArgs& a)
 {
     GBArgs g; g.a = a; g.f = RefineFuse();
     const size_t lds = a.M ? (size_t)256 * (3 * a.M + 1) * sizeof(float) : 0;
-    hipLaunchKernelGGL(geom_bwd_kernel<false>, dim3((a.P + 255) / 256), dim3(256), lds, s, g);
+    hipLaunchKernelGGL((geom_bwd_kernel<false, 256>), dim3((a.P + 255) / 256), dim3(256), lds, s, g);
     return hipGetLastError();
 }
+// The fused kernel alternates a latency-bound phase (per-Gaussian math) with a bandwidth-bound one (Adam over the SH span):
+// small workgroups put more of them on a CU (LDS: 49 floats per thread), so the two phases of different workgroups overlap.
+#ifndef GEOM_ADAM_THREADS
+#define GEOM_ADAM_THREADS 64
+#endif
 hipError_t launch_geom_bwd_adam(hipStream_t s, const GeomBwdArgs& a, const RefineFuse& f)
 {
     GBArgs g; g.a = a; g.f = f;
-    const size_t lds = a.M ? (size_t)256 * (3 * a.M + 1) * sizeof(float) : 0;
-    hipLaunchKernelGGL(geom_bwd_kernel<true>, dim3((a.P + 255) / 256), dim3(256), lds, s, g);
+    constexpr int NT = GEOM_ADAM_THREADS;
+    const size_t lds = a.M ? (size_t)NT * (3 * a.M + 1) * sizeof(float) : 0;
+    hipLaunchKernelGGL((geom_bwd_kernel<true, NT>), dim3((a.P + NT - 1) / NT), dim3(NT), lds, s, g);
     return hipGetLastError();
 }
