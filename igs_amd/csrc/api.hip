@@ -78,7 +78,7 @@ static void prof_mark(hipStream_t s, int tag)
 extern "C" int igs_rast_profile_enable(int on)
 {
     if (!on) prof_collect();
-    g_prof.on = on != 0; g_prof.every = on > 0 ? on : 1; g_prof.frame = 0; g_prof.active = false;
+    g_prof.on = on != 0; g_prof.every = on > 0 ? on : 1; g_prof.frame = 0; g_prof.active = g_prof.on;
     return 0;
 }
 static void prof_new_frame() { if (g_prof.on) { g_prof.active = (g_prof.frame % g_prof.every) == 0; g_prof.frame++; } }
@@ -452,8 +452,9 @@ static int backward_impl(
     ba.dL_dmdepth = dL_dpix_mdepth; ba.dL_dalpha = dL_dalphas; ba.dL_dnormal = dL_dpixel_normals;
     ba.gacc = gacc;
     ba.l1_gt = l1_gt; ba.l1_color = l1_color; ba.l1_scale = l1_scale; ba.l1_loss = loss_shards;
+    bool gacc_compact = false;
     if (R > 0) {
-        HIP_TRY(launch_blend_bwd(s, ba, require_coord != 0, require_depth != 0), "blend_bwd launch");
+        HIP_TRY(launch_blend_bwd(s, ba, require_coord != 0, require_depth != 0, &gacc_compact), "blend_bwd launch");
         DBG_SYNC("blend_bwd");
         prof_mark(s, ST_BLEND_BWD);
     }
@@ -463,7 +464,7 @@ static int backward_impl(
     ga.radii = radii; ga.scale_modifier = scale_modifier; ga.tan_fovx = tan_fovx; ga.tan_fovy = tan_fovy;
     ga.fx = fx; ga.fy = fy; ga.kernel_size = kernel_size;
     ga.view = viewmatrix; ga.proj = projmatrix; ga.campos = campos;
-    ga.rec = ba.rec; ga.gacc = gacc;
+    ga.rec = ba.rec; ga.gacc = gacc; ga.gacc_compact = gacc_compact ? 1 : 0;
     ga.dL_dmean2D = dL_dmean2D; ga.dL_dcolor = dL_dcolor; ga.dL_dopacity = dL_dopacity; ga.dL_dmean3D = dL_dmean3D;
     ga.dL_dcov3D = dL_dcov3D; ga.dL_dsh = dL_dsh; ga.dL_dscale = dL_dscale; ga.dL_drot = dL_drot;
     if (fuse) {

@@ -20,7 +20,6 @@
 #include "blend_common.h"
 
 #define BCHUNK 128            // splats staged per round in the backward (LDS is shared with the reduction scratch)
-#define RED_STRIDE 68         // floats per row of the per-wave transpose buffer: 16-byte aligned rows, conflict-free b128 reads
 
 // gacc slots (raw moments), see geom_bwd.hip for how they are combined:
 //  0..2  sum w*dL/dpix_ch            3..5  Sv = sum dLc_ch          6..8 Sx = sum dLc_ch*dx     9..11 Sy = sum dLc_ch*dy
@@ -36,7 +35,11 @@ blend_bwd_kernel(const BlendBwdArgs a)
     __shared__ uint32_t chunk_id[BCHUNK];
     __shared__ uint64_t quad_bits[4][2];                // [quad][staging wave pair]: BCHUNK = 2 x 64 splats
     __shared__ int wave_max[4];
-    __shared__ __attribute__((aligned(16))) float red[4][GA_USED * RED_STRIDE];
+    constexpr int NROWS = 10 + (COORD ? 9 : 0) + (DEPTH ? 3 : 0) + (NORMAL ? 3 : 0);   // live moments of this instance
+    // floats per row of the per-wave transpose buffer: 16-byte aligned rows, row starts spread over all banks for the b128 reads
+    // (16 rows x 4 banks), and rows r, r+1 -- which the compiler pairs into one ds_write2_b32 -- 36 banks apart instead of 4
+    constexpr int RED_STRIDE = NROWS <= 16 ? 100 : 68;
+    __shared__ __attribute__((aligned(16))) float red[4][NROWS * RED_STRIDE];
 
     uint32_t tile;
     if (!tile_for_block(blockIdx.x, a.gx, a.gy, tile)) return;
@@ -127,14 +130,16 @@ blend_bwd_kernel(const BlendBwdArgs a)
     const bool has_bg = (a.bg[0] != 0.f) || (a.bg[1] != 0.f) || (a.bg[2] != 0.f);      // wave-uniform
     const float halfW = 0.5f * a.W, halfH = 0.5f * a.H;
     float* myred = red[wid];
-    constexpr int NROWS = 10 + (COORD ? 9 : 0) + (DEPTH ? 3 : 0) + (NORMAL ? 3 : 0);   // live moments of this instance
     constexpr int LPR = NROWS <= 16 ? 4 : 2;             // lanes per row of the transpose buffer
     const int rrow = lane & (64 / LPR - 1), rpart = lane / (64 / LPR);
     // gacc slot of compact row `lane` (rows are emitted in slot order with the dead groups left out)
+    // (the colour-only instance packs its 10 moments into slots 0..9 instead: one 64-byte atomic request per row, not two --
+    //  float atomics execute at the memory side in 64-byte requests, ~20 G requests/s for the whole chip)
     int slot_of_row = (int)lane;
-    if (!COORD && slot_of_row >= 3) slot_of_row += 9;
-    if (!DEPTH && slot_of_row >= 12) slot_of_row += 3;
-    if (!NORMAL && slot_of_row >= 15) slot_of_row += 3;
+    constexpr bool COMPACT = !COORD && !DEPTH && !NORMAL;
+    if (!COMPACT && !COORD && slot_of_row >= 3) slot_of_row += 9;
+    if (!COMPACT && !DEPTH && slot_of_row >= 12) slot_of_row += 3;
+    if (!COMPACT && !NORMAL && slot_of_row >= 15) slot_of_row += 3;
 
     for (int i = 0; i < rounds; i++) {
         __syncthreads();
@@ -251,7 +256,7 @@ blend_bwd_kernel(const BlendBwdArgs a)
     }
 }
 
-hipError_t launch_blend_bwd(hipStream_t s, const BlendBwdArgs& a, bool coord, bool depth)
+hipError_t launch_blend_bwd(hipStream_t s, const BlendBwdArgs& a, bool coord, bool depth, bool* compact_layout)
 {
     const dim3 grid(tile_grid_blocks(a.gx, a.gy)), block(256);
     // The reference instantiates (COORD, DEPTH, NORMAL) from require_coord / require_depth alone (backward.cu:1153-1160).
@@ -261,6 +266,7 @@ hipError_t launch_blend_bwd(hipStream_t s, const BlendBwdArgs& a, bool coord, bo
     const bool C = coord && (a.dL_dcoord || a.dL_dmcoord);
     const bool D = depth && (a.dL_ddepth || a.dL_dmdepth);
     const bool N = (coord || depth) && a.dL_dnormal;
+    if (compact_layout) *compact_layout = !C && !D && !N;
 #define LAUNCH(c, d, n) hipLaunchKernelGGL((blend_bwd_kernel<c, d, n>), grid, block, 0, s, a)
     if (C) { if (D) { if (N) LAUNCH(true, true, true); else LAUNCH(true, true, false); }
              else   { if (N) LAUNCH(true, false, true); else LAUNCH(true, false, false); } }

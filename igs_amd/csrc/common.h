@@ -157,7 +157,7 @@ struct BlendBwdArgs {
     // refine step: L1 loss fused in -- dL_dpix = l1_scale * sign(l1_color - l1_gt), sum |l1_color - l1_gt| -> 64 shards l1_loss[16*s]
     const float *l1_color, *l1_gt; float l1_scale; float* l1_loss;
 };
-hipError_t launch_blend_bwd(hipStream_t s, const BlendBwdArgs& a, bool coord, bool depth);
+hipError_t launch_blend_bwd(hipStream_t s, const BlendBwdArgs& a, bool coord, bool depth, bool* compact_layout);
 
 struct GeomBwdArgs {
     int P, D, M, W, H;
@@ -165,6 +165,7 @@ struct GeomBwdArgs {
     float scale_modifier, tan_fovx, tan_fovy, fx, fy, kernel_size;
     const float *view, *proj, *campos;
     const float* rec; const float* gacc;
+    int gacc_compact;                       // gacc rows hold {colour 3, Q0, Qx, Qy, Qxx, Qxy, Qyy, Z} in slots 0..9 (colour-only blend instance)
     float *dL_dmean2D, *dL_dcolor, *dL_dopacity, *dL_dmean3D, *dL_dcov3D, *dL_dsh, *dL_dscale, *dL_drot;
 };
 hipError_t launch_geom_bwd(hipStream_t s, const GeomBwdArgs& a);

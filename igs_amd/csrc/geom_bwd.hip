@@ -105,7 +105,16 @@ geom_bwd_kernel(const GBArgs args)
         const float4* R4 = (const float4*)(a.rec + (size_t)idx * REC_F);
         const float4* G4 = (const float4*)(a.gacc + (size_t)idx * GACC_F);
         const float4 r0 = R4[0], r1 = R4[1], r2 = R4[2], r4 = R4[4], r5 = R4[5], r6 = R4[6], r7 = R4[7];
-        const float4 g0 = G4[0], g1 = G4[1], g2 = G4[2], g3 = G4[3], g4 = G4[4], g5 = G4[5], g6 = G4[6];
+        float4 g0, g1, g2, g3, g4, g5, g6;
+        if (a.gacc_compact) {
+            // colour-only blend instance: {c0 c1 c2 Q0} {Qx Qy Qxx Qxy} {Qyy Z - -}; every plane / depth / normal moment is zero
+            const float4 c0 = G4[0], c1 = G4[1], c2 = G4[2];
+            const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+            g0 = make_float4(c0.x, c0.y, c0.z, 0.f); g1 = z; g2 = z; g3 = z;
+            g4 = make_float4(0.f, 0.f, c0.w, c1.x); g5 = make_float4(c1.y, c1.z, c1.w, c2.x); g6 = make_float4(c2.y, 0.f, 0.f, 0.f);
+        } else {
+            g0 = G4[0]; g1 = G4[1]; g2 = G4[2]; g3 = G4[3]; g4 = G4[4]; g5 = G4[5]; g6 = G4[6];
+        }
         // ---- unpack raw moments ----
         o_color = make_float3(g0.x, g0.y, g0.z);
         const float Sv0 = g0.w, Sv1 = g1.x, Sv2 = g1.y;
