@@ -89,7 +89,11 @@ geom_bwd_kernel(const GBArgs args)
             if (threadIdx.x == 0) fz.loss_out[0] = v * fz.loss_scale;
         }
     }
-    const int idx = blockIdx.x * NT + threadIdx.x;
+    // a workgroup walks groups of NT Gaussians (grid-stride): with fewer workgroups than groups, the workgroups of a CU drift
+    // apart after their first group, so the latency-bound per-Gaussian phase of one overlaps the streaming Adam phase of another
+    const int ngroups = (a.P + NT - 1) / NT;
+    for (int grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+    const int idx = grp * NT + threadIdx.x;
     // dL_dsh rows are staged in LDS ((3M+1)-float padded rows) and written out with coalesced stores at the end
     extern __shared__ __attribute__((aligned(16))) float dsh_lds[];
     const int F = 3 * a.M, FS = F + 1;
@@ -433,7 +437,7 @@ geom_bwd_kernel(const GBArgs args)
     }
     if (a.M) {
         __syncthreads();
-        const int g0 = blockIdx.x * NT;
+        const int g0 = grp * NT;
         const int ng = min(NT, a.P - g0);
         const int total = ng * F;
         float* dst = FUSED ? fz.param + fz.off_sh + (size_t)g0 * F : a.dL_dsh + (size_t)g0 * F;
@@ -479,6 +483,8 @@ geom_bwd_kernel(const GBArgs args)
             }
         }
     }
+    if (grp + (int)gridDim.x < ngroups) __syncthreads();          // the LDS rows are reused by the next group
+    }
 }
 
 hipError_t launch_geom_bwd(hipStream_t s, const GeomBwdArgs& a)
@@ -493,11 +499,17 @@ hipError_t launch_geom_bwd(hipStream_t s, const GeomBwdArgs& a)
 #ifndef GEOM_ADAM_THREADS
 #define GEOM_ADAM_THREADS 64
 #endif
+#ifndef GEOM_ADAM_BLOCKS
+#define GEOM_ADAM_BLOCKS (1 << 30)     // (capping the grid was measured: at 12 waves per CU by LDS every group is resident at once anyway, fewer workgroups only lose occupancy)
+#endif
 hipError_t launch_geom_bwd_adam(hipStream_t s, const GeomBwdArgs& a, const RefineFuse& f)
 {
     GBArgs g; g.a = a; g.f = f;
     constexpr int NT = GEOM_ADAM_THREADS;
     const size_t lds = a.M ? (size_t)NT * (3 * a.M + 1) * sizeof(float) : 0;
-    hipLaunchKernelGGL((geom_bwd_kernel<true, NT>), dim3((a.P + NT - 1) / NT), dim3(NT), lds, s, g);
+    int blocks = (a.P + NT - 1) / NT;
+    const int cap = GEOM_ADAM_BLOCKS;
+    if (blocks > cap) blocks = cap;
+    hipLaunchKernelGGL((geom_bwd_kernel<true, NT>), dim3(blocks), dim3(NT), lds, s, g);
     return hipGetLastError();
 }
