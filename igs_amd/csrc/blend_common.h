@@ -64,98 +64,6 @@ __device__ __forceinline__ uint32_t quad_reach_mask(float4 q0, float4 q1, float 
     return m;
 }
 
-// The same decision for the sixteen 4x4 pixel blocks of a tile: bit b = by * 4 + bx.  The blend kernels give every 16-lane
-// group of a wave its own block and its own splat list, so the finer the culling the fewer lanes idle: on the bench scene a
-// splat reaches 2.3 blocks on average, and the longest of a wave's four lists is 0.62x the list of its whole 8x8 quad.
-// Per-axis terms are shared between the blocks (14 VALU per block on top).
-__device__ __forceinline__ uint32_t block_reach_mask(float4 q0, float4 q1, float tile_x0, float tile_y0)
-{
-    const float o = q1.y;
-    if (o < (1.0f / 255.0f)) return 0u;
-    const float cx = q0.z, cy = q0.w, cz = q1.x;
-    const float det = cx * cz - cy * cy;
-    if (!(det > 0.f) || !(cx > 0.f) || !(cz > 0.f) || !(det < 3.0e38f)) return 0xFFFFu;
-    const float two_tau = 2.0f * __logf(255.0f * o) * 1.002f + 1e-3f;
-    if (!(two_tau < 3.0e38f)) return 0xFFFFu;
-    const float inv = 1.0f / det;
-    const float ex = sqrtf(two_tau * cz * inv) * 1.001f + 0.02f;
-    const float ey = sqrtf(two_tau * cx * inv) * 1.001f + 0.02f;
-    if (!(ex < 3.0e38f) || !(ey < 3.0e38f)) return 0xFFFFu;
-    const float lx = q0.x - ex - tile_x0, hx = q0.x + ex - tile_x0;
-    const float ly = q0.y - ey - tile_y0, hy = q0.y + ey - tile_y0;
-    uint32_t xm = 0u, ym = 0u;
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-        xm |= ((hx >= (float)(4 * k)) && (lx <= (float)(4 * k + 3))) ? (1u << k) : 0u;
-        ym |= ((hy >= (float)(4 * k)) && (ly <= (float)(4 * k + 3))) ? (1u << k) : 0u;
-    }
-    if (xm == 0u || ym == 0u) return 0u;
-    const float nbc = -cy / cz, nba = -cy / cx, cy2 = 2.0f * cy;
-    const float bx0 = (tile_x0 - 0.02f) - q0.x, by0 = (tile_y0 - 0.02f) - q0.y;
-    float xl[4], xh[4], t1[4], e1[4], f1[4], yl[4], yh[4], t2[4], e2[4], f2[4];
-    bool xin[4], yin[4];
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-        xl[k] = bx0 + (float)(4 * k); xh[k] = xl[k] + 3.04f; xin[k] = (xl[k] <= 0.f) && (xh[k] >= 0.f);
-        const float fx = xl[k] > 0.f ? xl[k] : xh[k];
-        t1[k] = nbc * fx; e1[k] = cx * fx * fx; f1[k] = cy2 * fx;
-        yl[k] = by0 + (float)(4 * k); yh[k] = yl[k] + 3.04f; yin[k] = (yl[k] <= 0.f) && (yh[k] >= 0.f);
-        const float fy = yl[k] > 0.f ? yl[k] : yh[k];
-        t2[k] = nba * fy; e2[k] = cz * fy * fy; f2[k] = cy2 * fy;
-    }
-    uint32_t m = 0u;
-#pragma unroll
-    for (int by = 0; by < 4; by++) {
-#pragma unroll
-        for (int bx = 0; bx < 4; bx++) {
-            const float dyv = fminf(fmaxf(t1[bx], yl[by]), yh[by]);
-            const float qv = e1[bx] + (f1[bx] + cz * dyv) * dyv;
-            const float dxh = fminf(fmaxf(t2[by], xl[bx]), xh[bx]);
-            const float qh = e2[by] + (f2[by] + cx * dxh) * dxh;
-            float qmin = 3.0e38f;
-            if (!xin[bx]) qmin = qv;
-            if (!yin[by]) qmin = fminf(qmin, qh);
-            if (xin[bx] && yin[by]) qmin = 0.f;
-            const bool keep = ((xm >> bx) & (ym >> by) & 1u) && !(qmin > two_tau);        // (a NaN keeps the block)
-            m |= keep ? (1u << (by * 4 + bx)) : 0u;
-        }
-    }
-    return m;
-}
-
-// Builds the 16 per-block splat lists of one staged chunk (`bmask` = block_reach_mask of the splat this thread staged, 0 if
-// none).  lists[b][0..len_b) = chunk indices in staging order; wcount is scratch.  Contains two workgroup barriers; on return
-// every thread may read lists / the returned length of block `my_block`.
-__device__ __forceinline__ uint32_t build_block_lists(uint32_t bmask, uint32_t tid, uint32_t my_block, uint8_t (*lists)[CHUNK],
-                                                      uint16_t (*wcount)[16])
-{
-    const uint32_t lane = tid & 63, wid = tid >> 6;
-    uint64_t bal[16];
-#pragma unroll
-    for (int b = 0; b < 16; b++) bal[b] = __ballot((bmask >> b) & 1u);
-    if (lane < 16) {
-        uint32_t c = 0;
-#pragma unroll
-        for (int b = 0; b < 16; b++) c = (lane == (uint32_t)b) ? (uint32_t)__popcll(bal[b]) : c;
-        wcount[wid][lane] = (uint16_t)c;
-    }
-    __syncthreads();
-    // lane b < 16 of every wave: where this wave's entries of block b start
-    uint32_t off = 0;
-    if (lane < 16) { for (uint32_t w = 0; w < wid; w++) off += wcount[w][lane]; }
-#pragma unroll
-    for (int b = 0; b < 16; b++) {
-        const uint32_t base = (uint32_t)__builtin_amdgcn_readlane((int)off, b);
-        if ((bmask >> b) & 1u) {
-            const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(bal[b] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal[b], 0u));
-            lists[b][base + below] = (uint8_t)tid;
-        }
-    }
-    const uint32_t len = (uint32_t)wcount[0][my_block] + wcount[1][my_block] + wcount[2][my_block] + wcount[3][my_block];
-    __syncthreads();
-    return len;
-}
-
 // wave-uniform copy of a 64-bit value (readfirstlane returns a SIGNED int: widen through uint32_t, not int)
 __device__ __forceinline__ uint64_t uniform64(uint64_t v)
 {
