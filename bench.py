@@ -163,7 +163,7 @@ def main():
         if stages and calls:
             R_avg = r_sum / calls
             geo_bwd = args.loss != "l1" and False      # both losses only see the colour image: geometry gradients are absent
-            fused = world == 1 and args.loss == "l1"      # single GPU: igs_refine_step (L1 inside blend_bwd, Adam inside geom_bwd)
+            fused = world == 1 and args.loss == "l1"      # single GPU + pure L1: the loss is evaluated inside blend_bwd (reads colour + gt)
             ab = algorithmic_bytes(R_avg, args.width, args.height, True, True, geo_bwd, geo_bwd, geo_bwd, l1_fused=fused)
             per = {k: (ms / cnt if cnt else 0.0) for k, (ms, cnt) in stages.items()}
             dom = "blend_bwd" if per.get("blend_bwd", 0) >= per.get("blend_fwd", 0) else "blend_fwd"

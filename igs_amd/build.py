@@ -10,7 +10,10 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libigs_rast.so")
-SOURCES = ["api.hip", "preprocess.hip", "sort.hip", "blend_fwd.hip", "blend_bwd.hip", "geom_bwd.hip", "refine_ops.hip"]
+# files whose inner loops are independent FMA streams: let the SLP vectorizer form v_pk_fma_f32 (2 FMAs per lane and instruction);
+# everywhere else packing only added register moves
+SLP_OK = {"loss_ops.hip"}
+SOURCES = ["api.hip", "preprocess.hip", "sort.hip", "blend_fwd.hip", "blend_bwd.hip", "geom_bwd.hip", "refine_ops.hip", "loss_ops.hip"]
 # -fno-slp-vectorize: on gfx950 v_pk_*_f32 runs at the scalar-f32 rate per element, so SLP packing only adds v_mov shuffles
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-Wno-unused-variable",
          "-fno-slp-vectorize"]
@@ -45,7 +48,8 @@ def build(force=False, verbose=False):
             continue
         obj = os.path.join(objdir, src.replace(".hip", ".o"))
         objs.append(obj)
-        cmd = [hipcc] + FLAGS + os.environ.get("IGS_EXTRA_FLAGS", "").split() + ["-c", path, "-o", obj]
+        flags = [f for f in FLAGS if not (f == "-fno-slp-vectorize" and src in SLP_OK)]
+        cmd = [hipcc] + flags + os.environ.get("IGS_EXTRA_FLAGS", "").split() + ["-c", path, "-o", obj]
         if verbose:
             print(" ".join(cmd))
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))

@@ -110,6 +110,7 @@ static thread_local bool g_async_request = false;
 static thread_local bool g_raw_activations = false;       // set by igs_refine_step around its forward
 static thread_local float* g_zero_gacc = nullptr;         // ... workspace accumulators the forward zero-fills on the side
 static thread_local float* g_zero_loss = nullptr;
+static thread_local float* g_zero_loss2 = nullptr;
 // where the last slab-binned forward left its device-side validity words (refine step guards)
 struct LastFwd { const uint32_t* overflow = nullptr; const uint32_t* prefilter = nullptr; };
 static thread_local LastFwd g_last_fwd;
@@ -169,7 +170,7 @@ static int forward_impl(
     fp.kernel_size = kernel_size; fp.prefiltered = prefiltered;
     fp.view = viewmatrix; fp.proj = projmatrix; fp.campos = cam_pos;
     fp.raw_activations = g_raw_activations ? 1 : 0;
-    fp.zero_gacc = g_zero_gacc; fp.zero_loss = g_zero_loss;
+    fp.zero_gacc = g_zero_gacc; fp.zero_loss = g_zero_loss; fp.zero_loss2 = g_zero_loss2;
     g_last_fwd = LastFwd();
 
     const size_t counter_bytes = (COUNTER_SHARDS + 1) * COUNTER_SHARD_STRIDE * 4;
@@ -469,7 +470,7 @@ static int backward_impl(
     ga.dL_dcov3D = dL_dcov3D; ga.dL_dsh = dL_dsh; ga.dL_dscale = dL_dscale; ga.dL_drot = dL_drot;
     if (fuse) {
         RefineFuse f = *fuse;
-        f.loss_shards = loss_shards;
+        if (!f.loss_shards) f.loss_shards = loss_shards;
         HIP_TRY(launch_geom_bwd_adam(s, ga, f), "geom_bwd_adam launch");
     } else {
         HIP_TRY(launch_geom_bwd(s, ga), "geom_bwd launch");
@@ -506,6 +507,12 @@ extern "C" int igs_rast_backward(
 struct ScratchCapture { igs_rast_alloc_fn fn; void* user; char* last; };
 static char* capture_alloc(void* user, size_t n) { ScratchCapture* c = (ScratchCapture*)user; c->last = c->fn(c->user, n); return c->last; }
 
+extern "C" size_t igs_refine_loss_scratch_bytes(int width, int height)
+{
+    const size_t HW = (size_t)(width > 0 ? width : 0) * (size_t)(height > 0 ? height : 0);
+    return ((igs_ssim_l1_scratch_bytes(width, height) + 255) & ~(size_t)255) + 3 * HW * 4 + 256;
+}
+
 extern "C" int igs_refine_step(const igs_refine_step_args* a)
 {
     if (!a) return fail(IGS_RAST_E_INVALID, "igs_refine_step: NULL args");
@@ -528,29 +535,54 @@ extern "C" int igs_refine_step(const igs_refine_step_args* a)
     f.lr_xyz = (float)(a->lr_xyz / bc1); f.lr_rot = (float)(a->lr_rot / bc1); f.lr_sh = (float)(a->lr_sh / bc1);
     f.lr_opacity = (float)(a->lr_opacity / bc1); f.lr_scale = (float)(a->lr_scale / bc1);
     f.b1 = a->beta1; f.b2 = a->beta2; f.eps = a->eps; f.inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
-    f.loss_shards = nullptr; f.loss_out = a->loss_out; f.loss_scale = a->loss_weight / (float)(3 * HW);
-    const float l1_scale = a->loss_weight / (float)(3 * HW);
+    const float inv_n = 1.0f / (float)(3 * HW);
+    const bool dssim = a->lambda_dssim > 0.f;
+    if (dssim && !a->loss_scratch) return fail(IGS_RAST_E_INVALID, "igs_refine_step: lambda_dssim > 0 needs loss_scratch");
+    // scratch of the SSIM mode: { loss kernels' own scratch (maps + 2 x 64 shards) | dL/dcolor [3][H][W] }
+    float* ssim_shards = nullptr; float* grad_img = nullptr;
+    if (dssim) {
+        const size_t own = (igs_ssim_l1_scratch_bytes(a->width, a->height) + 255) & ~(size_t)255;
+        ssim_shards = (float*)((char*)a->loss_scratch + (((size_t)9 * HW * 4 + 255) & ~(size_t)255));
+        grad_img = (float*)((char*)a->loss_scratch + own);
+    }
+    f.loss_out = a->loss_out; f.loss_shards2 = nullptr; f.loss_bias = 0.f; f.loss_scale2 = 0.f;
+    if (dssim) {          // loss = lambda w (1 - mean ssim) + (1 - lambda) w mean|d|
+        f.loss_shards = ssim_shards; f.loss_scale = -a->lambda_dssim * a->loss_weight * inv_n;
+        f.loss_shards2 = ssim_shards + 1024; f.loss_scale2 = (1.f - a->lambda_dssim) * a->loss_weight * inv_n;
+        f.loss_bias = a->lambda_dssim * a->loss_weight;
+    } else {
+        f.loss_shards = nullptr; f.loss_scale = a->loss_weight * inv_n;
+    }
+    const float l1_scale = a->loss_weight * inv_n;
 
     prof_new_frame();
     for (int attempt = 0; attempt < 2; attempt++) {
         g_pending.active = false;
         f.prezeroed = 1;
         g_zero_gacc = (float*)align_ptr((const char*)a->workspace);
-        g_zero_loss = (float*)((char*)g_zero_gacc + ws_gacc_bytes(a->P));
+        g_zero_loss = dssim ? ssim_shards : (float*)((char*)g_zero_gacc + ws_gacc_bytes(a->P));
+        g_zero_loss2 = dssim ? ssim_shards + 1024 : nullptr;
         g_async_request = attempt == 0;            // second attempt: synchronous forward, which sorts out its scratch sizes itself
         g_raw_activations = true;
         const int R = forward_impl(a->stream, capture_alloc, &cg, capture_alloc, &cb, capture_alloc, &ci, a->P, a->D, a->M, a->background,
                                    a->width, a->height, xyz, shs, nullptr, opac, scal, 1.0f, rotn, nullptr, a->viewmatrix, a->projmatrix,
                                    a->cam_pos, a->tan_fovx, a->tan_fovy, 0.0f, 0, color, coord, mcoord, depth, mdepth, alpha, normal,
                                    a->radii, a->require_coord, a->require_depth, 0, false, 0);
-        g_async_request = false; g_raw_activations = false; g_zero_gacc = nullptr; g_zero_loss = nullptr;
+        g_async_request = false; g_raw_activations = false; g_zero_gacc = nullptr; g_zero_loss = nullptr; g_zero_loss2 = nullptr;
         if (R < 0) return R;
         f.guard_overflow = g_last_fwd.overflow; f.guard_prefilter = g_last_fwd.prefilter;
+        if (dssim) {
+            prof_mark((hipStream_t)a->stream, ST_GAP);
+            if (launch_ssim_l1((hipStream_t)a->stream, a->width, a->height, color, a->gt, a->lambda_dssim, a->loss_weight, a->loss_scratch,
+                               grad_img, false) != hipSuccess)
+                return fail(IGS_RAST_E_HIP, "ssim loss launch");
+            prof_mark((hipStream_t)a->stream, ST_MEMSET);          // (the stage slot the fused step does not otherwise use: "loss")
+        }
         const int rc = backward_impl(a->stream, a->P, a->D, a->M, R, a->background, a->width, a->height, xyz, shs, nullptr, alpha, scal, 1.0f,
                                      rotn, nullptr, a->viewmatrix, a->projmatrix, a->cam_pos, a->tan_fovx, a->tan_fovy, 0.0f, a->radii,
-                                     normal, cg.last, cb.last, ci.last, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
-                                     a->workspace, a->dL_dmean2D, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
-                                     a->require_coord, a->require_depth, 0, a->gt, color, l1_scale, &f);
+                                     normal, cg.last, cb.last, ci.last, dssim ? grad_img : nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
+                                     nullptr, a->workspace, a->dL_dmean2D, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
+                                     a->require_coord, a->require_depth, 0, dssim ? nullptr : a->gt, color, l1_scale, &f);
         if (rc < 0) return rc;
         if (!g_pending.active) return R;           // synchronous forward: R is already the true count
         const int Rt = igs_rast_forward_finish();

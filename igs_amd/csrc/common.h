@@ -108,7 +108,7 @@ struct FwdParams {
     float scale_modifier, tan_fovx, tan_fovy, fx, fy, kernel_size;
     int prefiltered;
     const float *view, *proj, *campos;      // device pointers (transposed 4x4 matrices, camera centre)
-    float* zero_gacc; float* zero_loss;     // refine step: backward accumulators to zero-fill on the side (NULL = no)
+    float* zero_gacc; float* zero_loss; float* zero_loss2;     // refine step: backward accumulators / loss shards to zero-fill on the side (NULL = no)
     int raw_activations;                    // refine step: opacities / scales / rotations are the raw optimiser leaves
                                             // (sigmoid / exp / normalize applied here: gaussian_model.py:90-127)
 };
@@ -179,10 +179,14 @@ struct RefineFuse {
     float lr_xyz, lr_rot, lr_sh, lr_opacity, lr_scale;                     // lr / bias_correction1 per group
     float b1, b2, eps, inv_sqrt_bc2;
     const uint32_t *guard_overflow, *guard_prefilter;                      // nonzero = the frame is invalid: touch nothing
-    const float* loss_shards; float* loss_out; float loss_scale;           // loss_out[0] = loss_scale * sum of the 64 shards
+    // loss_out[0] = loss_bias + loss_scale * sum(loss_shards) + loss_scale2 * sum(loss_shards2)   (64 shards each, 16 floats apart)
+    const float* loss_shards; const float* loss_shards2; float* loss_out; float loss_scale, loss_scale2, loss_bias;
     int prezeroed;                                                         // the accumulators were zero-filled by the forward
 };
 hipError_t launch_geom_bwd_adam(hipStream_t s, const GeomBwdArgs& a, const RefineFuse& f);
+// 0.8 L1 + 0.2 (1 - SSIM)-style loss, forward + backward (loss_ops.hip); scratch: igs_ssim_l1_scratch_bytes
+hipError_t launch_ssim_l1(hipStream_t s, int W, int H, const float* pred, const float* gt, float lambda_dssim, float weight,
+                          void* scratch, float* grad, bool zero_shards);
 
 // ---------------------------------------------------------------------------------------------
 // device helpers

@@ -1,0 +1,262 @@
+// loss_ops.hip -- the photometric loss of the refine loop, forward + backward in two launches, gfx950.
+//   loss = (1 - lambda) * mean|x - y| + lambda * (1 - mean SSIM(x, y))        (infer_batch.py:300-306, configs: lambda_dssim 0.2)
+// SSIM as igs/utils/loss_utils.py:34-63: 11x11 Gaussian window (sigma 1.5) = outer product of a normalised 1-D kernel, grouped
+// conv with ZERO padding 5, C1 = 0.01^2, C2 = 0.03^2, mean over every element.  The reference runs 5 convolutions forward and
+// their autograd graph backward ("second-largest cost after the blend backward"); here
+//   ssim_stats_kernel : per 32x32 tile and channel, a 42x42 halo of x and y in LDS, separable blur of {x, y, xx, yy, xy},
+//                       the SSIM value (summed into 64 shards) and its three partial derivatives w.r.t. the blurred
+//                       {x, xx, xy} at that pixel -> three maps;
+//   ssim_grad_kernel  : the adjoint: the same separable blur of the three maps (the window is symmetric), combined with x and y
+//                       into dL/dx, plus the L1 term and its sum.
+// With independent variables m1 = blur(x), e2 = blur(xx), e12 = blur(xy) (m2, blur(yy) constant w.r.t. x):
+//   A = 2 m1 m2 + C1,  B = 2 (e12 - m1 m2) + C2,  C = m1^2 + m2^2 + C1,  D = (e2 - m1^2) + s2 + C2,   ssim = A B / (C D)
+//   d/dm1  = 2 m2 (B - A) / (C D) - 2 m1 A B (D - C) / (C D)^2,   d/de2 = -A B / (C D^2),   d/de12 = 2 A / (C D)
+//   dL/dx(p) = sum_q w(q - p) g(q) d/dm1(q) + 2 x(p) sum_q w(q - p) g(q) d/de2(q) + y(p) sum_q w(q - p) g(q) d/de12(q)
+#include "common.h"
+#include "../../include/igs_rast.h"
+#include <math.h>
+
+#define SSIM_R 5                       // window radius
+#define SSIM_T 32                      // tile edge (outputs per workgroup: 32 x 32)
+#define SSIM_H (SSIM_T + 2 * SSIM_R)   // halo edge (42): 1.72x the tile area (2.6x at 16 x 16)
+#define SSIM_HS 44                     // floats per halo row (16-byte aligned rows)
+#define SSIM_BS 36                     // floats per row of the horizontally blurred arrays
+// LDS banks: in the horizontal pass consecutive lanes take consecutive ROWS and move float4s; with row strides of 44 and 36
+// floats (11 and 9 float4s, both odd) 16 consecutive rows start in 16 different 4-bank groups, so the b128 reads and writes
+// are conflict-free (one output column group per lane and scalar accesses put 64 lanes on 16 banks: 4-way conflicts, 2.5x slower)
+// Both passes are register-blocked: a work item produces 4 adjacent outputs from 14 loaded inputs (3x fewer LDS reads than one
+// output per thread); the vertical pass has exactly 32 columns x 8 row groups = 256 work items.
+
+struct SsimWin { float g[2 * SSIM_R + 1]; };
+
+static SsimWin make_window()
+{
+    // loss_utils.py:21-24: gauss = Tensor([exp(-(x - 5)^2 / (2 * 1.5^2))]) ; gauss / gauss.sum()   (float32 tensor arithmetic)
+    SsimWin w; float sum = 0.f;
+    for (int i = 0; i <= 2 * SSIM_R; i++) { w.g[i] = (float)exp(-(double)((i - SSIM_R) * (i - SSIM_R)) / (2.0 * 1.5 * 1.5)); sum += w.g[i]; }
+    for (int i = 0; i <= 2 * SSIM_R; i++) w.g[i] = w.g[i] / sum;
+    return w;
+}
+
+__global__ void __launch_bounds__(256)
+ssim_stats_kernel(const SsimWin win, int W, int H, const float* __restrict__ x, const float* __restrict__ y,
+                  float* __restrict__ maps, float* __restrict__ ssim_sum)
+{
+    __shared__ __attribute__((aligned(16))) float sx[SSIM_H][SSIM_HS], sy[SSIM_H][SSIM_HS];
+    __shared__ __attribute__((aligned(16))) float hb[5][SSIM_H][SSIM_BS];
+    const int tid = threadIdx.x, c = blockIdx.z;
+    const int x0 = blockIdx.x * SSIM_T - SSIM_R, y0 = blockIdx.y * SSIM_T - SSIM_R;
+    const size_t HW = (size_t)W * H;
+    const float* xc = x + c * HW; const float* yc = y + c * HW;
+    {
+        // halo load: every global load of the tile is issued before the first one is waited for (7 independent round trips
+        // instead of 7 dependent ones -- the kernel is otherwise bound by exactly that latency at 3 workgroups per CU)
+        constexpr int NIT = (SSIM_H * SSIM_H + 255) / 256;
+        float tx[NIT], ty[NIT];
+#pragma unroll
+        for (int it = 0; it < NIT; it++) {
+            const int i = tid + it * 256;
+            const int r = i / SSIM_H, q = i - r * SSIM_H;
+            const int gx = x0 + q, gy = y0 + r;
+            const bool in = i < SSIM_H * SSIM_H && gx >= 0 && gx < W && gy >= 0 && gy < H;      // zero padding (F.conv2d padding=5)
+            const size_t o = in ? (size_t)gy * W + gx : 0;
+            const float a = xc[o], b = yc[o];
+            tx[it] = in ? a : 0.f; ty[it] = in ? b : 0.f;
+        }
+#pragma unroll
+        for (int it = 0; it < NIT; it++) {
+            const int i = tid + it * 256;
+            if (i < SSIM_H * SSIM_H) { const int r = i / SSIM_H, q = i - r * SSIM_H; sx[r][q] = tx[it]; sy[r][q] = ty[it]; }
+        }
+    }
+    __syncthreads();
+    // horizontal: work item = (halo row r, group of 4 output columns); consecutive lanes = consecutive rows
+    for (int i = tid; i < SSIM_H * (SSIM_T / 4); i += 256) {
+        const int qg = i / SSIM_H, r = i - qg * SSIM_H, q = qg * 4;
+        float u[16], v[16], uu[14], vv[14], uv[14];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const float4 a = *(const float4*)&sx[r][q + 4 * k], b = *(const float4*)&sy[r][q + 4 * k];
+            u[4 * k] = a.x; u[4 * k + 1] = a.y; u[4 * k + 2] = a.z; u[4 * k + 3] = a.w;
+            v[4 * k] = b.x; v[4 * k + 1] = b.y; v[4 * k + 2] = b.z; v[4 * k + 3] = b.w;
+        }
+#pragma unroll
+        for (int k = 0; k < 14; k++) { uu[k] = u[k] * u[k]; vv[k] = v[k] * v[k]; uv[k] = u[k] * v[k]; }
+        float a0[4], a1[4], a2[4], a3[4], a4[4];
+#pragma unroll
+        for (int o = 0; o < 4; o++) {
+            a0[o] = 0.f; a1[o] = 0.f; a2[o] = 0.f; a3[o] = 0.f; a4[o] = 0.f;
+#pragma unroll
+            for (int k = 0; k <= 2 * SSIM_R; k++) {
+                const float w = win.g[k];
+                a0[o] += w * u[o + k]; a1[o] += w * v[o + k]; a2[o] += w * uu[o + k]; a3[o] += w * vv[o + k]; a4[o] += w * uv[o + k];
+            }
+        }
+        *(float4*)&hb[0][r][q] = make_float4(a0[0], a0[1], a0[2], a0[3]);
+        *(float4*)&hb[1][r][q] = make_float4(a1[0], a1[1], a1[2], a1[3]);
+        *(float4*)&hb[2][r][q] = make_float4(a2[0], a2[1], a2[2], a2[3]);
+        *(float4*)&hb[3][r][q] = make_float4(a3[0], a3[1], a3[2], a3[3]);
+        *(float4*)&hb[4][r][q] = make_float4(a4[0], a4[1], a4[2], a4[3]);
+    }
+    __syncthreads();
+    // vertical: work item = (column lx, group of 4 output rows)
+    const int lx = tid & 31, ly = (tid >> 5) * 4;
+    const int px = blockIdx.x * SSIM_T + lx;
+    float val = 0.f;
+    float m1[4] = { 0, 0, 0, 0 }, m2[4] = { 0, 0, 0, 0 }, e1[4] = { 0, 0, 0, 0 }, e2[4] = { 0, 0, 0, 0 }, e12[4] = { 0, 0, 0, 0 };
+#pragma unroll
+    for (int k = 0; k < 14; k++) {
+        const float h0 = hb[0][ly + k][lx], h1 = hb[1][ly + k][lx], h2 = hb[2][ly + k][lx], h3 = hb[3][ly + k][lx], h4 = hb[4][ly + k][lx];
+#pragma unroll
+        for (int o = 0; o < 4; o++) {
+            if (k - o >= 0 && k - o <= 2 * SSIM_R) {
+                const float w = win.g[k - o];
+                m1[o] += w * h0; m2[o] += w * h1; e1[o] += w * h2; e2[o] += w * h3; e12[o] += w * h4;
+            }
+        }
+    }
+    float* mc = maps + (size_t)c * 3 * HW;
+#pragma unroll
+    for (int o = 0; o < 4; o++) {
+        const int py = blockIdx.y * SSIM_T + ly + o;
+        if (px < W && py < H) {
+            const float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;
+            const float m1s = m1[o] * m1[o], m2s = m2[o] * m2[o], m12 = m1[o] * m2[o];
+            const float s1 = e1[o] - m1s, s2 = e2[o] - m2s, s12 = e12[o] - m12;
+            const float A = 2.f * m12 + C1, B = 2.f * s12 + C2, Cc = m1s + m2s + C1, D = s1 + s2 + C2;
+            const float inv_cd = 1.f / (Cc * D);
+            val += A * B * inv_cd;
+            const size_t off = (size_t)py * W + px;
+            mc[off] = 2.f * m2[o] * (B - A) * inv_cd - 2.f * m1[o] * A * B * (D - Cc) * inv_cd * inv_cd;     // d/d blur(x)
+            mc[HW + off] = -A * B * inv_cd / D;                                                              // d/d blur(xx)
+            mc[2 * HW + off] = 2.f * A * inv_cd;                                                             // d/d blur(xy)
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) val += __shfl_down(val, off, 64);
+    if ((tid & 63) == 0 && val != 0.f)
+        atomicAdd(&ssim_sum[16 * ((blockIdx.x + blockIdx.y * gridDim.x + (tid >> 6) + 7 * c) & 63)], val);
+}
+
+__global__ void __launch_bounds__(256)
+ssim_grad_kernel(const SsimWin win, int W, int H, const float* __restrict__ x, const float* __restrict__ y,
+                 const float* __restrict__ maps, float c_ssim, float c_l1, float* __restrict__ grad, float* __restrict__ l1_sum)
+{
+    __shared__ __attribute__((aligned(16))) float sm[3][SSIM_H][SSIM_HS];
+    __shared__ __attribute__((aligned(16))) float hb[3][SSIM_H][SSIM_BS];
+    const int tid = threadIdx.x, c = blockIdx.z;
+    const int x0 = blockIdx.x * SSIM_T - SSIM_R, y0 = blockIdx.y * SSIM_T - SSIM_R;
+    const size_t HW = (size_t)W * H;
+    const float* mc = maps + (size_t)c * 3 * HW;
+    {
+        constexpr int NIT = (SSIM_H * SSIM_H + 255) / 256;
+        float t0[NIT], t1[NIT], t2[NIT];
+#pragma unroll
+        for (int it = 0; it < NIT; it++) {
+            const int i = tid + it * 256;
+            const int r = i / SSIM_H, q = i - r * SSIM_H;
+            const int gx = x0 + q, gy = y0 + r;
+            const bool in = i < SSIM_H * SSIM_H && gx >= 0 && gx < W && gy >= 0 && gy < H;      // no SSIM value exists outside the image
+            const size_t o = in ? (size_t)gy * W + gx : 0;
+            const float a = mc[o], b = mc[HW + o], d = mc[2 * HW + o];
+            t0[it] = in ? a : 0.f; t1[it] = in ? b : 0.f; t2[it] = in ? d : 0.f;
+        }
+#pragma unroll
+        for (int it = 0; it < NIT; it++) {
+            const int i = tid + it * 256;
+            if (i < SSIM_H * SSIM_H) { const int r = i / SSIM_H, q = i - r * SSIM_H; sm[0][r][q] = t0[it]; sm[1][r][q] = t1[it]; sm[2][r][q] = t2[it]; }
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < SSIM_H * (SSIM_T / 4); i += 256) {
+        const int qg = i / SSIM_H, r = i - qg * SSIM_H, q = qg * 4;
+#pragma unroll
+        for (int m = 0; m < 3; m++) {
+            float u[16];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const float4 a = *(const float4*)&sm[m][r][q + 4 * k];
+                u[4 * k] = a.x; u[4 * k + 1] = a.y; u[4 * k + 2] = a.z; u[4 * k + 3] = a.w;
+            }
+            float acc[4];
+#pragma unroll
+            for (int o = 0; o < 4; o++) {
+                acc[o] = 0.f;
+#pragma unroll
+                for (int k = 0; k <= 2 * SSIM_R; k++) acc[o] += win.g[k] * u[o + k];
+            }
+            *(float4*)&hb[m][r][q] = make_float4(acc[0], acc[1], acc[2], acc[3]);
+        }
+    }
+    __syncthreads();
+    const int lx = tid & 31, ly = (tid >> 5) * 4;
+    const int px = blockIdx.x * SSIM_T + lx;
+    float b0[4] = { 0, 0, 0, 0 }, b1[4] = { 0, 0, 0, 0 }, b2[4] = { 0, 0, 0, 0 };
+#pragma unroll
+    for (int k = 0; k < 14; k++) {
+        const float h0 = hb[0][ly + k][lx], h1 = hb[1][ly + k][lx], h2 = hb[2][ly + k][lx];
+#pragma unroll
+        for (int o = 0; o < 4; o++) {
+            if (k - o >= 0 && k - o <= 2 * SSIM_R) { const float w = win.g[k - o]; b0[o] += w * h0; b1[o] += w * h1; b2[o] += w * h2; }
+        }
+    }
+    float l1 = 0.f;
+#pragma unroll
+    for (int o = 0; o < 4; o++) {
+        const int py = blockIdx.y * SSIM_T + ly + o;
+        if (px < W && py < H) {
+            const size_t off = (size_t)c * HW + (size_t)py * W + px;
+            const float xv = x[off], yv = y[off], d = xv - yv;
+            l1 += fabsf(d);
+            const float g_l1 = d > 0.f ? c_l1 : (d < 0.f ? -c_l1 : 0.f);
+            grad[off] = c_ssim * (b0[o] + 2.f * xv * b1[o] + yv * b2[o]) + g_l1;
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) l1 += __shfl_down(l1, off, 64);
+    if ((tid & 63) == 0 && l1 != 0.f)
+        atomicAdd(&l1_sum[16 * ((blockIdx.x + blockIdx.y * gridDim.x + (tid >> 6) + 7 * c) & 63)], l1);
+}
+
+// scratch = { maps [3 channels][3][H][W] | 64 SSIM-sum shards | 64 L1-sum shards } (shards 16 floats apart)
+extern "C" size_t igs_ssim_l1_scratch_bytes(int width, int height)
+{
+    return (size_t)9 * (size_t)(width > 0 ? width : 0) * (size_t)(height > 0 ? height : 0) * 4 + 2 * 4096 + 256;
+}
+static inline float* scratch_shards(void* scratch, int width, int height)
+{
+    return (float*)((char*)scratch + (((size_t)9 * width * height * 4 + 255) & ~(size_t)255));
+}
+
+hipError_t launch_ssim_l1(hipStream_t s, int W, int H, const float* pred, const float* gt, float lambda_dssim, float weight,
+                          void* scratch, float* grad, bool zero_shards)
+{
+    static const SsimWin win = make_window();
+    float* maps = (float*)scratch;
+    float* shards = scratch_shards(scratch, W, H);
+    if (zero_shards) {
+        const hipError_t e = hipMemsetAsync(shards, 0, 2 * 4096, s);
+        if (e != hipSuccess) return e;
+    }
+    const dim3 grid((W + SSIM_T - 1) / SSIM_T, (H + SSIM_T - 1) / SSIM_T, 3), block(256);
+    const float n = 3.f * (float)W * (float)H;
+    hipLaunchKernelGGL(ssim_stats_kernel, grid, block, 0, s, win, W, H, pred, gt, maps, shards);
+    hipLaunchKernelGGL(ssim_grad_kernel, grid, block, 0, s, win, W, H, pred, gt, maps, -lambda_dssim * weight / n,
+                       (1.f - lambda_dssim) * weight / n, grad, shards + 1024);
+    return hipGetLastError();
+}
+
+extern "C" int igs_ssim_l1_loss_fwd_bwd(void* stream, int width, int height, const float* pred, const float* gt, float lambda_dssim,
+                                        float weight, void* scratch, float* grad, float* sums)
+{
+    if (width <= 0 || height <= 0) return 0;
+    if (!pred || !gt || !scratch || !grad) return IGS_RAST_E_INVALID;
+    if (launch_ssim_l1((hipStream_t)stream, width, height, pred, gt, lambda_dssim, weight, scratch, grad, true) != hipSuccess)
+        return IGS_RAST_E_HIP;
+    if (sums) {
+        // sums[0..1023] = SSIM shards, sums[1024..2047] = L1 shards (the caller adds up [16*s])
+        if (hipMemcpyAsync(sums, scratch_shards(scratch, width, height), 2 * 4096, hipMemcpyDeviceToDevice, (hipStream_t)stream) != hipSuccess)
+            return IGS_RAST_E_HIP;
+    }
+    return 0;
+}

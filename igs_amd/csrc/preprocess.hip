@@ -61,7 +61,10 @@ preprocess_fwd_kernel(const PreArgs a, float* __restrict__ rec, uint32_t* __rest
 #pragma unroll
             for (int k = 0; k < GACC_F / 4; k++) Z4[k] = z;
         }
-        if (blockIdx.x == 0 && threadIdx.x < 64) p.zero_loss[16 * threadIdx.x] = 0.f;
+        if (blockIdx.x == 0 && threadIdx.x < 64) {
+            p.zero_loss[16 * threadIdx.x] = 0.f;
+            if (p.zero_loss2) p.zero_loss2[16 * threadIdx.x] = 0.f;
+        }
     }
     if (idx < p.P) {
         int radius = 0;

@@ -141,6 +141,34 @@ class L1Fused:
         return self.loss_sum        # 64 partial sums of |pred - gt| at [::16] (call .sum() when the value is needed)
 
 
+class L1SsimFused:
+    """(1 - lambda) L1 + lambda (1 - SSIM), forward + backward in two HIP launches (igs_ssim_l1_loss_fwd_bwd)."""
+
+    def __init__(self, device, lambda_dssim):
+        self.device, self.lambda_dssim = device, float(lambda_dssim)
+        self.scratch, self.key = None, None
+        self.sums = torch.zeros(2048, dtype=torch.float32, device=device)
+
+    def __call__(self, pred, gt, grad_out, weight=1.0):
+        L = _cabi.lib()
+        H, W = int(pred.shape[-2]), int(pred.shape[-1])
+        if self.key != (H, W):
+            self.key = (H, W)
+            self.scratch = torch.empty(L.igs_ssim_l1_scratch_bytes(W, H), dtype=torch.uint8, device=self.device)
+        rc = L.igs_ssim_l1_loss_fwd_bwd(torch.cuda.current_stream(self.device).cuda_stream, W, H, pred.data_ptr(), gt.data_ptr(),
+                                        self.lambda_dssim, float(weight), self.scratch.data_ptr(), grad_out.data_ptr(),
+                                        self.sums.data_ptr())
+        if rc != 0:
+            raise RuntimeError("igs_ssim_l1_loss_fwd_bwd failed: %d" % rc)
+        return self.sums
+
+    def value(self, n, weight=1.0):
+        """Loss value of the last call (synchronises)."""
+        ssim_mean = float(self.sums[:1024].sum().item()) / n
+        l1_mean = float(self.sums[1024:].sum().item()) / n
+        return weight * ((1.0 - self.lambda_dssim) * l1_mean + self.lambda_dssim * (1.0 - ssim_mean))
+
+
 class Refiner:
     """One refine step = one view per rank: render, loss, backward, gradient all-reduce (N > 1), Adam."""
 
@@ -152,7 +180,7 @@ class Refiner:
         # injectable for the CPU (gloo) tests of the sharding logic; the product path uses the HIP renderer / Adam
         self.render_fn = render if render_fn is None else render_fn
         self.adam_fn = params.adam_step if adam_fn is None else adam_fn
-        self.l1 = L1Fused(params.device) if loss == "l1" else None
+        self.l1 = L1Fused(params.device) if loss == "l1" else L1SsimFused(params.device, 1.0 - lambda_l1)
         self.native = native          # L1 loss: drive the C ABI directly instead of going through autograd
         self.fused = fused            # ... and on a single GPU run the whole iteration as one library call (igs_refine_step)
         self.grad_img = None
@@ -196,7 +224,7 @@ class Refiner:
             nr, color, coord, mcoord, alpha, normal, depth, mdepth, radii, gb, bb, ib = out
             if self.grad_img is None or self.grad_img.shape != color.shape:
                 self.grad_img = torch.empty_like(color)
-            self.l1(color, gt, self.grad_img, weight=1.0 / self.world_size)
+            self.l1(color, gt, self.grad_img, weight=1.0 / self.world_size)      # L1 or L1 + D-SSIM, fused fwd + bwd
             G = p.grad
             def span(name, shape):
                 o, n = p.spans[name]
@@ -254,6 +282,13 @@ class Refiner:
         a.cam_pos = cam.camera_center.data_ptr()
         a.tan_fovx, a.tan_fovy = cam.tanfovx, cam.tanfovy
         a.gt, a.loss_weight = gt.data_ptr(), 1.0
+        if self.loss == "l1_ssim":
+            if getattr(self, "_loss_scratch_key", None) != (H, W):
+                self._loss_scratch_key = (H, W)
+                self._loss_scratch = torch.empty(L.igs_refine_loss_scratch_bytes(W, H), dtype=torch.uint8, device=dev)
+            a.lambda_dssim, a.loss_scratch = 1.0 - self.lambda_l1, self._loss_scratch.data_ptr()
+        else:
+            a.lambda_dssim, a.loss_scratch = 0.0, None
         a.out_images, a.radii = imgs.data_ptr(), radii.data_ptr()
         a.dL_dmean2D, a.loss_out = self._fused["m2d"].data_ptr(), self._fused["loss"].data_ptr()
         a.require_coord, a.require_depth = 1, 1
@@ -270,10 +305,9 @@ class Refiner:
         if view is None:
             view = self._next_view()
         cam, gt = self.cams[view], self.gt[view]
-        if (self.loss == "l1" and self.native and self.fused and self.render_fn is render and self.world_size == 1
-                and self.adam_fn == p.adam_step):
+        if (self.native and self.fused and self.render_fn is render and self.world_size == 1 and self.adam_fn == p.adam_step):
             return self._fused_step(cam, gt)
-        if self.loss == "l1" and self.native and self.render_fn is render:
+        if self.native and self.render_fn is render:
             pkg = self._native_step(cam, gt)
             if self.world_size > 1:
                 import torch.distributed as dist

@@ -225,7 +225,9 @@ typedef struct igs_refine_step_args {
     const float *viewmatrix, *projmatrix, *cam_pos;   /* device */
     float tan_fovx, tan_fovy;
     const float* gt;                          /* [3][H][W] device */
-    float loss_weight;
+    float loss_weight;                        /* loss = loss_weight * ((1 - lambda_dssim) * mean|color - gt| + lambda_dssim * (1 - mean SSIM)) */
+    float lambda_dssim;                       /* 0: pure L1 (fused into the blend backward); the reference uses 0.2 (loss_utils.py:34-63) */
+    void* loss_scratch;                       /* lambda_dssim > 0: igs_refine_loss_scratch_bytes(width, height) bytes, else NULL */
     float* out_images;                        /* [15][H][W]: color 3 | coord 3 | mcoord 3 | depth 1 | mdepth 1 | alpha 1 | normal 3 */
     int* radii;                               /* [P] */
     float* dL_dmean2D;                        /* [P][3] view-space gradient (densification statistic) or NULL */
@@ -233,6 +235,16 @@ typedef struct igs_refine_step_args {
     int require_coord, require_depth;
 } igs_refine_step_args;
 int igs_refine_step(const igs_refine_step_args* args);
+size_t igs_refine_loss_scratch_bytes(int width, int height);
+
+/* Photometric loss of the refine loop, forward + backward in two launches (igs/utils/loss_utils.py:17-63; infer_batch.py:300-306):
+ *   loss = weight * ((1 - lambda_dssim) * mean|pred - gt| + lambda_dssim * (1 - mean SSIM(pred, gt))),   grad = dloss/dpred.
+ * SSIM: 11x11 Gaussian window (sigma 1.5), zero padding, C1 = 1e-4, C2 = 9e-4, mean over all elements.  `scratch` holds
+ * igs_ssim_l1_scratch_bytes(width, height) bytes.  `sums` (device, 2048 floats, or NULL) receives the 64 SSIM-sum shards at
+ * [16*s] and the 64 L1-sum shards at [1024 + 16*s]; the caller adds them up and forms the loss value. */
+size_t igs_ssim_l1_scratch_bytes(int width, int height);
+int igs_ssim_l1_loss_fwd_bwd(void* stream, int width, int height, const float* pred, const float* gt, float lambda_dssim, float weight,
+                             void* scratch, float* grad, float* sums);
 
 /* Fused L1 loss forward + backward (igs/utils/loss_utils.py:17-18): grad[i] = sign(pred[i] - gt[i]) * scale, and
  * sum |pred - gt| is accumulated into 64 shards loss_sum[16*s], s = 0..63 (1024 floats, zeroed by the caller, summed by

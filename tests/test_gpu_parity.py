@@ -575,3 +575,63 @@ def test_fused_refine_step_equals_unfused_step(dev):
     finally:
         L.igs_rast_set_slab_hint(0)
     assert pa.step_count == pb.step_count == 4
+
+
+@pytest.mark.parametrize("shape", [(70, 53), (128, 128), (33, 200)])
+def test_fused_ssim_l1_loss_matches_torch_autograd(dev, shape):
+    """(1 - lambda) L1 + lambda (1 - SSIM), forward + backward in two HIP launches, against the PyTorch restatement of
+    igs/utils/loss_utils.py:17-63 (11x11 window, zero padding) differentiated by autograd; ragged sizes cover the borders."""
+    from igs_amd.refine import L1SsimFused, ssim
+    H, W = shape
+    g = torch.Generator().manual_seed(H * 1000 + W)
+    gt = torch.rand((3, H, W), generator=g)
+    pred = (gt + 0.15 * torch.randn((3, H, W), generator=g)).clamp(0, 1.2)
+    pred_d, gt_d = pred.to(dev), gt.to(dev)
+    lam = 0.2
+    f = L1SsimFused(dev, lam)
+    grad = torch.empty_like(pred_d)
+    f(pred_d, gt_d, grad, weight=1.0)
+    val = f.value(pred.numel())
+    x = pred_d.clone().requires_grad_(True)
+    loss = (1.0 - lam) * torch.abs(x - gt_d).mean() + lam * (1.0 - ssim(x, gt_d))
+    loss.backward()
+    assert abs(val - float(loss.item())) < 1e-5 * max(1.0, abs(float(loss.item()))), (val, float(loss.item()))
+    a, b = grad.cpu().numpy(), x.grad.cpu().numpy()
+    # tolerance: fp32 separable blur vs the 121-tap conv; gradients are O(1/n)
+    assert np.abs(a - b).max() < 2e-4 * np.abs(b).max(), (np.abs(a - b).max(), np.abs(b).max())
+    r = rel(a, b)
+    assert np.quantile(r, 0.99) < 1e-3, np.quantile(r, 0.99)
+
+
+def test_refine_step_with_reference_loss_l1_plus_dssim(dev):
+    """The reference's loss 0.8 L1 + 0.2 (1 - SSIM) (configs lambda_dssim = 0.2): the single-call fused step, the unfused native
+    step and the autograd step (torch SSIM) agree on the loss and on the resulting parameters."""
+    from igs_amd.refine import GaussianParams, Refiner, render
+    from igs_amd.scenes import perturbed_copy
+    raw, cams, bg = cfg1_scene(P=3000, size=128)
+    cams = [cams[0].to(dev)]
+    bg = bg.to(dev)
+    gt_raw = {k: v.to(dev) for k, v in perturbed_copy(raw, sigma=0.03).items()}
+    with torch.no_grad():
+        gts = [render(activate(gt_raw), cams[0], bg)["images_pred"].clone()]
+    ps = [GaussianParams(raw, dev) for _ in range(3)]
+    rf = Refiner(ps[0], cams, gts, bg, loss="l1_ssim", native=True, fused=True)
+    rn = Refiner(ps[1], cams, gts, bg, loss="l1_ssim", native=True, fused=False)
+    ra = Refiner(ps[2], cams, gts, bg, loss="l1_ssim", native=False)
+    pkf = rf.step(view=0); rn.step(view=0); ra.step(view=0)
+    lf = float(pkf["loss"].item())
+    ln = rn.l1.value(gts[0].numel())
+    assert abs(lf - ln) < 1e-5, (lf, ln)
+    with torch.no_grad():
+        from igs_amd.refine import ssim
+        img = render(activate({k: v.to(dev) for k, v in raw.items()}), cams[0], bg)["images_pred"]
+        lt = 0.8 * torch.abs(img - gts[0]).mean() + 0.2 * (1.0 - ssim(img, gts[0]))
+    assert abs(lf - float(lt.item())) < 1e-5, (lf, float(lt.item()))
+    # native (unfused) gradients vs autograd gradients
+    for k in ps[1].leaves:
+        A, B = ps[1].leaves[k].grad.cpu().numpy(), ps[2].leaves[k].grad.cpu().numpy()
+        r = rel(A, B)
+        assert np.quantile(r, 0.99) < 2e-3 and np.median(r) < 1e-4, (k, np.quantile(r, 0.99), np.median(r))
+    # parameters after one Adam step: |dp| <= lr, so compare against the step size
+    x, y, z = ps[0].flat.cpu().numpy(), ps[1].flat.cpu().numpy(), ps[2].flat.cpu().numpy()
+    assert np.quantile(np.abs(x - y), 0.98) < 2e-6 and np.quantile(np.abs(y - z), 0.95) < 2e-5
