@@ -37,7 +37,7 @@ class RefineStepArgs(C.Structure):
 
 EXPORTS = ["igs_rast_version", "igs_rast_last_error", "igs_rast_forward", "igs_rast_backward_workspace_bytes",
            "igs_rast_forward_async", "igs_rast_forward_finish", "igs_rast_set_slab_hint", "igs_rast_get_slab_hint", "igs_rast_backward", "igs_rast_mark_visible", "igs_rast_debug_dump",
-           "igs_rast_profile_enable", "igs_rast_profile_read", "igs_adam_step", "igs_adam_step_groups", "igs_refine_step", "igs_refine_loss_scratch_bytes", "igs_ssim_l1_scratch_bytes", "igs_ssim_l1_loss_fwd_bwd", "igs_l1_loss_fwd_bwd", "igs_activate_fwd", "igs_activate_bwd"]
+           "igs_rast_profile_enable", "igs_rast_profile_read", "igs_adam_step", "igs_adam_step_groups", "igs_densify_stats", "igs_densify_remap", "igs_refine_step", "igs_refine_loss_scratch_bytes", "igs_ssim_l1_scratch_bytes", "igs_ssim_l1_loss_fwd_bwd", "igs_l1_loss_fwd_bwd", "igs_activate_fwd", "igs_activate_bwd"]
 
 STAGES = ["preprocess", "depth_sort", "scan", "emit", "tile_sort", "ranges", "blend_fwd", "memset", "blend_bwd", "geom_bwd"]
 
@@ -85,6 +85,10 @@ def lib():
         L.igs_adam_step.argtypes = [_vp, C.c_size_t, _vp, _vp, _vp, _vp, _f, _f, _f, _f, _f, _f]
         L.igs_adam_step_groups.restype = _i
         L.igs_adam_step_groups.argtypes = [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _f, _f, _f]
+        L.igs_densify_stats.restype = _i
+        L.igs_densify_stats.argtypes = [_vp, _i, _vp, _vp, _vp, _vp, _vp]
+        L.igs_densify_remap.restype = _i
+        L.igs_densify_remap.argtypes = [_vp, _i, _i] + [_vp] * 13
         L.igs_refine_step.restype = _i
         L.igs_refine_step.argtypes = [C.POINTER(RefineStepArgs)]
         L.igs_refine_loss_scratch_bytes.restype = C.c_size_t

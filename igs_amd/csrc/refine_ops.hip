@@ -192,3 +192,80 @@ extern "C" int igs_activate_bwd(void* stream, int P, const float* opacity, const
     hipLaunchKernelGGL(activate_bwd_kernel, dim3((P + 255) / 256), dim3(256), 0, (hipStream_t)stream, P, opacity, scale, rot, d_opacity, d_scale, d_rot, g_logit, g_log_scale, g_rot);
     return hipGetLastError() == hipSuccess ? 0 : IGS_RAST_E_HIP;
 }
+
+// ---- densification support (igs/models/gaussian_model.py:586-663,865-868; infer_batch.py:308-321) -------------------------
+// per-step statistics: for every Gaussian visible in the view (radii > 0):
+//   xyz_gradient_accum += || dL/dmean2D[:2] ||,  denom += 1,  max_radii2D = max(max_radii2D, radii)
+__global__ void __launch_bounds__(256)
+densify_stats_kernel(int P, const float* __restrict__ dL_dmean2D, const int* __restrict__ radii, float* __restrict__ grad_accum,
+                     float* __restrict__ denom, float* __restrict__ max_radii)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= P) return;
+    const int r = radii[i];
+    if (r > 0) {
+        const float gx = dL_dmean2D[3 * i], gy = dL_dmean2D[3 * i + 1];
+        grad_accum[i] += sqrtf(gx * gx + gy * gy);
+        denom[i] += 1.0f;
+        max_radii[i] = fmaxf(max_radii[i], (float)r);
+    }
+}
+extern "C" int igs_densify_stats(void* stream, int P, const float* dL_dmean2D, const int* radii, float* grad_accum, float* denom,
+                                 float* max_radii)
+{
+    if (P <= 0) return 0;
+    if (!dL_dmean2D || !radii || !grad_accum || !denom || !max_radii) return IGS_RAST_E_INVALID;
+    hipLaunchKernelGGL(densify_stats_kernel, dim3((P + 255) / 256), dim3(256), 0, (hipStream_t)stream, P, dL_dmean2D, radii, grad_accum, denom, max_radii);
+    return hipGetLastError() == hipSuccess ? 0 : IGS_RAST_E_HIP;
+}
+
+// Rebuilds the flat optimiser state after clone / split / prune in ONE pass (the reference re-creates five nn.Parameters and
+// ten Adam-state tensors with masks and torch.cat: _prune_optimizer / cat_tensors_to_optimizer, gaussian_model.py:466-557).
+// New Gaussian i is a copy of old Gaussian src[i]; fresh[i] != 0: a Gaussian created by this densification (Adam moments
+// start at zero); ovr[i] >= 0: a split child whose position and log-scale come from row ovr[i] of ovr_xyz / ovr_scale.
+struct RemapArgs {
+    int P_new, M;
+    const int *src, *fresh, *ovr;
+    const float *ovr_xyz, *ovr_scale;
+    const float *p_old, *m_old, *v_old; float *p_new, *m_new, *v_new;
+    size_t off_old[5], off_new[5];          // xyz, rotation, shs, opacity, scaling
+};
+__global__ void __launch_bounds__(256)
+densify_remap_kernel(const RemapArgs a)
+{
+    const int per = 11 + 3 * a.M;                                   // floats per Gaussian
+    const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= (size_t)a.P_new * per) return;
+    // group-major work order so that consecutive threads write consecutive addresses
+    const size_t P = (size_t)a.P_new;
+    int g; size_t rem = t;
+    const size_t n0 = 3 * P, n1 = 4 * P, n2 = (size_t)3 * a.M * P, n3 = P;
+    if (rem < n0) g = 0; else if ((rem -= n0) < n1) g = 1; else if ((rem -= n1) < n2) g = 2; else if ((rem -= n2) < n3) g = 3; else { rem -= n3; g = 4; }
+    const int k = g == 0 ? 3 : g == 1 ? 4 : g == 2 ? 3 * a.M : g == 3 ? 1 : 3;
+    const size_t i = rem / k; const int c = (int)(rem - i * k);
+    const int s = a.src[i];
+    const size_t so = a.off_old[g] + (size_t)s * k + c, dn = a.off_new[g] + rem;
+    float pv = a.p_old[so];
+    const int o = a.ovr ? a.ovr[i] : -1;
+    if (o >= 0) { if (g == 0) pv = a.ovr_xyz[3 * (size_t)o + c]; else if (g == 4) pv = a.ovr_scale[3 * (size_t)o + c]; }
+    const bool fresh = a.fresh && a.fresh[i] != 0;
+    a.p_new[dn] = pv;
+    a.m_new[dn] = fresh ? 0.f : a.m_old[so];
+    a.v_new[dn] = fresh ? 0.f : a.v_old[so];
+}
+extern "C" int igs_densify_remap(void* stream, int P_new, int M, const int* src, const int* fresh, const int* ovr, const float* ovr_xyz,
+                                 const float* ovr_scale, const float* param_old, const float* exp_avg_old, const float* exp_avg_sq_old,
+                                 const size_t* off_old, float* param_new, float* exp_avg_new, float* exp_avg_sq_new, const size_t* off_new)
+{
+    if (P_new <= 0) return 0;
+    if (!src || !param_old || !exp_avg_old || !exp_avg_sq_old || !off_old || !param_new || !exp_avg_new || !exp_avg_sq_new || !off_new || M < 0)
+        return IGS_RAST_E_INVALID;
+    if (ovr && (!ovr_xyz || !ovr_scale)) return IGS_RAST_E_INVALID;
+    RemapArgs a;
+    a.P_new = P_new; a.M = M; a.src = src; a.fresh = fresh; a.ovr = ovr; a.ovr_xyz = ovr_xyz; a.ovr_scale = ovr_scale;
+    a.p_old = param_old; a.m_old = exp_avg_old; a.v_old = exp_avg_sq_old; a.p_new = param_new; a.m_new = exp_avg_new; a.v_new = exp_avg_sq_new;
+    for (int g = 0; g < 5; g++) { a.off_old[g] = off_old[g]; a.off_new[g] = off_new[g]; }
+    const size_t total = (size_t)P_new * (11 + 3 * (size_t)M);
+    hipLaunchKernelGGL(densify_remap_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
+    return hipGetLastError() == hipSuccess ? 0 : IGS_RAST_E_HIP;
+}

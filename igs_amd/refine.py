@@ -32,21 +32,32 @@ class GaussianParams:
 
     def __init__(self, raw, device, lrs=None, betas=(0.9, 0.999), eps=1e-15):
         P = raw["xyz"].shape[0]
-        self.P, self.device = P, device
+        self.device = device
         self.lrs = dict(DEFAULT_LRS if lrs is None else lrs)
         self.betas, self.eps, self.step_count = betas, eps, 0
         total = sum(k for _, k in GROUPS) * P
-        self.flat = torch.empty(total, dtype=torch.float32, device=device)
-        self.grad = torch.zeros(total, dtype=torch.float32, device=device)
-        self.exp_avg = torch.zeros(total, dtype=torch.float32, device=device)
-        self.exp_avg_sq = torch.zeros(total, dtype=torch.float32, device=device)
+        flat = torch.empty(total, dtype=torch.float32, device=device)
+        o = 0
+        for name, k in GROUPS:
+            n = k * P
+            flat[o:o + n].copy_(raw[name].reshape(-1).to(device))
+            o += n
+        self._bind(P, flat, torch.zeros(total, dtype=torch.float32, device=device),
+                   torch.zeros(total, dtype=torch.float32, device=device))
+
+    def _bind(self, P, flat, exp_avg, exp_avg_sq):
+        """(Re)binds the store to flat buffers of P Gaussians: spans, aliasing leaves and a fresh gradient buffer."""
+        self.P = P
+        self.flat, self.exp_avg, self.exp_avg_sq = flat, exp_avg, exp_avg_sq
+        self.grad = torch.zeros(flat.numel(), dtype=torch.float32, device=self.device)
         self.spans, self.leaves = {}, {}
+        if hasattr(self, "_adam_groups"):
+            del self._adam_groups
         o = 0
         for name, k in GROUPS:
             n = k * P
             self.spans[name] = (o, n)
             shape = (P, 16, 3) if name == "shs" else (P, k)
-            self.flat[o:o + n].copy_(raw[name].reshape(-1).to(device))
             leaf = self.flat[o:o + n].view(shape).requires_grad_(True)     # a leaf that aliases the flat buffer
             leaf.grad = self.grad[o:o + n].view(shape)                     # autograd accumulates in place into the flat gradient
             self.leaves[name] = leaf
@@ -173,7 +184,7 @@ class Refiner:
     """One refine step = one view per rank: render, loss, backward, gradient all-reduce (N > 1), Adam."""
 
     def __init__(self, params, cams, gt_images, bg, loss="l1", lambda_l1=0.8, world_size=1, rank=0, seed=0,
-                 render_fn=None, adam_fn=None, native=True, fused=True):
+                 render_fn=None, adam_fn=None, native=True, fused=True, densify=None, densify_seed=0):
         self.params, self.cams, self.gt, self.bg = params, cams, gt_images, bg
         self.loss, self.lambda_l1 = loss, lambda_l1
         self.world_size, self.rank = world_size, rank
@@ -187,6 +198,13 @@ class Refiner:
         self.gen = torch.Generator().manual_seed(seed)      # same seed on every rank -> same view permutation
         self.order = []
         self.last_num_rendered = 0
+        # optional densify-and-prune (configs/demo.yaml:57-62): a DensifyConfig; statistics and iteration counter per frame
+        self.densify = densify
+        self.iteration = 0
+        self.densify_state = None
+        self.densify_gen = None
+        self.densify_seed = densify_seed
+        self.densify_log = []
 
     def _next_view(self):
         """Without-replacement view sampling (infer_batch.py:280-288); a step consumes `world_size` views."""
@@ -205,6 +223,8 @@ class Refiner:
         dev, P = p.device, p.P
         if not hasattr(self, "_bufs"):
             self._bufs = _rast.RasterBuffers()
+        if getattr(self, "_native_P", None) != P:
+            self._native_P = P
             self._act = torch.empty(8 * P, dtype=torch.float32, device=dev)       # opacity P | scale 3P | rot 4P
             self._dact = torch.empty(8 * P, dtype=torch.float32, device=dev)
             self._tmp = torch.empty(12 * P, dtype=torch.float32, device=dev)      # means2D 3 | colors 3 | cov3D 6
@@ -262,7 +282,7 @@ class Refiner:
         if not hasattr(self, "_bufs"):
             self._bufs = _rast.RasterBuffers()
         imgs, radii, (geom, binning, img) = self._bufs.get(P, H, W, dev)
-        if not hasattr(self, "_fused"):
+        if not hasattr(self, "_fused") or self._fused["m2d"].shape[0] != P:
             self._fused = dict(m2d=torch.zeros((P, 3), dtype=torch.float32, device=dev),
                                loss=torch.zeros(1, dtype=torch.float32, device=dev))
         a = _cabi.RefineStepArgs()
@@ -300,14 +320,61 @@ class Refiner:
         return dict(images_pred=imgs[0:3], radii=radii, visibility_filter=None, viewspace_points=self._fused["m2d"],
                     alpha=imgs[11:12], depth_pred=imgs[9:10], normal=imgs[12:15], loss=self._fused["loss"])
 
+    def start_frame(self):
+        """A new frame of the stream begins (infer_batch.py:270-278): iteration counter and densification statistics restart."""
+        self.iteration = 0
+        self.densify_state = None
+
+    def _densify_hooks(self, pkg, did_adam):
+        """infer_batch.py:308-321, after the backward of iteration `self.iteration`: statistics, then (every `interval`
+        iterations) densify-and-prune.  Returns True when the Gaussian set was rebuilt."""
+        from . import densify as _dn
+        cfg, p = self.densify, self.params
+        rebuilt = False
+        if self.iteration < cfg.until_iter:
+            if self.densify_state is None or self.densify_state.denom.numel() != p.P:
+                self.densify_state = _dn.DensifyState(p.P, p.device)
+            self.densify_state.add(pkg["viewspace_points"], pkg["radii"])
+            if self.iteration > cfg.from_iter and self.iteration % cfg.interval == 0:
+                assert not did_adam
+                if self.densify_gen is None:
+                    self.densify_gen = torch.Generator(device=p.device).manual_seed(self.densify_seed)
+                pl = _dn.densify_and_prune(p, self.densify_state, cfg, self.densify_gen)
+                self.densify_log.append((self.iteration, pl["n_clone"], pl["n_split"], pl["n_pruned"], p.P))
+                rebuilt = True
+        return rebuilt
+
+    def _densify_due(self):
+        cfg = self.densify
+        return (cfg is not None and self.iteration < cfg.until_iter and self.iteration > cfg.from_iter
+                and self.iteration % cfg.interval == 0)
+
+    def _native_then_adam(self, cam, gt):
+        pkg = self._native_step(cam, gt)
+        self.adam_fn()
+        return pkg
+
     def step(self, view=None):
         p = self.params
         if view is None:
             view = self._next_view()
         cam, gt = self.cams[view], self.gt[view]
-        if (self.native and self.fused and self.render_fn is render and self.world_size == 1 and self.adam_fn == p.adam_step):
+        native_ok = self.native and self.render_fn is render
+        if native_ok and self.densify is not None and self.world_size == 1 and self.adam_fn == p.adam_step:
+            # the reference updates the statistics after every backward and, on a densification iteration, rebuilds the
+            # Gaussians BEFORE optimizer.step() -- which then finds no gradients and does nothing (infer_batch.py:308-324)
+            if self._densify_due():
+                pkg = self._native_step(cam, gt)                    # gradients only, no Adam
+                self._densify_hooks(pkg, did_adam=False)
+            else:
+                pkg = self._fused_step(cam, gt) if self.fused else self._native_then_adam(cam, gt)
+                self._densify_hooks(pkg, did_adam=True) if self.iteration < self.densify.until_iter else None
+            self.iteration += 1
+            return pkg
+        self.iteration += 1
+        if (native_ok and self.fused and self.world_size == 1 and self.adam_fn == p.adam_step):
             return self._fused_step(cam, gt)
-        if self.native and self.render_fn is render:
+        if native_ok:
             pkg = self._native_step(cam, gt)
             if self.world_size > 1:
                 import torch.distributed as dist

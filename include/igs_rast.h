@@ -251,6 +251,18 @@ int igs_ssim_l1_loss_fwd_bwd(void* stream, int width, int height, const float* p
  * the caller: same-address atomics would serialise). */
 int igs_l1_loss_fwd_bwd(void* stream, size_t n, const float* pred, const float* gt, float* grad, float* loss_sum, float scale);
 
+/* Densification support (igs/models/gaussian_model.py:586-663,865-868; driven by infer_batch.py:308-321).
+ * igs_densify_stats: per-step statistics of add_densification_stats + the max_radii2D update, for Gaussians with radii > 0:
+ *   grad_accum += ||dL_dmean2D[:2]||, denom += 1, max_radii = max(max_radii, radii).
+ * igs_densify_remap: rebuilds the flat optimiser state (param / exp_avg / exp_avg_sq, five groups at off_*[5] = xyz, rotation,
+ *   shs, opacity, scaling) after clone / split / prune in one pass: new Gaussian i copies old Gaussian src[i]; fresh[i] != 0
+ *   zeroes its Adam moments; ovr[i] >= 0 takes position and log-scale from row ovr[i] of ovr_xyz / ovr_scale (split children).
+ *   The selection itself (masks, top-k, sampling) is host logic: igs_amd/densify.py. */
+int igs_densify_stats(void* stream, int P, const float* dL_dmean2D, const int* radii, float* grad_accum, float* denom, float* max_radii);
+int igs_densify_remap(void* stream, int P_new, int M, const int* src, const int* fresh, const int* ovr, const float* ovr_xyz,
+                      const float* ovr_scale, const float* param_old, const float* exp_avg_old, const float* exp_avg_sq_old,
+                      const size_t* off_old, float* param_new, float* exp_avg_new, float* exp_avg_sq_new, const size_t* off_new);
+
 /* Fused activations applied outside the rasterizer (igs/models/gaussian_model.py:90-127): opacity = sigmoid(logit),
  * scale = exp(log_scale), rotation = F.normalize(rot) (eps 1e-12); and their backward. */
 int igs_activate_fwd(void* stream, int P, const float* logit, const float* log_scale, const float* rot, float* opacity,

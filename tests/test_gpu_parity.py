@@ -635,3 +635,122 @@ def test_refine_step_with_reference_loss_l1_plus_dssim(dev):
     # parameters after one Adam step: |dp| <= lr, so compare against the step size
     x, y, z = ps[0].flat.cpu().numpy(), ps[1].flat.cpu().numpy(), ps[2].flat.cpu().numpy()
     assert np.quantile(np.abs(x - y), 0.98) < 2e-6 and np.quantile(np.abs(y - z), 0.95) < 2e-5
+
+
+def _reference_style_densify(t, m, v, stats, cfg, gen):
+    """Literal restatement of igs/models/gaussian_model.py:586-663 (densify_and_prune -> clone -> split -> prune) on separate
+    tensors with mask / cat surgery of parameters AND Adam moments (:466-557), for comparison with the one-pass remap."""
+    from igs_amd.densify import build_rotation
+    def cat_all(new):               # cat_tensors_to_optimizer + densification_postfix
+        for k in t:
+            t[k] = torch.cat((t[k], new[k]), dim=0)
+            m[k] = torch.cat((m[k], torch.zeros_like(new[k])), dim=0)
+            v[k] = torch.cat((v[k], torch.zeros_like(new[k])), dim=0)
+    def prune(mask):                # prune_points / _prune_optimizer
+        keep = ~mask
+        for k in t:
+            t[k], m[k], v[k] = t[k][keep], m[k][keep], v[k][keep]
+    P = t["xyz"].shape[0]
+    grads = stats["accum"].view(P, 1) / stats["denom"].view(P, 1)
+    grads[grads.isnan()] = 0.0
+    max_num_add = cfg.max_num - P
+    sel = torch.where(torch.norm(grads, dim=-1) >= cfg.grad_threshold, True, False)
+    if cfg.control_max and sel.sum() > max_num_add:
+        tv, ti = torch.topk(grads, max_num_add, dim=0)
+        grads = torch.zeros_like(grads)
+        grads.scatter_(0, ti, tv)
+    # clone
+    sel = torch.where(torch.norm(grads, dim=-1) >= cfg.grad_threshold, True, False)
+    sel = torch.logical_and(sel, torch.max(torch.exp(t["scaling"]), dim=1).values <= cfg.percent_dense * cfg.extent)
+    cat_all({k: t[k][sel] for k in t})
+    # split
+    n_init = t["xyz"].shape[0]
+    padded = torch.zeros((n_init,), device=grads.device)
+    padded[:grads.shape[0]] = grads.squeeze()
+    sel = torch.where(padded >= cfg.grad_threshold, True, False)
+    sel = torch.logical_and(sel, torch.max(torch.exp(t["scaling"]), dim=1).values > cfg.percent_dense * cfg.extent)
+    N = 2
+    stds = torch.exp(t["scaling"])[sel].repeat(N, 1)
+    means = torch.zeros((stds.size(0), 3), device=grads.device)
+    samples = torch.normal(mean=means, std=stds, generator=gen)
+    rots = build_rotation(t["rotation"][sel]).repeat(N, 1, 1)
+    new = dict(xyz=torch.bmm(rots, samples.unsqueeze(-1)).squeeze(-1) + t["xyz"][sel].repeat(N, 1),
+               scaling=torch.log(torch.exp(t["scaling"])[sel].repeat(N, 1) / (0.8 * N)), rotation=t["rotation"][sel].repeat(N, 1),
+               opacity=t["opacity"][sel].repeat(N, 1), shs=t["shs"][sel].repeat(N, 1, 1))
+    cat_all(new)
+    prune(torch.cat((sel, torch.zeros(N * int(sel.sum()), device=grads.device, dtype=bool))))
+    prune((torch.sigmoid(t["opacity"]) < cfg.min_opacity).squeeze())
+
+
+def test_densify_and_prune_matches_reference_style_surgery(dev):
+    """Clone / split / prune with Adam-moment remapping in one gather pass (igs_densify_remap + igs_amd/densify.plan) against the
+    reference's sequence of mask / cat operations, same RNG: identical parameters and moments, in the same order; also the
+    max-points-bounded (top-k) branch."""
+    from igs_amd.refine import GaussianParams
+    from igs_amd import densify as dn
+    raw, cams, bg = cfg1_scene(P=4000, size=64)
+    for max_num in (150000, 4300):
+        params = GaussianParams(raw, dev)
+        g = torch.Generator().manual_seed(3)
+        params.exp_avg.copy_(torch.randn(params.exp_avg.shape, generator=g).to(dev))
+        params.exp_avg_sq.copy_(torch.rand(params.exp_avg_sq.shape, generator=g).to(dev))
+        P = params.P
+        st = dn.DensifyState(P, dev)
+        st.grad_accum.copy_((torch.rand(P, generator=g) * 6e-4).to(dev))
+        st.denom.copy_(torch.randint(0, 3, (P,), generator=g).float().to(dev))          # zeros -> NaN -> 0
+        cfg = dn.DensifyConfig(grad_threshold=0.00015, min_opacity=0.005, max_num=max_num, percent_dense=0.01, extent=5.0)
+        t = {k: params.leaves[k].detach().clone() for k in params.leaves}
+        sp = lambda buf: {k: buf[params.spans[k][0]:params.spans[k][0] + params.spans[k][1]].view(params.leaves[k].shape).clone()
+                          for k in params.leaves}
+        m, v = sp(params.exp_avg), sp(params.exp_avg_sq)
+        stats = dict(accum=st.grad_accum.clone(), denom=st.denom.clone())
+        _reference_style_densify(t, m, v, stats, cfg, torch.Generator(device=dev).manual_seed(11))
+        pl = dn.densify_and_prune(params, st, cfg, torch.Generator(device=dev).manual_seed(11))
+        assert pl["n_clone"] > 0 and pl["n_split"] > 0 and pl["n_pruned"] > 0
+        assert params.P == t["xyz"].shape[0] and params.P != P
+        if max_num == 4300:
+            assert pl["n_clone"] + pl["n_split"] <= 300
+        for k in t:
+            o, n = params.spans[k]
+            assert torch.equal(params.flat[o:o + n].view(t[k].shape), t[k]), k
+            assert torch.equal(params.exp_avg[o:o + n].view(t[k].shape), m[k]), k
+            assert torch.equal(params.exp_avg_sq[o:o + n].view(t[k].shape), v[k]), k
+        assert st.denom.numel() == params.P and float(st.denom.sum()) == 0.0
+
+
+def test_refine_loop_with_densification(dev):
+    """The refine loop with densify-and-prune switched on (statistics every step, rebuild every `interval` steps, no Adam on a
+    rebuild step -- infer_batch.py:308-324): the Gaussian count changes, the statistics kernel matches torch, PSNR improves."""
+    from igs_amd.refine import GaussianParams, Refiner, render, psnr
+    from igs_amd import densify as dn
+    from igs_amd.scenes import perturbed_copy
+    raw, cams, bg = cfg1_scene(P=3000, size=128)
+    cams = [cams[0].to(dev)]
+    bg = bg.to(dev)
+    gt_raw = {k: v.to(dev) for k, v in perturbed_copy(raw, sigma=0.05).items()}
+    with torch.no_grad():
+        gts = [render(activate(gt_raw), cams[0], bg)["images_pred"].clone()]
+    params = GaussianParams(raw, dev)
+    cfg = dn.DensifyConfig(until_iter=30, from_iter=0, interval=10, grad_threshold=2e-5, min_opacity=0.005, max_num=3400,
+                           percent_dense=0.01, extent=5.0)
+    ref = Refiner(params, cams, gts, bg, loss="l1_ssim", densify=cfg)
+    with torch.no_grad():
+        p0 = float(psnr(render(params.activated(), cams[0], bg)["images_pred"], gts[0]))
+    # statistics kernel vs torch on the first step
+    pk = ref.step(view=0)
+    m2d, radii = pk["viewspace_points"], pk["radii"]
+    vis = radii > 0
+    exp_acc = torch.where(vis, torch.norm(m2d[:, :2], dim=-1), torch.zeros_like(m2d[:, 0]))
+    torch.testing.assert_close(ref.densify_state.grad_accum, exp_acc, rtol=1e-6, atol=0)
+    assert torch.equal(ref.densify_state.denom, vis.float())
+    assert torch.equal(ref.densify_state.max_radii, torch.where(vis, radii.float(), torch.zeros_like(radii, dtype=torch.float32)))
+    counts = [params.P]
+    for it in range(1, 40):
+        ref.step(view=0)
+        counts.append(params.P)
+    assert [e[0] for e in ref.densify_log] == [10, 20]                      # iteration > from_iter, % interval == 0, < until_iter
+    assert len(set(counts)) > 1 and max(counts) <= 3400 + 2 * 400
+    assert params.step_count == 40 - 2                                        # no Adam on the two rebuild iterations
+    with torch.no_grad():
+        p1 = float(psnr(render(params.activated(), cams[0], bg)["images_pred"], gts[0]))
+    assert p1 > p0 + 0.5, (p0, p1)
