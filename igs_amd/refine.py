@@ -184,7 +184,8 @@ class Refiner:
     """One refine step = one view per rank: render, loss, backward, gradient all-reduce (N > 1), Adam."""
 
     def __init__(self, params, cams, gt_images, bg, loss="l1", lambda_l1=0.8, world_size=1, rank=0, seed=0,
-                 render_fn=None, adam_fn=None, native=True, fused=True, densify=None, densify_seed=0):
+                 render_fn=None, adam_fn=None, native=True, fused=True, densify=None, densify_seed=0,
+                 lambda_depth_normal=0.0):
         self.params, self.cams, self.gt, self.bg = params, cams, gt_images, bg
         self.loss, self.lambda_l1 = loss, lambda_l1
         self.world_size, self.rank = world_size, rank
@@ -192,7 +193,10 @@ class Refiner:
         self.render_fn = render if render_fn is None else render_fn
         self.adam_fn = params.adam_step if adam_fn is None else adam_fn
         self.l1 = L1Fused(params.device) if loss == "l1" else L1SsimFused(params.device, 1.0 - lambda_l1)
-        self.native = native          # L1 loss: drive the C ABI directly instead of going through autograd
+        # RaDe-GS depth-normal regulariser (train.py:143-164; BASELINE cfg-5 uses 0.05): needs dL/d depth, mdepth, normal, so the
+        # step goes through the autograd Function (full backward instance) instead of the colour-only native paths
+        self.lambda_depth_normal = float(lambda_depth_normal)
+        self.native = native and self.lambda_depth_normal == 0.0          # drive the C ABI directly instead of going through autograd
         self.fused = fused            # ... and on a single GPU run the whole iteration as one library call (igs_refine_step)
         self.grad_img = None
         self.gen = torch.Generator().manual_seed(seed)      # same seed on every rank -> same view permutation
@@ -385,7 +389,7 @@ class Refiner:
         act = p.activated()
         pkg = self.render_fn(act, cam, self.bg)
         img = pkg["images_pred"]
-        if self.loss == "l1":
+        if self.loss == "l1" and self.lambda_depth_normal == 0.0:
             if self.grad_img is None or self.grad_img.shape != img.shape:
                 self.grad_img = torch.empty_like(img)
             scale = 1.0 / self.world_size           # gradients are averaged over the views of a step
@@ -393,7 +397,11 @@ class Refiner:
             img.backward(gradient=self.grad_img)
         else:
             Ll1 = torch.abs(img - gt).mean()
-            loss = self.lambda_l1 * Ll1 + (1.0 - self.lambda_l1) * (1.0 - ssim(img, gt))
+            loss = Ll1 if self.loss == "l1" else self.lambda_l1 * Ll1 + (1.0 - self.lambda_l1) * (1.0 - ssim(img, gt))
+            if self.lambda_depth_normal > 0.0:
+                from .regularizers import depth_normal_loss
+                self.last_depth_normal_loss = depth_normal_loss(pkg, cam)
+                loss = loss + self.lambda_depth_normal * self.last_depth_normal_loss
             (loss / self.world_size).backward()
         if self.world_size > 1:
             import torch.distributed as dist

@@ -188,3 +188,29 @@ def test_view_sharding_and_gradient_allreduce_gloo_world2():
     np.testing.assert_allclose(p.flat.numpy(), f0, rtol=1e-5, atol=1e-7)
     # without-replacement sampling: the first 3 steps (6 draws) cover all 6 views once
     assert sorted(v0[:3] + v1[:3]) == list(range(6))
+
+
+def test_depth_to_normal_on_an_analytic_plane():
+    """RaDe-GS depth_double_to_normal (graphics_utils.py:97-126): a planar depth map gives the plane's normal at every interior
+    pixel (sign convention of cross(d/dy, d/dx) as the reference indexes it), zero on the border."""
+    import math
+    import torch
+    from igs_amd.camera import Camera
+    from igs_amd.regularizers import depth_double_to_normal, depths_double_to_points
+    H, W = 24, 32
+    cam = Camera(torch.eye(4), 2 * math.atan(W / (2 * 40.0)), 2 * math.atan(H / (2 * 40.0)), (H, W))
+    # plane n . p = d in camera space, seen along the pixel rays: depth z = d / (n . ray)
+    n = torch.tensor([0.2, -0.3, 0.93]); n = n / n.norm(); d = 4.0
+    ys, xs = torch.meshgrid(torch.arange(H) + 0.5, torch.arange(W) + 0.5, indexing="ij")
+    rays = torch.stack([(xs - W / 2) / 40.0, (ys - H / 2) / 40.0, torch.ones_like(xs)], dim=0)
+    z = d / (rays * n.view(3, 1, 1)).sum(0)
+    p1, p2 = depths_double_to_points(cam, z[None], 2 * z[None])
+    torch.testing.assert_close(p1, rays * z, rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(p2, 2 * p1)
+    nm = depth_double_to_normal(cam, z[None], 2 * z[None])
+    assert nm.shape == (2, 3, H, W)
+    inner = nm[0][:, 1:-1, 1:-1]
+    dots = (inner * n.view(3, 1, 1)).sum(0)
+    assert torch.all(dots.abs() > 1 - 1e-4) and torch.all(dots.sign() == dots.flatten()[0].sign())
+    assert float(nm[0][:, 0, :].abs().max()) == 0.0 and float(nm[1][:, :, -1].abs().max()) == 0.0
+    torch.testing.assert_close(nm[1], nm[0], rtol=1e-4, atol=1e-5)          # scaling the depth does not change the normal
