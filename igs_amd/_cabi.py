@@ -53,6 +53,11 @@ def lib():
             path = _build.LIB          # stale but present (e.g. no hipcc on this box): use what travelled
         else:
             raise RuntimeError("igs_amd: the HIP extension libigs_rast.so is missing and could not be built: %s" % e)
+    # Load order matters: the library needs libamdhip64, and so does PyTorch, which ships its own copy.  Whichever is mapped
+    # first serves both; if ours (from /opt/rocm) came first, torch would bring a SECOND runtime and the two would not share
+    # the device (symptom: hipGetDevice -> "no ROCm-capable device is detected").  Device memory and streams come from torch
+    # on this path, so torch's runtime goes first.
+    import torch  # noqa: F401
     L = C.CDLL(path)
     L.igs_rast_version.restype = _i
     L.igs_rast_last_error.restype = C.c_char_p
