@@ -26,18 +26,46 @@ def _hipcc():
     raise RuntimeError("hipcc not found")
 
 
+STAMP = os.path.join(LIBDIR, "build.stamp")
+
+
+def _fingerprint():
+    """Content hash of everything the library is made from (sources, headers, flags): file times do not survive a copy to
+    another machine, and a spurious rebuild by eight ranks at once is exactly what must not happen."""
+    import hashlib
+    h = hashlib.sha256()
+    deps = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC)) + [os.path.join(HERE, "..", "include", "igs_rast.h")]
+    for d in deps:
+        h.update(os.path.basename(d).encode())
+        with open(d, "rb") as f:
+            h.update(f.read())
+    h.update(" ".join(FLAGS + sorted(SLP_OK) + [os.environ.get("IGS_EXTRA_FLAGS", "")]).encode())
+    return h.hexdigest()
+
+
 def needs_build():
-    if not os.path.exists(LIB):
+    if not os.path.exists(LIB) or not os.path.exists(STAMP):
         return True
-    t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(HERE, "..", "include", "igs_rast.h")]
-    return any(os.path.getmtime(d) > t for d in deps)
+    with open(STAMP) as f:
+        return f.read().strip() != _fingerprint()
 
 
 def build(force=False, verbose=False):
     if not force and not needs_build():
         return LIB
     os.makedirs(LIBDIR, exist_ok=True)
+    import fcntl
+    with open(os.path.join(LIBDIR, "build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)                    # one builder at a time (ranks of a multi-GPU run share the tree)
+        try:
+            if not force and not needs_build():             # somebody else built it while we waited
+                return LIB
+            return _build_locked(verbose)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+
+
+def _build_locked(verbose):
     objdir = os.path.join(LIBDIR, "obj")
     os.makedirs(objdir, exist_ok=True)
     hipcc = _hipcc()
@@ -59,10 +87,14 @@ def build(force=False, verbose=False):
             raise RuntimeError("hipcc failed on %s:\n%s" % (src, out))
         if verbose and out.strip():
             print(out)
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+    tmp = LIB + ".tmp.%d" % os.getpid()
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", tmp] + objs
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if r.returncode != 0:
         raise RuntimeError("link failed:\n" + r.stdout)
+    os.replace(tmp, LIB)                                    # a process that has the old file mapped keeps it; nobody sees half a file
+    with open(STAMP, "w") as f:
+        f.write(_fingerprint())
     return LIB
 
 
