@@ -1,6 +1,9 @@
 #!/usr/bin/env python3
 """Headline benchmark: Gaussians rendered/sec (fwd+bwd) at 1352x1014  (BASELINE.json metric).
 
+Every step is ONE library call per rank (igs_refine_step: activations, forward, loss, backward and -- for N = 1 -- the Adam
+update, 6 launches); for N > 1 the call ends in the flat gradient, which is all-reduced and followed by one Adam launch.
+
 Workload at every N (weak scaling): BASELINE.json configs[2] -- the sear_steak-like frame-0 scene (200k Gaussians,
 synthetic stand-in), 10 train cameras at 1352x1014, and per step ONE view per rank:
 forward render + L1 loss + backward + (N>1: RCCL all-reduce of the flat 59*P-float gradient) + Adam step.
@@ -82,6 +85,8 @@ def main():
     ap.add_argument("--loss", default="l1", choices=["l1", "l1_ssim"])
     ap.add_argument("--cpu-views", type=int, default=2, help="views timed on the CPU oracle (0 = skip)")
     ap.add_argument("--no-profile", action="store_true", help="do not record per-stage HIP events")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse the\n"
+                    "N > 1 code path on a box with fewer GPUs than ranks)")
     ap.add_argument("--profile-every", type=int, default=8,
                     help="record the per-stage HIP events on every N-th step of the timed region (each event costs stream time)")
     args = ap.parse_args()
@@ -92,12 +97,15 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=args.backend)
     if args.gpus != world and rank == 0 and world > 1:
         print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback for the product path)")
-    dev = torch.device("cuda", local_rank)
+    dev = torch.device("cuda", local_rank if args.backend == "nccl" else local_rank % torch.cuda.device_count())
     torch.cuda.set_device(dev)
 
     from igs_amd import _cabi, rasterizer
@@ -163,7 +171,7 @@ def main():
         if stages and calls:
             R_avg = r_sum / calls
             geo_bwd = args.loss != "l1" and False      # both losses only see the colour image: geometry gradients are absent
-            fused = world == 1 and args.loss == "l1"      # single GPU + pure L1: the loss is evaluated inside blend_bwd (reads colour + gt)
+            fused = args.loss == "l1"      # pure L1: the loss is evaluated inside blend_bwd (reads colour + gt instead of dL_dpix)
             ab = algorithmic_bytes(R_avg, args.width, args.height, True, True, geo_bwd, geo_bwd, geo_bwd, l1_fused=fused)
             per = {k: (ms / cnt if cnt else 0.0) for k, (ms, cnt) in stages.items()}
             dom = "blend_bwd" if per.get("blend_bwd", 0) >= per.get("blend_fwd", 0) else "blend_fwd"

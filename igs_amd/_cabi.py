@@ -22,7 +22,7 @@ class RefineStepArgs(C.Structure):
                 ("workspace", C.c_void_p),
                 ("P", C.c_int), ("D", C.c_int), ("M", C.c_int), ("width", C.c_int), ("height", C.c_int),
                 ("background", C.c_void_p),
-                ("param", C.c_void_p), ("exp_avg", C.c_void_p), ("exp_avg_sq", C.c_void_p),
+                ("param", C.c_void_p), ("exp_avg", C.c_void_p), ("exp_avg_sq", C.c_void_p), ("grad_out", C.c_void_p),
                 ("off_xyz", C.c_size_t), ("off_rot", C.c_size_t), ("off_sh", C.c_size_t), ("off_opacity", C.c_size_t),
                 ("off_scale", C.c_size_t),
                 ("lr_xyz", C.c_float), ("lr_rot", C.c_float), ("lr_sh", C.c_float), ("lr_opacity", C.c_float), ("lr_scale", C.c_float),

@@ -516,9 +516,9 @@ extern "C" size_t igs_refine_loss_scratch_bytes(int width, int height)
 extern "C" int igs_refine_step(const igs_refine_step_args* a)
 {
     if (!a) return fail(IGS_RAST_E_INVALID, "igs_refine_step: NULL args");
-    if (a->P <= 0 || a->M <= 0 || a->width <= 0 || a->height <= 0 || a->step < 1)
+    if (a->P <= 0 || a->M <= 0 || a->width <= 0 || a->height <= 0 || (a->step < 1 && !a->grad_out))
         return fail(IGS_RAST_E_INVALID, "igs_refine_step: bad sizes");
-    if (!a->param || !a->exp_avg || !a->exp_avg_sq || !a->gt || !a->out_images || !a->radii || !a->workspace || !a->background)
+    if (!a->param || (!a->grad_out && (!a->exp_avg || !a->exp_avg_sq)) || !a->gt || !a->out_images || !a->radii || !a->workspace || !a->background)
         return fail(IGS_RAST_E_INVALID, "igs_refine_step: NULL pointer");
     const size_t HW = (size_t)a->width * a->height;
     float* img = a->out_images;
@@ -528,9 +528,10 @@ extern "C" int igs_refine_step(const igs_refine_step_args* a)
     const float* opac = a->param + a->off_opacity; const float* scal = a->param + a->off_scale; const float* rotn = a->param + a->off_rot;
     ScratchCapture cg{ a->geometry_buffer, a->geometry_user, nullptr }, cb{ a->binning_buffer, a->binning_user, nullptr },
                    ci{ a->image_buffer, a->image_user, nullptr };
-    const double bc1 = 1.0 - pow((double)a->beta1, (double)a->step), bc2 = 1.0 - pow((double)a->beta2, (double)a->step);
+    const int stepno = a->step < 1 ? 1 : a->step;
+    const double bc1 = 1.0 - pow((double)a->beta1, (double)stepno), bc2 = 1.0 - pow((double)a->beta2, (double)stepno);
     RefineFuse f;
-    f.param = a->param; f.exp_avg = a->exp_avg; f.exp_avg_sq = a->exp_avg_sq;
+    f.param = a->param; f.exp_avg = a->exp_avg; f.exp_avg_sq = a->exp_avg_sq; f.grad_out = a->grad_out;
     f.off_xyz = a->off_xyz; f.off_rot = a->off_rot; f.off_sh = a->off_sh; f.off_opacity = a->off_opacity; f.off_scale = a->off_scale;
     f.lr_xyz = (float)(a->lr_xyz / bc1); f.lr_rot = (float)(a->lr_rot / bc1); f.lr_sh = (float)(a->lr_sh / bc1);
     f.lr_opacity = (float)(a->lr_opacity / bc1); f.lr_scale = (float)(a->lr_scale / bc1);

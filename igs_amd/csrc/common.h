@@ -175,6 +175,7 @@ hipError_t launch_geom_bwd(hipStream_t s, const GeomBwdArgs& a);
 // point at the RAW leaves inside `param`; only dL_dmean2D (may be NULL) is still written.
 struct RefineFuse {
     float *param, *exp_avg, *exp_avg_sq;                                   // flat optimiser state
+    float* grad_out;                                                       // non-NULL: write the flat gradient (same offsets) INSTEAD of applying Adam
     size_t off_xyz, off_rot, off_sh, off_opacity, off_scale;               // group offsets (floats) into the three buffers
     float lr_xyz, lr_rot, lr_sh, lr_opacity, lr_scale;                     // lr / bias_correction1 per group
     float b1, b2, eps, inv_sqrt_bc2;

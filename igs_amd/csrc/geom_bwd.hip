@@ -404,6 +404,7 @@ geom_bwd_kernel(const GBArgs args)
         } else {
             // ---- activation backward (gaussian_model.py:90-127) + Adam on this Gaussian's 11 small parameters ----
             auto upd = [&](size_t off, float g, float lr) {
+                if (fz.grad_out) { fz.grad_out[off] = g; return; }       // multi-GPU: the gradient goes to the all-reduce
                 float p = fz.param[off], m = fz.exp_avg[off], v = fz.exp_avg_sq[off];
                 adam_update(p, m, v, g, lr, fz.b1, fz.b2, fz.eps, fz.inv_sqrt_bc2);
                 fz.param[off] = p; fz.exp_avg[off] = m; fz.exp_avg_sq[off] = v;
@@ -445,7 +446,8 @@ geom_bwd_kernel(const GBArgs args)
         float* dst_m = FUSED ? fz.exp_avg + fz.off_sh + (size_t)g0 * F : nullptr;
         float* dst_v = FUSED ? fz.exp_avg_sq + fz.off_sh + (size_t)g0 * F : nullptr;
         bool aligned = ((F & 3) == 0) && ((((uintptr_t)dst) & 15) == 0);
-        if constexpr (FUSED) aligned = aligned && (((((uintptr_t)dst_m) | ((uintptr_t)dst_v)) & 15) == 0);
+        if constexpr (FUSED) aligned = aligned && (((((uintptr_t)dst_m) | ((uintptr_t)dst_v)) & 15) == 0)
+                                       && (!fz.grad_out || (((uintptr_t)(fz.grad_out + fz.off_sh + (size_t)g0 * F)) & 15) == 0);
         if (aligned) {
             const int total4 = total >> 2;
             int f = (int)threadIdx.x * 4;
@@ -453,7 +455,9 @@ geom_bwd_kernel(const GBArgs args)
             const int dg = (4 * NT) / F, dk = (4 * NT) - dg * F;
             for (int i = threadIdx.x; i < total4; i += NT) {
                 const float* sp = dsh_lds + g * FS + k;
-                if constexpr (FUSED) {
+                if (FUSED && fz.grad_out) {
+                    ((float4*)(fz.grad_out + fz.off_sh + (size_t)g0 * F))[i] = make_float4(sp[0], sp[1], sp[2], sp[3]);
+                } else if constexpr (FUSED) {
                     // Adam on the SH coefficients of the workgroup's NT Gaussians: one contiguous, coalesced span of each buffer
                     float4 P4 = ((float4*)dst)[i], M4 = ((float4*)dst_m)[i], V4 = ((float4*)dst_v)[i];
                     adam_update(P4.x, M4.x, V4.x, sp[0], fz.lr_sh, fz.b1, fz.b2, fz.eps, fz.inv_sqrt_bc2);
@@ -472,7 +476,9 @@ geom_bwd_kernel(const GBArgs args)
             int g = f / F, k = f - g * F;
             const int dg = NT / F, dk = NT - dg * F;
             for (int i = threadIdx.x; i < total; i += NT) {
-                if constexpr (FUSED) {
+                if (FUSED && fz.grad_out) {
+                    fz.grad_out[fz.off_sh + (size_t)g0 * F + i] = dsh_lds[g * FS + k];
+                } else if constexpr (FUSED) {
                     float p = dst[i], m = dst_m[i], v = dst_v[i];
                     adam_update(p, m, v, dsh_lds[g * FS + k], fz.lr_sh, fz.b1, fz.b2, fz.eps, fz.inv_sqrt_bc2);
                     dst[i] = p; dst_m[i] = m; dst_v[i] = v;

@@ -275,7 +275,7 @@ class Refiner:
         return dict(images_pred=color, radii=radii, visibility_filter=None, viewspace_points=outs["means2D"], alpha=alpha,
                     depth_pred=depth, normal=normal)
 
-    def _fused_step(self, cam, gt):
+    def _fused_step(self, cam, gt, grads_only=False):
         """Single-GPU step entirely inside the library: `igs_refine_step` (include/igs_rast.h) -- activations, render, L1,
         backward and the Adam update in 7 launches; no gradient array is materialised."""
         import ctypes as C
@@ -296,6 +296,7 @@ class Refiner:
         a.P, a.D, a.M, a.width, a.height = P, 3, 16, W, H
         a.background = self.bg.data_ptr()
         a.param, a.exp_avg, a.exp_avg_sq = p.flat.data_ptr(), p.exp_avg.data_ptr(), p.exp_avg_sq.data_ptr()
+        a.grad_out = p.grad.data_ptr() if grads_only else None          # multi-GPU: gradients for the all-reduce, Adam afterwards
         a.off_xyz, a.off_rot, a.off_sh = p.spans["xyz"][0], p.spans["rotation"][0], p.spans["shs"][0]
         a.off_opacity, a.off_scale = p.spans["opacity"][0], p.spans["scaling"][0]
         a.lr_xyz, a.lr_rot, a.lr_sh = p.lrs["xyz"], p.lrs["rotation"], p.lrs["shs"]
@@ -305,7 +306,7 @@ class Refiner:
         a.viewmatrix, a.projmatrix = cam.world_view_transform.data_ptr(), cam.full_proj_transform.data_ptr()
         a.cam_pos = cam.camera_center.data_ptr()
         a.tan_fovx, a.tan_fovy = cam.tanfovx, cam.tanfovy
-        a.gt, a.loss_weight = gt.data_ptr(), 1.0
+        a.gt, a.loss_weight = gt.data_ptr(), 1.0 / self.world_size      # gradients are averaged over the views of a step
         if self.loss == "l1_ssim":
             if getattr(self, "_loss_scratch_key", None) != (H, W):
                 self._loss_scratch_key = (H, W)
@@ -319,7 +320,8 @@ class Refiner:
         with torch.cuda.device(dev):
             nr = L.igs_refine_step(C.byref(a))
         _rast._check(nr, "igs_refine_step")
-        p.step_count += 1
+        if not grads_only:
+            p.step_count += 1
         self.last_num_rendered = nr
         return dict(images_pred=imgs[0:3], radii=radii, visibility_filter=None, viewspace_points=self._fused["m2d"],
                     alpha=imgs[11:12], depth_pred=imgs[9:10], normal=imgs[12:15], loss=self._fused["loss"])
@@ -379,10 +381,11 @@ class Refiner:
         if (native_ok and self.fused and self.world_size == 1 and self.adam_fn == p.adam_step):
             return self._fused_step(cam, gt)
         if native_ok:
-            pkg = self._native_step(cam, gt)
+            # N > 1 (or an injected optimiser): the same fused launches, ending in the flat gradient instead of the update
+            pkg = self._fused_step(cam, gt, grads_only=True) if self.fused else self._native_step(cam, gt)
             if self.world_size > 1:
                 import torch.distributed as dist
-                dist.all_reduce(p.grad, op=dist.ReduceOp.SUM)
+                dist.all_reduce(p.grad, op=dist.ReduceOp.SUM)      # one flat 59*P-float buffer over RCCL / xGMI
             self.adam_fn()
             return pkg
         p.zero_grad()

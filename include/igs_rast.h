@@ -207,7 +207,8 @@ int igs_adam_step_groups(void* stream, int ngroups, const size_t* offset, const 
  * Everything is enqueued on `stream` without a host wait; the gradients never reach HBM (the per-Gaussian backward kernel
  * applies the update itself).  `param` / `exp_avg` / `exp_avg_sq` are flat fp32 buffers holding the five groups at the given
  * float offsets: xyz [P][3], rotation [P][4] (raw quaternion), shs [P][M][3], opacity [P] (logit), scale [P][3] (log).
- * Multi-GPU runs need the gradients for the all-reduce and use igs_rast_forward/backward + igs_adam_step_groups instead.
+ * Multi-GPU runs need the gradients for the all-reduce: with `grad_out` set the same 6 launches end in the flat gradient
+ * instead of the update (then all-reduce it and call igs_adam_step_groups).
  * Returns num_rendered or a negative error code. */
 typedef struct igs_refine_step_args {
     void* stream;
@@ -218,6 +219,8 @@ typedef struct igs_refine_step_args {
     int P, D, M, width, height;
     const float* background;                  /* [3] device */
     float *param, *exp_avg, *exp_avg_sq;      /* flat optimiser state, device */
+    float* grad_out;                          /* NULL: apply Adam in place.  Non-NULL (multi-GPU): write the flat gradient of the raw
+                                                 leaves here (same offsets) and leave param / exp_avg / exp_avg_sq untouched */
     size_t off_xyz, off_rot, off_sh, off_opacity, off_scale;
     float lr_xyz, lr_rot, lr_sh, lr_opacity, lr_scale;
     float beta1, beta2, eps;

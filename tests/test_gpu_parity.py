@@ -785,3 +785,30 @@ def test_depth_normal_regulariser_drives_the_full_backward(dev):
         ref.step(view=0)
         vals.append(float(ref.last_depth_normal_loss.detach()))
     assert vals[-1] < vals[0] - 1e-4, vals
+
+
+def test_fused_gradient_only_step_equals_unfused_native_step(dev):
+    """Multi-GPU form of the fused iteration (igs_refine_step with grad_out: activations + render + loss + backward through the
+    activations, ending in the flat gradient for the all-reduce) against the unfused native step, for both losses; parameters
+    and Adam moments stay untouched."""
+    from igs_amd.refine import GaussianParams, Refiner, render
+    from igs_amd.scenes import perturbed_copy
+    raw, cams, bg = cfg1_scene(P=3000, size=128)
+    cams = [cams[0].to(dev)]
+    bg = bg.to(dev)
+    gt_raw = {k: v.to(dev) for k, v in perturbed_copy(raw, sigma=0.03).items()}
+    with torch.no_grad():
+        gts = [render(activate(gt_raw), cams[0], bg)["images_pred"].clone()]
+    for loss in ("l1", "l1_ssim"):
+        pa, pb = GaussianParams(raw, dev), GaussianParams(raw, dev)
+        ra = Refiner(pa, cams, gts, bg, loss=loss, native=True, fused=True)
+        rb = Refiner(pb, cams, gts, bg, loss=loss, native=True, fused=False)
+        ra.adam_fn = lambda: None
+        rb.adam_fn = lambda: None
+        before = pa.flat.clone()
+        ra.step(view=0); rb.step(view=0)
+        assert torch.equal(pa.flat, before) and float(pa.exp_avg.abs().max()) == 0.0 and pa.step_count == 0
+        for k in pa.leaves:
+            A, B = pa.leaves[k].grad.cpu().numpy(), pb.leaves[k].grad.cpu().numpy()
+            r = rel(A, B)
+            assert np.quantile(r, 0.999) < 2e-3 and np.median(r) < 1e-5, (loss, k, np.quantile(r, 0.999), np.median(r))
