@@ -85,6 +85,7 @@ def main():
     ap.add_argument("--loss", default="l1", choices=["l1", "l1_ssim"])
     ap.add_argument("--cpu-views", type=int, default=2, help="views timed on the CPU oracle (0 = skip)")
     ap.add_argument("--no-profile", action="store_true", help="do not record per-stage HIP events")
+    ap.add_argument("--no-spatial-sort", action="store_true", help="keep the Gaussians in the (random) order of the synthetic scene")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse the\n"
                     "N > 1 code path on a box with fewer GPUs than ranks)")
     ap.add_argument("--profile-every", type=int, default=8,
@@ -121,6 +122,8 @@ def main():
     with torch.no_grad():
         gts = [render(activate(gt_raw), c, bg)["images_pred"].clone() for c in cams]
     params = GaussianParams(raw, dev)
+    if not args.no_spatial_sort:
+        params.spatial_sort()              # once per frame, outside the timed region: Morton order of the positions
     ref = Refiner(params, cams, gts, bg, loss=args.loss, world_size=world, rank=rank, seed=0)
 
     def barrier():

@@ -63,6 +63,49 @@ class GaussianParams:
             self.leaves[name] = leaf
             o += n
 
+    def spatial_sort(self, bits=10):
+        """Reorders the Gaussians along a Morton (Z-order) curve of their positions, in place (parameters and Adam moments, one
+        gather pass).  Consecutive Gaussians then project to neighbouring tiles, which lets the binning stage reserve slots
+        once per (workgroup, tile) instead of once per instance (preprocess.hip).  The rasterizer's results do not depend on
+        the order (apart from which of two splats at EXACTLY the same depth comes first); `self.order[i]` is the index Gaussian i
+        had when the store was created -- `original_order()` undoes every sort so far."""
+        import ctypes as C
+        xyz = self.leaves["xyz"].detach()
+        lo, hi = xyz.min(dim=0).values, xyz.max(dim=0).values
+        q = ((xyz - lo) / (hi - lo).clamp(min=1e-12) * (2 ** bits - 1)).long().clamp(0, 2 ** bits - 1)
+
+        def spread(v):
+            v = (v | (v << 16)) & 0x30000FF
+            v = (v | (v << 8)) & 0x300F00F
+            v = (v | (v << 4)) & 0x30C30C3
+            return (v | (v << 2)) & 0x9249249
+        code = spread(q[:, 0]) | (spread(q[:, 1]) << 1) | (spread(q[:, 2]) << 2)
+        perm = torch.argsort(code, stable=True).to(torch.int32).contiguous()
+        P = self.P
+        new = [torch.empty_like(self.flat) for _ in range(3)]
+        off = (C.c_size_t * 5)(*[self.spans[n][0] for n in ("xyz", "rotation", "shs", "opacity", "scaling")])
+        with torch.cuda.device(self.device):
+            rc = _cabi.lib().igs_densify_remap(torch.cuda.current_stream(self.device).cuda_stream, P, 16, perm.data_ptr(), None, None, None,
+                                               None, self.flat.data_ptr(), self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(), off,
+                                               new[0].data_ptr(), new[1].data_ptr(), new[2].data_ptr(), off)
+        if rc != 0:
+            raise RuntimeError("igs_densify_remap failed: %d" % rc)
+        prev = getattr(self, "order", None)
+        self._bind(P, *new)
+        self.order = perm.long() if prev is None or prev.numel() != P else prev[perm.long()]
+        return perm
+
+    def original_order(self):
+        """Raw leaves permuted back to the order the store was created with (valid while no densification changed the set)."""
+        out = {}
+        inv = None
+        if getattr(self, "order", None) is not None and self.order.numel() == self.P:
+            inv = torch.empty_like(self.order)
+            inv[self.order] = torch.arange(self.P, device=self.order.device)
+        for k, v in self.leaves.items():
+            out[k] = v.detach()[inv] if inv is not None else v.detach()
+        return out
+
     def activated(self):
         L = self.leaves
         return dict(means3D=L["xyz"], shs=L["shs"], opacities=torch.sigmoid(L["opacity"]), scales=torch.exp(L["scaling"]),
