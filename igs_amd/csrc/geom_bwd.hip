@@ -74,8 +74,11 @@ __device__ __forceinline__ float3 sh_backward(int deg, int M, const float* __res
 
 struct GBArgs { GeomBwdArgs a; RefineFuse f; };
 
+#ifndef GEOM_WAVES_PER_EU
+#define GEOM_WAVES_PER_EU 2
+#endif
 template <bool FUSED, int NT>
-__global__ void __launch_bounds__(NT)
+__global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(GEOM_WAVES_PER_EU)))
 geom_bwd_kernel(const GBArgs args)
 {
     const GeomBwdArgs& a = args.a;
@@ -105,6 +108,7 @@ geom_bwd_kernel(const GBArgs args)
     float4 o_rot = make_float4(0, 0, 0, 0);
     float* dsh = a.M ? dsh_lds + threadIdx.x * FS : nullptr;
     bool sh_written = false;
+    __shared__ float small_lds[FUSED ? NT * 12 : 1];      // xyz 3 | rotation 4 | opacity 1 | scale 3 gradients of every thread
 
     if (active && a.radii[idx] > 0) {
         const float4* R4 = (const float4*)(a.rec + (size_t)idx * REC_F);
@@ -402,13 +406,7 @@ geom_bwd_kernel(const GBArgs args)
             a.dL_dscale[3 * idx] = o_scale.x; a.dL_dscale[3 * idx + 1] = o_scale.y; a.dL_dscale[3 * idx + 2] = o_scale.z;
             a.dL_drot[4 * idx] = o_rot.x; a.dL_drot[4 * idx + 1] = o_rot.y; a.dL_drot[4 * idx + 2] = o_rot.z; a.dL_drot[4 * idx + 3] = o_rot.w;
         } else {
-            // ---- activation backward (gaussian_model.py:90-127) + Adam on this Gaussian's 11 small parameters ----
-            auto upd = [&](size_t off, float g, float lr) {
-                if (fz.grad_out) { fz.grad_out[off] = g; return; }       // multi-GPU: the gradient goes to the all-reduce
-                float p = fz.param[off], m = fz.exp_avg[off], v = fz.exp_avg_sq[off];
-                adam_update(p, m, v, g, lr, fz.b1, fz.b2, fz.eps, fz.inv_sqrt_bc2);
-                fz.param[off] = p; fz.exp_avg[off] = m; fz.exp_avg_sq[off] = v;
-            };
+            // ---- activation backward (gaussian_model.py:90-127) for this Gaussian's 11 small parameters ----
             const float g_xyz[3] = { o_mean.x, o_mean.y, o_mean.z };
             const float s_op = act_sigmoid(fz.param[fz.off_opacity + idx]);
             const float g_logit = o_opacity * s_op * (1.0f - s_op);
@@ -427,13 +425,12 @@ geom_bwd_kernel(const GBArgs args)
                 g_rot[0] = (o_rot.x - n0 * dt) * inv; g_rot[1] = (o_rot.y - n1 * dt) * inv;
                 g_rot[2] = (o_rot.z - n2 * dt) * inv; g_rot[3] = (o_rot.w - n3 * dt) * inv;
             }
-#pragma unroll
-            for (int k = 0; k < 3; k++) upd(fz.off_xyz + 3 * (size_t)idx + k, g_xyz[k], fz.lr_xyz);
-#pragma unroll
-            for (int k = 0; k < 4; k++) upd(fz.off_rot + 4 * (size_t)idx + k, g_rot[k], fz.lr_rot);
-            upd(fz.off_opacity + idx, g_logit, fz.lr_opacity);
-#pragma unroll
-            for (int k = 0; k < 3; k++) upd(fz.off_scale + 3 * (size_t)idx + k, g_ls[k], fz.lr_scale);
+            // staged in LDS: the update below walks each parameter group's contiguous span of this workgroup with coalesced
+            // accesses (per-thread 4-byte updates at strides of 12 / 16 bytes cost 30 us for 11 of the 59 parameters)
+            float* sg = small_lds + threadIdx.x * 12;
+            sg[0] = g_xyz[0]; sg[1] = g_xyz[1]; sg[2] = g_xyz[2];
+            sg[3] = g_rot[0]; sg[4] = g_rot[1]; sg[5] = g_rot[2]; sg[6] = g_rot[3];
+            sg[7] = g_logit; sg[8] = g_ls[0]; sg[9] = g_ls[1]; sg[10] = g_ls[2];
         }
         if (dsh && !sh_written) for (int k = 0; k < F; k++) dsh[k] = 0.f;
     }
@@ -441,6 +438,41 @@ geom_bwd_kernel(const GBArgs args)
         __syncthreads();
         const int g0 = grp * NT;
         const int ng = min(NT, a.P - g0);
+        if constexpr (FUSED) {
+            // the four small groups: element e of the workgroup's span of group (off, k) belongs to Gaussian e / k, component e % k
+            auto small_group = [&](size_t off, int k, int first, float lr) {
+                const size_t base = off + (size_t)g0 * k;
+                const int n = ng * k;
+                float* P = fz.grad_out ? fz.grad_out + base : fz.param + base;
+                float* Mo = fz.exp_avg + base; float* Vo = fz.exp_avg_sq + base;
+                const bool al = (((uintptr_t)P | (uintptr_t)Mo | (uintptr_t)Vo) & 15) == 0;
+                const int n4 = al ? n >> 2 : 0;
+                for (int i = threadIdx.x; i < n4; i += NT) {
+                    float g[4];
+#pragma unroll
+                    for (int q = 0; q < 4; q++) { const int e = 4 * i + q, gl = e / k; g[q] = small_lds[gl * 12 + first + (e - gl * k)]; }
+                    if (fz.grad_out) { ((float4*)P)[i] = make_float4(g[0], g[1], g[2], g[3]); continue; }      // multi-GPU: gradient for the all-reduce
+                    float4 P4 = ((float4*)P)[i], M4 = ((float4*)Mo)[i], V4 = ((float4*)Vo)[i];
+                    adam_update(P4.x, M4.x, V4.x, g[0], lr, fz.b1, fz.b2, fz.eps, fz.inv_sqrt_bc2);
+                    adam_update(P4.y, M4.y, V4.y, g[1], lr, fz.b1, fz.b2, fz.eps, fz.inv_sqrt_bc2);
+                    adam_update(P4.z, M4.z, V4.z, g[2], lr, fz.b1, fz.b2, fz.eps, fz.inv_sqrt_bc2);
+                    adam_update(P4.w, M4.w, V4.w, g[3], lr, fz.b1, fz.b2, fz.eps, fz.inv_sqrt_bc2);
+                    ((float4*)P)[i] = P4; ((float4*)Mo)[i] = M4; ((float4*)Vo)[i] = V4;
+                }
+                for (int e = 4 * n4 + threadIdx.x; e < n; e += NT) {
+                    const int gl = e / k;
+                    const float g = small_lds[gl * 12 + first + (e - gl * k)];
+                    if (fz.grad_out) { P[e] = g; continue; }
+                    float p = P[e], m = Mo[e], v = Vo[e];
+                    adam_update(p, m, v, g, lr, fz.b1, fz.b2, fz.eps, fz.inv_sqrt_bc2);
+                    P[e] = p; Mo[e] = m; Vo[e] = v;
+                }
+            };
+            small_group(fz.off_xyz, 3, 0, fz.lr_xyz);
+            small_group(fz.off_rot, 4, 3, fz.lr_rot);
+            small_group(fz.off_opacity, 1, 7, fz.lr_opacity);
+            small_group(fz.off_scale, 3, 8, fz.lr_scale);
+        }
         const int total = ng * F;
         float* dst = FUSED ? fz.param + fz.off_sh + (size_t)g0 * F : a.dL_dsh + (size_t)g0 * F;
         float* dst_m = FUSED ? fz.exp_avg + fz.off_sh + (size_t)g0 * F : nullptr;
