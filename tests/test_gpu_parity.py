@@ -844,3 +844,18 @@ def test_spatial_sort_keeps_results_and_aggregated_binning_is_exact(dev):
     # sorting twice composes
     perm2 = pb.spatial_sort().long()
     assert torch.equal(pb.order, perm[perm2])
+
+
+def test_streaming_refinement_tracks_a_moving_scene(dev):
+    """The per-frame loop (igs_amd/stream.py; infer_batch.py:245-357 without AGM-Net): every frame starts from the previous
+    frame's result with a fresh optimiser and must recover PSNR lost to the scene's motion."""
+    from igs_amd.stream import run_stream, SyntheticStream
+    raw, cams, bg = cfg1_scene(P=3000, size=128)
+    src = SyntheticStream(raw, [c.to(dev) for c in cams], bg.to(dev), dev, motion_sigma=0.02, seed=3, start_sigma=0.03)
+    src.dynamic[:] = True
+    res = run_stream(raw, cams, bg, frames=3, refine_iterations=25, device=dev, loss="l1_ssim", source=src,
+                     lrs=dict(xyz=0.002, rotation=0.001, shs=0.0025, opacity=0.01, scaling=0.001))
+    assert len(res) == 3
+    for r in res:
+        assert r["psnr_after"] > r["psnr_before"] + 0.3, r
+    assert res[2]["psnr_before"] > res[0]["psnr_before"] - 3.0          # the stream does not drift away
