@@ -70,33 +70,37 @@ ssim_stats_kernel(const SsimWin win, int W, int H, const float* __restrict__ x, 
         }
     }
     __syncthreads();
-    // horizontal: work item = (halo row r, group of 4 output columns); consecutive lanes = consecutive rows
-    for (int i = tid; i < SSIM_H * (SSIM_T / 4); i += 256) {
-        const int qg = i / SSIM_H, r = i - qg * SSIM_H, q = qg * 4;
-        float u[16], v[16], uu[14], vv[14], uv[14];
+    // horizontal: work item = (halo row r, group of 8 output columns): 42 x 4 = 168 items, one pass of the 256 threads;
+    // consecutive lanes = consecutive rows
+    if (tid < SSIM_H * (SSIM_T / 8)) {
+        const int qg = tid / SSIM_H, r = tid - qg * SSIM_H, q = qg * 8;
+        float u[20], v[20], uu[18], vv[18], uv[18];
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
+        for (int k = 0; k < 5; k++) {
             const float4 a = *(const float4*)&sx[r][q + 4 * k], b = *(const float4*)&sy[r][q + 4 * k];
             u[4 * k] = a.x; u[4 * k + 1] = a.y; u[4 * k + 2] = a.z; u[4 * k + 3] = a.w;
             v[4 * k] = b.x; v[4 * k + 1] = b.y; v[4 * k + 2] = b.z; v[4 * k + 3] = b.w;
         }
 #pragma unroll
-        for (int k = 0; k < 14; k++) { uu[k] = u[k] * u[k]; vv[k] = v[k] * v[k]; uv[k] = u[k] * v[k]; }
-        float a0[4], a1[4], a2[4], a3[4], a4[4];
+        for (int k = 0; k < 18; k++) { uu[k] = u[k] * u[k]; vv[k] = v[k] * v[k]; uv[k] = u[k] * v[k]; }
 #pragma unroll
-        for (int o = 0; o < 4; o++) {
-            a0[o] = 0.f; a1[o] = 0.f; a2[o] = 0.f; a3[o] = 0.f; a4[o] = 0.f;
+        for (int h = 0; h < 2; h++) {
+            float a0[4], a1[4], a2[4], a3[4], a4[4];
 #pragma unroll
-            for (int k = 0; k <= 2 * SSIM_R; k++) {
-                const float w = win.g[k];
-                a0[o] += w * u[o + k]; a1[o] += w * v[o + k]; a2[o] += w * uu[o + k]; a3[o] += w * vv[o + k]; a4[o] += w * uv[o + k];
+            for (int o = 0; o < 4; o++) {
+                a0[o] = 0.f; a1[o] = 0.f; a2[o] = 0.f; a3[o] = 0.f; a4[o] = 0.f;
+#pragma unroll
+                for (int k = 0; k <= 2 * SSIM_R; k++) {
+                    const float w = win.g[k]; const int j = 4 * h + o + k;
+                    a0[o] += w * u[j]; a1[o] += w * v[j]; a2[o] += w * uu[j]; a3[o] += w * vv[j]; a4[o] += w * uv[j];
+                }
             }
+            *(float4*)&hb[0][r][q + 4 * h] = make_float4(a0[0], a0[1], a0[2], a0[3]);
+            *(float4*)&hb[1][r][q + 4 * h] = make_float4(a1[0], a1[1], a1[2], a1[3]);
+            *(float4*)&hb[2][r][q + 4 * h] = make_float4(a2[0], a2[1], a2[2], a2[3]);
+            *(float4*)&hb[3][r][q + 4 * h] = make_float4(a3[0], a3[1], a3[2], a3[3]);
+            *(float4*)&hb[4][r][q + 4 * h] = make_float4(a4[0], a4[1], a4[2], a4[3]);
         }
-        *(float4*)&hb[0][r][q] = make_float4(a0[0], a0[1], a0[2], a0[3]);
-        *(float4*)&hb[1][r][q] = make_float4(a1[0], a1[1], a1[2], a1[3]);
-        *(float4*)&hb[2][r][q] = make_float4(a2[0], a2[1], a2[2], a2[3]);
-        *(float4*)&hb[3][r][q] = make_float4(a3[0], a3[1], a3[2], a3[3]);
-        *(float4*)&hb[4][r][q] = make_float4(a4[0], a4[1], a4[2], a4[3]);
     }
     __syncthreads();
     // vertical: work item = (column lx, group of 4 output rows)
@@ -168,24 +172,27 @@ ssim_grad_kernel(const SsimWin win, int W, int H, const float* __restrict__ x, c
         }
     }
     __syncthreads();
-    for (int i = tid; i < SSIM_H * (SSIM_T / 4); i += 256) {
-        const int qg = i / SSIM_H, r = i - qg * SSIM_H, q = qg * 4;
+    if (tid < SSIM_H * (SSIM_T / 8)) {
+        const int qg = tid / SSIM_H, r = tid - qg * SSIM_H, q = qg * 8;
 #pragma unroll
         for (int m = 0; m < 3; m++) {
-            float u[16];
+            float u[20];
 #pragma unroll
-            for (int k = 0; k < 4; k++) {
+            for (int k = 0; k < 5; k++) {
                 const float4 a = *(const float4*)&sm[m][r][q + 4 * k];
                 u[4 * k] = a.x; u[4 * k + 1] = a.y; u[4 * k + 2] = a.z; u[4 * k + 3] = a.w;
             }
-            float acc[4];
 #pragma unroll
-            for (int o = 0; o < 4; o++) {
-                acc[o] = 0.f;
+            for (int h = 0; h < 2; h++) {
+                float acc[4];
 #pragma unroll
-                for (int k = 0; k <= 2 * SSIM_R; k++) acc[o] += win.g[k] * u[o + k];
+                for (int o = 0; o < 4; o++) {
+                    acc[o] = 0.f;
+#pragma unroll
+                    for (int k = 0; k <= 2 * SSIM_R; k++) acc[o] += win.g[k] * u[4 * h + o + k];
+                }
+                *(float4*)&hb[m][r][q + 4 * h] = make_float4(acc[0], acc[1], acc[2], acc[3]);
             }
-            *(float4*)&hb[m][r][q] = make_float4(acc[0], acc[1], acc[2], acc[3]);
         }
     }
     __syncthreads();
