@@ -859,3 +859,30 @@ def test_streaming_refinement_tracks_a_moving_scene(dev):
     for r in res:
         assert r["psnr_after"] > r["psnr_before"] + 0.3, r
     assert res[2]["psnr_before"] > res[0]["psnr_before"] - 3.0          # the stream does not drift away
+
+
+def test_fused_step_on_a_ragged_image(dev):
+    """igs_refine_step on an image whose sides are no multiples of the 16-pixel blend tile or the 32-pixel SSIM tile (203 x 150),
+    both losses: same loss value and parameters as the unfused step."""
+    import math
+    from igs_amd.camera import Camera
+    from igs_amd.refine import GaussianParams, Refiner, render
+    from igs_amd.scenes import perturbed_copy
+    raw, _, bg = cfg1_scene(P=2500, size=64)
+    c2w = torch.eye(4); c2w[2, 3] = -5.0
+    cam = Camera.from_c2w(c2w, (math.radians(60.0), math.radians(46.0)), (150, 203)).to(dev)
+    bg = torch.tensor([0.1, 0.2, 0.3]).to(dev)
+    gt_raw = {k: v.to(dev) for k, v in perturbed_copy(raw, sigma=0.03).items()}
+    with torch.no_grad():
+        gts = [render(activate(gt_raw), cam, bg)["images_pred"].clone()]
+    assert gts[0].shape == (3, 150, 203)
+    for loss in ("l1", "l1_ssim"):
+        pa, pb = GaussianParams(raw, dev), GaussianParams(raw, dev)
+        ra = Refiner(pa, [cam], gts, bg, loss=loss, fused=True)
+        rb = Refiner(pb, [cam], gts, bg, loss=loss, fused=False)
+        pka = ra.step(view=0); rb.step(view=0)
+        la = float(pka["loss"].item())
+        lb = rb.l1.value(gts[0].numel()) if loss == "l1_ssim" else float(rb.l1.loss_sum.sum().item()) / gts[0].numel()
+        assert abs(la - lb) < 1e-5 * max(1.0, abs(lb)), (loss, la, lb)
+        d = (pa.flat - pb.flat).abs().cpu().numpy()
+        assert np.quantile(d, 0.98) < 2e-6 and d.max() <= 0.11, (loss, np.quantile(d, 0.98), d.max())
