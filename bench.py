@@ -76,14 +76,14 @@ def cpu_baseline(raw, cams, bg, gts, n_views):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--points", type=int, default=200000)
     ap.add_argument("--width", type=int, default=1352)
     ap.add_argument("--height", type=int, default=1014)
     ap.add_argument("--cams", type=int, default=10)
     ap.add_argument("--loss", default="l1", choices=["l1", "l1_ssim"])
-    ap.add_argument("--cpu-views", type=int, default=2, help="views timed on the CPU oracle (0 = skip)")
+    ap.add_argument("--cpu-views", type=int, default=3, help="views timed on the CPU oracle (0 = skip)")
     ap.add_argument("--no-profile", action="store_true", help="do not record per-stage HIP events")
     ap.add_argument("--no-spatial-sort", action="store_true", help="keep the Gaussians in the (random) order of the synthetic scene")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse the\n"
