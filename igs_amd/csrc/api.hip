@@ -42,7 +42,7 @@ enum { ST_PREPROCESS = 0, ST_DEPTH_SORT, ST_SCAN, ST_EMIT, ST_TILE_SORT, ST_RANG
 struct Prof {
     bool on = false;
     int every = 1; long long frame = 0; bool active = false;     // marks are recorded on every `every`-th frame only
-    static const int CAP = 4096;
+    static const int CAP = 1024;
     hipEvent_t ev[CAP]; int tag[CAP]; int n = 0; bool created = false;
     double ms[ST_COUNT] = {0}; long long cnt[ST_COUNT] = {0}; double r_sum = 0; long long calls = 0;
 };
@@ -63,7 +63,6 @@ static void prof_collect()
 static void prof_mark(hipStream_t s, int tag)
 {
     if (!g_prof.on || !g_prof.active) return;
-    if (!g_prof.created) { for (int i = 0; i < Prof::CAP; i++) (void)hipEventCreate(&g_prof.ev[i]); g_prof.created = true; }
     if (g_prof.n >= Prof::CAP - 1) {                // keep the last mark as the start of the next interval
         const hipEvent_t last = g_prof.ev[g_prof.n - 1];
         prof_collect();
@@ -78,6 +77,8 @@ static void prof_mark(hipStream_t s, int tag)
 extern "C" int igs_rast_profile_enable(int on)
 {
     if (!on) prof_collect();
+    // (the events are created here, not at the first mark: a thousand hipEventCreate calls take over a millisecond)
+    if (on && !g_prof.created) { for (int i = 0; i < Prof::CAP; i++) (void)hipEventCreate(&g_prof.ev[i]); g_prof.created = true; }
     g_prof.on = on != 0; g_prof.every = on > 0 ? on : 1; g_prof.frame = 0; g_prof.active = g_prof.on;
     return 0;
 }
