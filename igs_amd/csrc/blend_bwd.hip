@@ -116,11 +116,13 @@ blend_bwd_kernel(const BlendBwdArgs a)
     }
 
     // nothing behind the deepest last_contributor of the tile is ever touched: start there
+    int my_wave_max;                               // ... and this wave's own deepest one (wave-uniform): rows behind it are skipped
     {
         int m = last_contributor;
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) m = max(m, __shfl_xor(m, off, 64));
         if (lane == 0) wave_max[wid] = m;
+        my_wave_max = __builtin_amdgcn_readfirstlane(m);
     }
     __syncthreads();
     const int n = max(max(wave_max[0], wave_max[1]), max(wave_max[2], wave_max[3]));   // elements [0, n) of the range
@@ -175,6 +177,7 @@ blend_bwd_kernel(const BlendBwdArgs a)
                 const int j = sw * 64 + __builtin_ctzll(bits);
                 bits &= bits - 1;
                 const int eidx = n - 1 - (i * BCHUNK + j);      // 0-based position in the tile's list = the reference's `contributor`
+                if (eidx >= my_wave_max) continue;              // (scalar test) behind every pixel of this quad: another quad's tail
                 const float4 q0 = chunk[j * NQ + 0];
                 const float4 q1 = chunk[j * NQ + 1];
                 const float dx = q0.x - pixfx, dy = q0.y - pixfy;

@@ -207,7 +207,12 @@ __device__ __forceinline__ void adam_update(float& p, float& m, float& v, float 
 }
 struct M3 { float m[3][3]; };     // standard row-major [row][col]
 
+// The helpers below feed discrete decisions of the per-Gaussian stage (near-plane cull, radius, tile rectangle, depth key):
+// every multiply and add is rounded separately, like the oracle's plain C (`#pragma clang fp contract(off)` travels with the
+// instructions when the function is inlined; a pragma placed after this header's inclusion would not reach them).
+
 __device__ __forceinline__ M3 m3_mul(const M3& A, const M3& B) {
+#pragma clang fp contract(off)
     M3 R;
 #pragma unroll
     for (int i = 0; i < 3; i++)
@@ -224,26 +229,33 @@ __device__ __forceinline__ M3 m3_T(const M3& A) {
     return R;
 }
 __device__ __forceinline__ float3 m3_vec(const M3& A, float3 v) {
+#pragma clang fp contract(off)
     return make_float3(A.m[0][0] * v.x + A.m[0][1] * v.y + A.m[0][2] * v.z,
                        A.m[1][0] * v.x + A.m[1][1] * v.y + A.m[1][2] * v.z,
                        A.m[2][0] * v.x + A.m[2][1] * v.y + A.m[2][2] * v.z);
 }
 __device__ __forceinline__ float3 m3T_vec(const M3& A, float3 v) {   // A^T v
+#pragma clang fp contract(off)
     return make_float3(A.m[0][0] * v.x + A.m[1][0] * v.y + A.m[2][0] * v.z,
                        A.m[0][1] * v.x + A.m[1][1] * v.y + A.m[2][1] * v.z,
                        A.m[0][2] * v.x + A.m[1][2] * v.y + A.m[2][2] * v.z);
 }
-__device__ __forceinline__ float dot3(float3 a, float3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ __forceinline__ float dot3(float3 a, float3 b) {
+#pragma clang fp contract(off)
+    return a.x * b.x + a.y * b.y + a.z * b.z;
+}
 __device__ __forceinline__ float3 operator*(float3 a, float s) { return make_float3(a.x * s, a.y * s, a.z * s); }
 __device__ __forceinline__ float3 operator+(float3 a, float3 b) { return make_float3(a.x + b.x, a.y + b.y, a.z + b.z); }
 __device__ __forceinline__ float3 operator-(float3 a, float3 b) { return make_float3(a.x - b.x, a.y - b.y, a.z - b.z); }
 
 // the reference's transformPoint4x3 / 4x4 on the TRANSPOSED matrices the callers pass (auxiliary.h:74-93)
 __device__ __forceinline__ float3 xform4x3(float3 p, const float* m) {
+#pragma clang fp contract(off)
     return make_float3(m[0] * p.x + m[4] * p.y + m[8] * p.z + m[12], m[1] * p.x + m[5] * p.y + m[9] * p.z + m[13],
                        m[2] * p.x + m[6] * p.y + m[10] * p.z + m[14]);
 }
 __device__ __forceinline__ float4 xform4x4(float3 p, const float* m) {
+#pragma clang fp contract(off)
     return make_float4(m[0] * p.x + m[4] * p.y + m[8] * p.z + m[12], m[1] * p.x + m[5] * p.y + m[9] * p.z + m[13],
                        m[2] * p.x + m[6] * p.y + m[10] * p.z + m[14], m[3] * p.x + m[7] * p.y + m[11] * p.z + m[15]);
 }

@@ -94,7 +94,7 @@ def check_images(out, oo, tol=1e-4, flips=2e-4):
             assert d.max() < 0.05, (k, d.max())
 
 
-def check_grads(gout, gr, bulk=0.96, p99=1e-2):
+def check_grads(gout, gr, bulk=0.96, p99=1e-2, worst=0.25):
     for n, t in zip(GNAMES, gout):
         A = t.cpu().numpy().reshape(gr[n].shape)
         assert not np.isnan(A).any(), n
@@ -102,7 +102,7 @@ def check_grads(gout, gr, bulk=0.96, p99=1e-2):
         assert (r <= 1e-3).mean() >= bulk, (n, (r <= 1e-3).mean(), r.max())
         assert np.median(r) < 1e-4, (n, np.median(r))
         assert np.quantile(r, 0.99) < p99, (n, np.quantile(r, 0.99))
-        assert r.max() < 0.25, (n, r.max())
+        assert r.max() < worst, (n, r.max())
 
 
 @pytest.mark.parametrize("req", [(True, True), (True, False), (False, True), (False, False)])
@@ -886,3 +886,32 @@ def test_fused_step_on_a_ragged_image(dev):
         assert abs(la - lb) < 1e-5 * max(1.0, abs(lb)), (loss, la, lb)
         d = (pa.flat - pb.flat).abs().cpu().numpy()
         assert np.quantile(d, 0.98) < 2e-6 and d.max() <= 0.11, (loss, np.quantile(d, 0.98), d.max())
+
+
+def test_full_size_frame_matches_oracle(dev):
+    """BASELINE.json configs[1]/[2] at FULL size (200k Gaussians, 1352x1014, one view): the instance count, radii, the sorted
+    instance list, the tile ranges and the contributor counts are bit-exact against the CPU oracle, the seven images are within
+    1e-4, and the colour-loss gradients agree on the bulk (about 4 s of oracle time)."""
+    from igs_amd import rasterizer as R
+    raw, cams, bg = sear_steak_like_scene()
+    cam, a = cams[3], activate(raw)
+    out, ad, mats = hip_forward(a, cam, bg, dev, debug=False)
+    nr_o, oo, st = oracle_forward(a, cam, bg)
+    it = st.intermediates()
+    P = a["means3D"].shape[0]
+    d = R.debug_dump(P, out[0], cam.width, cam.height, out[9], out[10], out[11])
+    assert out[0] == nr_o and nr_o > 400000
+    np.testing.assert_array_equal(out[8].cpu().numpy(), oo["radii"])
+    np.testing.assert_array_equal(d["point_list"].cpu().numpy().astype(np.uint32), it["point_list"])
+    np.testing.assert_array_equal(d["ranges"].cpu().numpy().astype(np.uint32), it["ranges"])
+    np.testing.assert_array_equal(d["n_contrib"].cpu().numpy().astype(np.uint32), it["n_contrib"])
+    check_images(out, oo)
+    rng = np.random.default_rng(1)
+    g = {k: None for k in KEYS}
+    g["color"] = (rng.standard_normal(tuple(out[1].shape)) / out[1].numel()).astype(np.float32)
+    zeros = {k: np.zeros(tuple(out[i].shape), np.float32) for k, i in zip(KEYS, (1, 2, 3, 6, 7, 4, 5))}
+    zeros["color"] = g["color"]
+    gout = hip_backward(out, ad, mats, cam, bg, dev, zeros)
+    gr = oracle_backward(st, oo, a, cam, bg, zeros)
+    # (worst single element out of ~12 million: behind saturated pixels 1/T_final amplifies last-ulp differences, DESIGN.md 2)
+    check_grads(gout, gr, worst=1.0)
