@@ -178,8 +178,8 @@ static int forward_impl(
     uint32_t* ranges = (uint32_t*)(ibase + IL.ranges);
     uint32_t* point_list = nullptr;
     uint32_t R = 0;
-    bool bucket_pending = false;            // bucket path: the host has not looked at R yet
-    uint32_t bucket_cap = 0;                // slab size of this call
+    bool slab_pending = false;            // slab path: the host has not looked at R yet
+    uint32_t slab_size = 0;                // slab size of this call
     const uint32_t* slab_stats = nullptr;
 
     if (!force_radix) {
@@ -198,7 +198,7 @@ static int forward_impl(
                                 out_coord, out_mcoord, out_depth, out_mdepth, out_alpha, out_normal, radii, require_coord, require_depth,
                                 debug, true, 0);
         }
-        bucket_cap = (uint32_t)slab;
+        slab_size = (uint32_t)slab;
         const SlabLayout KL(Tn, slab);
         char* bbase = binning_buffer(binning_user, KL.total);
         if (!bbase) return fail(IGS_RAST_E_ALLOC, "binning buffer callback returned NULL");
@@ -208,16 +208,16 @@ static int forward_impl(
         counters = (uint32_t*)(ibase + IL.counters);
         HIP_TRY(hipMemsetAsync(tile_count, 0, IL.zero_end - IL.tile_count, s), "memset tile counters");   // tile_count + stats + counters
         prof_mark(s, ST_GAP);
-        HIP_TRY(launch_preprocess_fwd(s, fp, rec, tiles, nullptr, nullptr, radii, counters, nullptr, 0, tile_count, pairs, bucket_cap),
+        HIP_TRY(launch_preprocess_fwd(s, fp, rec, tiles, nullptr, nullptr, radii, counters, nullptr, 0, tile_count, pairs, slab_size),
                 "preprocess_fwd launch");
         DBG_SYNC("preprocess_fwd");
         prof_mark(s, ST_PREPROCESS);
-        HIP_TRY(launch_tile_sort(s, (uint32_t)Tn, tile_count, pairs, point_list, ranges, bucket_cap, stats, counters), "tile_sort launch");
+        HIP_TRY(launch_tile_sort(s, (uint32_t)Tn, tile_count, pairs, point_list, ranges, slab_size, stats, counters), "tile_sort launch");
         DBG_SYNC("tile_sort");
         prof_mark(s, ST_TILE_SORT);
         slab_stats = stats;
         g_last_fwd.overflow = stats + 1; g_last_fwd.prefilter = counters + 1;
-        bucket_pending = true;
+        slab_pending = true;
     } else {
         // ---------------- global radix binning (fallback for tiles denser than TILE_SORT_BIG) ----------------
         HIP_TRY(hipMemsetAsync(counters, 0, counter_bytes, s), "memset counters");
@@ -295,17 +295,17 @@ static int forward_impl(
     ba.n_contrib = (uint32_t*)(ibase + IL.n_contrib);
     ba.accum_coord = (float*)(ibase + IL.accum_coord); ba.accum_depth = (float*)(ibase + IL.accum_depth);
     ba.normal_length = (float*)(ibase + IL.normal_length);
-    ba.stats_src = slab_stats; ba.flag_src = counters + 1; ba.host_dst = bucket_pending ? g_slot.pinned_dev : nullptr;
+    ba.stats_src = slab_stats; ba.flag_src = counters + 1; ba.host_dst = slab_pending ? g_slot.pinned_dev : nullptr;
     HIP_TRY(launch_blend_fwd(s, ba, require_coord != 0, require_depth != 0), "blend_fwd launch");
     DBG_SYNC("blend_fwd");
     prof_mark(s, ST_BLEND_FWD);
-    if (bucket_pending) HIP_TRY(hipEventRecord(g_slot.ev, s), "event record");
-    if (bucket_pending && g_async_request) {
-        g_pending.active = true; g_pending.slab = bucket_cap;
+    if (slab_pending) HIP_TRY(hipEventRecord(g_slot.ev, s), "event record");
+    if (slab_pending && g_async_request) {
+        g_pending.active = true; g_pending.slab = slab_size;
         if (g_prof.on) g_prof.calls++;
         return 0x7FFFFFFF;                       // "unknown yet": an upper bound that igs_rast_backward accepts as R
     }
-    if (bucket_pending) {
+    if (slab_pending) {
         // only now does the host look at R: the whole pipeline above was enqueued without waiting for it
         HIP_TRY(hipEventSynchronize(g_slot.ev), "event sync");
         const uint32_t R_dev = g_slot.pinned[0], overflow = g_slot.pinned[1];
