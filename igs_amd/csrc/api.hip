@@ -21,6 +21,8 @@ static int fail(int code, const char* what, hipError_t e = hipSuccess)
 // pinned 4-byte read-back slot + event, one per host thread and device
 struct HostSlot { int device = -1; uint32_t* pinned = nullptr; uint32_t* pinned_dev = nullptr; hipEvent_t ev = nullptr; };
 static thread_local HostSlot g_slot;
+static thread_local hipStream_t g_status_stream = nullptr;
+static thread_local uint32_t g_host_seq = 0;      // sequence number of the last status the blend kernel was asked to post
 static int ensure_slot()
 {
     int dev = 0;
@@ -32,6 +34,23 @@ static int ensure_slot()
     HIP_TRY(hipEventCreateWithFlags(&g_slot.ev, hipEventDisableTiming), "hipEventCreate");
     g_slot.device = dev;
     return 0;
+}
+
+// Waits until the blend kernel of the current slab-binned frame has posted {R, overflow, prefilter flag} into pinned host
+// memory: a poll on the sequence word instead of an event -- an event record between blend_fwd and blend_bwd costs the stream
+// a ~6 us bubble per step, and the first workgroup posts at the START of the kernel, so the host is released earlier too.
+static int wait_status(hipStream_t s)
+{
+    volatile uint32_t* seq = (volatile uint32_t*)&g_slot.pinned[3];
+    for (long spins = 0;; spins++) {
+        if (__atomic_load_n(seq, __ATOMIC_ACQUIRE) == g_host_seq) return 0;
+        if ((spins & 0xFFFF) == 0xFFFF) {
+            const hipError_t q = hipStreamQuery(s);
+            if (q != hipSuccess && q != hipErrorNotReady) return fail(IGS_RAST_E_HIP, "stream error while waiting for the frame status");
+            if (q == hipSuccess && __atomic_load_n(seq, __ATOMIC_ACQUIRE) != g_host_seq)
+                return fail(IGS_RAST_E_HIP, "the frame status was never posted");
+        }
+    }
 }
 
 static int ceil_log2(uint32_t n) { int b = 0; while ((1u << b) < n) b++; return b; }
@@ -296,10 +315,12 @@ static int forward_impl(
     ba.accum_coord = (float*)(ibase + IL.accum_coord); ba.accum_depth = (float*)(ibase + IL.accum_depth);
     ba.normal_length = (float*)(ibase + IL.normal_length);
     ba.stats_src = slab_stats; ba.flag_src = counters + 1; ba.host_dst = slab_pending ? g_slot.pinned_dev : nullptr;
+    if (slab_pending) { g_host_seq = g_host_seq + 1 ? g_host_seq + 1 : 1; g_slot.pinned[3] = 0; }
+    ba.host_seq = g_host_seq;
+    g_status_stream = s;
     HIP_TRY(launch_blend_fwd(s, ba, require_coord != 0, require_depth != 0), "blend_fwd launch");
     DBG_SYNC("blend_fwd");
     prof_mark(s, ST_BLEND_FWD);
-    if (slab_pending) HIP_TRY(hipEventRecord(g_slot.ev, s), "event record");
     if (slab_pending && g_async_request) {
         g_pending.active = true; g_pending.slab = slab_size;
         if (g_prof.on) g_prof.calls++;
@@ -307,7 +328,7 @@ static int forward_impl(
     }
     if (slab_pending) {
         // only now does the host look at R: the whole pipeline above was enqueued without waiting for it
-        HIP_TRY(hipEventSynchronize(g_slot.ev), "event sync");
+        if (int rc = wait_status(s)) return rc;
         const uint32_t R_dev = g_slot.pinned[0], overflow = g_slot.pinned[1];
         if (g_slot.pinned[2]) return fail(IGS_RAST_E_PREFILTER, "Point is filtered although prefiltered is set. This shouldn't happen!");
         if (R_dev > 0x7FFFFFFFu) return fail(IGS_RAST_E_INVALID, "instance count overflows int");
@@ -383,7 +404,7 @@ extern "C" int igs_rast_forward_finish(void)
 {
     if (!g_pending.active) return fail(IGS_RAST_E_INVALID, "igs_rast_forward_finish: no asynchronous forward pending");
     g_pending.active = false;
-    HIP_TRY(hipEventSynchronize(g_slot.ev), "event sync");
+    if (int rc = wait_status(g_status_stream)) return rc;
     const uint32_t R_dev = g_slot.pinned[0], overflow = g_slot.pinned[1];
     if (g_slot.pinned[2]) return fail(IGS_RAST_E_PREFILTER, "Point is filtered although prefiltered is set. This shouldn't happen!");
     if (R_dev > 0x7FFFFFFFu) return fail(IGS_RAST_E_INVALID, "instance count overflows int");

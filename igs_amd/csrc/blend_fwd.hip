@@ -24,6 +24,8 @@ blend_fwd_kernel(const BlendFwdArgs a)
     if (blockIdx.x == 0 && threadIdx.x == 0 && a.host_dst) {
         a.host_dst[0] = a.stats_src[0]; a.host_dst[1] = a.stats_src[1]; a.host_dst[2] = a.flag_src[0];
         __threadfence_system();
+        __hip_atomic_store(&a.host_dst[3], a.host_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);      // the host polls this word
+        __threadfence_system();
     }
     uint32_t tile;
     if (!tile_for_block(blockIdx.x, a.gx, a.gy, tile)) return;

@@ -143,7 +143,7 @@ struct BlendFwdArgs {
     float *out_color, *out_coord, *out_mcoord, *out_depth, *out_mdepth, *out_alpha, *out_normal;
     uint32_t* n_contrib; float *accum_coord, *accum_depth, *normal_length;
     // slab binning: workgroup 0 forwards {R, overflow, prefilter flag} to host-visible memory (no copy kernels on the stream)
-    const uint32_t* stats_src; const uint32_t* flag_src; uint32_t* host_dst;
+    const uint32_t* stats_src; const uint32_t* flag_src; uint32_t* host_dst; uint32_t host_seq;      // host_dst[3] = host_seq, written last
 };
 hipError_t launch_blend_fwd(hipStream_t s, const BlendFwdArgs& a, bool coord, bool depth);
 
