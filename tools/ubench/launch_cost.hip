@@ -1,4 +1,5 @@
 // Micro-benchmark: what does a (nearly) empty kernel cost as a function of grid size, workgroup size, dynamic LDS and VGPR
+// build: hipcc --offload-arch=gfx950 -O3 -o tools/ubench/launch_cost tools/ubench/launch_cost.hip ; run it on the GPU box
 // allocation?  (Question behind it: the fused per-Gaussian backward + Adam kernel takes ~80 us whatever its body does.)
 #include <hip/hip_runtime.h>
 #include <cstdio>
