@@ -245,6 +245,7 @@ class Refiner:
         self.gen = torch.Generator().manual_seed(seed)      # same seed on every rank -> same view permutation
         self.order = []
         self.last_num_rendered = 0
+        self.torch_ssim = False       # autograd path: use the PyTorch SSIM (five grouped convolutions) instead of the fused one
         # optional densify-and-prune (configs/demo.yaml:57-62): a DensifyConfig; statistics and iteration counter per frame
         self.densify = densify
         self.iteration = 0
@@ -443,7 +444,12 @@ class Refiner:
             img.backward(gradient=self.grad_img)
         else:
             Ll1 = torch.abs(img - gt).mean()
-            loss = Ll1 if self.loss == "l1" else self.lambda_l1 * Ll1 + (1.0 - self.lambda_l1) * (1.0 - ssim(img, gt))
+            if self.loss == "l1":
+                loss = Ll1
+            else:       # infer_batch.py:302, with the drop-in fused SSIM (igs_amd/losses.py) unless the caller asked for torch's
+                from .losses import ssim as fused_ssim
+                s_val = ssim(img, gt) if self.torch_ssim else fused_ssim(img, gt.unsqueeze(0), size_average=False).squeeze()
+                loss = self.lambda_l1 * Ll1 + (1.0 - self.lambda_l1) * (1.0 - s_val)
             if self.lambda_depth_normal > 0.0:
                 from .regularizers import depth_normal_loss
                 self.last_depth_normal_loss = depth_normal_loss(pkg, cam)

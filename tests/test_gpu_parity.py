@@ -915,3 +915,22 @@ def test_full_size_frame_matches_oracle(dev):
     gr = oracle_backward(st, oo, a, cam, bg, zeros)
     # (worst single element out of ~12 million: behind saturated pixels 1/T_final amplifies last-ulp differences)
     check_grads(gout, gr, worst=1.0)
+
+
+def test_drop_in_ssim_matches_the_reference_formula(dev):
+    """igs_amd.losses.ssim with the reference's call shape (`ssim(render, gt.unsqueeze(0), size_average=False)`): value and
+    gradient against the PyTorch restatement of loss_utils.py:34-63; other argument shapes fall back to that restatement."""
+    from igs_amd.losses import ssim as fused, _ssim_torch
+    g = torch.Generator().manual_seed(9)
+    gt = torch.rand((3, 90, 131), generator=g).to(dev)
+    x = (gt + 0.1 * torch.randn(gt.shape, generator=g).to(dev)).clamp(0, 1)
+    a = x.clone().requires_grad_(True)
+    b = x.clone().requires_grad_(True)
+    va = fused(a, gt.unsqueeze(0), size_average=False)
+    vb = _ssim_torch(b, gt.unsqueeze(0), 11, False)
+    assert va.shape == vb.shape == (1,)
+    torch.testing.assert_close(va, vb, rtol=1e-5, atol=1e-6)
+    (1.0 - va).sum().backward(); (1.0 - vb).sum().backward()
+    assert float((a.grad - b.grad).abs().max()) < 2e-4 * float(b.grad.abs().max())
+    m, mp = fused(x, gt, size_average=True)                       # fallback keeps the (mean, map) return
+    assert mp.shape == (3, 90, 131) and abs(float(m.detach()) - float(vb.detach())) < 1e-5
