@@ -85,6 +85,9 @@ def main():
     ap.add_argument("--loss", default="l1", choices=["l1", "l1_ssim"])
     ap.add_argument("--cpu-views", type=int, default=3, help="views timed on the CPU oracle (0 = skip)")
     ap.add_argument("--no-profile", action="store_true", help="do not record per-stage HIP events")
+    ap.add_argument("--colour-only-forward", action="store_true",
+                    help="NOT the reference configuration: render colour only (require_coord = require_depth = False); the L1 / SSIM\n"
+                         "losses never look at the other outputs, so the refined parameters are the same")
     ap.add_argument("--no-spatial-sort", action="store_true", help="keep the Gaussians in the (random) order of the synthetic scene")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse the\n"
                     "N > 1 code path on a box with fewer GPUs than ranks)")
@@ -125,6 +128,7 @@ def main():
     if not args.no_spatial_sort:
         params.spatial_sort()              # once per frame, outside the timed region: Morton order of the positions
     ref = Refiner(params, cams, gts, bg, loss=args.loss, world_size=world, rank=rank, seed=0)
+    ref.require_geometry = not args.colour_only_forward
 
     def barrier():
         if world > 1:
@@ -175,7 +179,8 @@ def main():
             R_avg = r_sum / calls
             geo_bwd = args.loss != "l1" and False      # both losses only see the colour image: geometry gradients are absent
             fused = args.loss == "l1"      # pure L1: the loss is evaluated inside blend_bwd (reads colour + gt instead of dL_dpix)
-            ab = algorithmic_bytes(R_avg, args.width, args.height, True, True, geo_bwd, geo_bwd, geo_bwd, l1_fused=fused)
+            geo_fwd = not args.colour_only_forward
+            ab = algorithmic_bytes(R_avg, args.width, args.height, geo_fwd, geo_fwd, geo_bwd, geo_bwd, geo_bwd, l1_fused=fused)
             per = {k: (ms / cnt if cnt else 0.0) for k, (ms, cnt) in stages.items()}
             dom = "blend_bwd" if per.get("blend_bwd", 0) >= per.get("blend_fwd", 0) else "blend_fwd"
             ach = ab[dom] / (per[dom] * 1e-3) / 1e9 if per[dom] > 0 else 0.0

@@ -360,7 +360,8 @@ class Refiner:
             a.lambda_dssim, a.loss_scratch = 0.0, None
         a.out_images, a.radii = imgs.data_ptr(), radii.data_ptr()
         a.dL_dmean2D, a.loss_out = self._fused["m2d"].data_ptr(), self._fused["loss"].data_ptr()
-        a.require_coord, a.require_depth = 1, 1
+        rq = 1 if getattr(self, "require_geometry", True) else 0      # the reference's loop always renders coord / depth / normal
+        a.require_coord, a.require_depth = rq, rq
         with torch.cuda.device(dev):
             nr = L.igs_refine_step(C.byref(a))
         _rast._check(nr, "igs_refine_step")
