@@ -126,11 +126,14 @@ static thread_local BinHint g_hint;
 // igs_rast_forward_async leaves its host-side check of R to igs_rast_forward_finish
 struct PendingFwd { bool active = false; uint32_t slab = 0; };
 static thread_local PendingFwd g_pending;
-static thread_local bool g_async_request = false;
-static thread_local bool g_raw_activations = false;       // set by igs_refine_step around its forward
-static thread_local float* g_zero_gacc = nullptr;         // ... workspace accumulators the forward zero-fills on the side
-static thread_local float* g_zero_loss = nullptr;
-static thread_local float* g_zero_loss2 = nullptr;
+// what the extended entry points ask of the forward on top of the reference's argument list
+struct FwdExtra {
+    bool defer_status = false;          // igs_rast_forward_async / igs_refine_step: do not wait for {R, overflow}
+    bool raw_activations = false;       // igs_refine_step: opacities / scales / rotations are the raw optimiser leaves
+    float* zero_gacc = nullptr;         // ... backward accumulators / loss shards the preprocess kernel zero-fills on the side
+    float* zero_loss = nullptr;
+    float* zero_loss2 = nullptr;
+};
 // where the last slab-binned forward left its device-side validity words (refine step guards)
 struct LastFwd { const uint32_t* overflow = nullptr; const uint32_t* prefilter = nullptr; };
 static thread_local LastFwd g_last_fwd;
@@ -146,7 +149,7 @@ static int forward_impl(
     float tan_fovx, float tan_fovy, float kernel_size, int prefiltered,
     float* out_color, float* out_coord, float* out_mcoord, float* out_depth, float* out_mdepth, float* out_alpha,
     float* out_normal, int* radii, int require_coord, int require_depth, int debug,
-    bool force_radix, uint64_t min_capacity)
+    bool force_radix, uint64_t min_capacity, const FwdExtra& ex)
 {
     hipStream_t s = (hipStream_t)stream;
     if (P < 0 || width <= 0 || height <= 0) return fail(IGS_RAST_E_INVALID, "igs_rast_forward: bad sizes");
@@ -189,8 +192,8 @@ static int forward_impl(
     fp.fy = height / (2.0f * tan_fovy); fp.fx = width / (2.0f * tan_fovx);       // rasterizer_impl.cu:288-289
     fp.kernel_size = kernel_size; fp.prefiltered = prefiltered;
     fp.view = viewmatrix; fp.proj = projmatrix; fp.campos = cam_pos;
-    fp.raw_activations = g_raw_activations ? 1 : 0;
-    fp.zero_gacc = g_zero_gacc; fp.zero_loss = g_zero_loss; fp.zero_loss2 = g_zero_loss2;
+    fp.raw_activations = ex.raw_activations ? 1 : 0;
+    fp.zero_gacc = ex.zero_gacc; fp.zero_loss = ex.zero_loss; fp.zero_loss2 = ex.zero_loss2;
     g_last_fwd = LastFwd();
 
     const size_t counter_bytes = (COUNTER_SHARDS + 1) * COUNTER_SHARD_STRIDE * 4;
@@ -215,7 +218,7 @@ static int forward_impl(
                                 background, width, height, means3D, shs, colors_precomp, opacities, scales, scale_modifier, rotations,
                                 cov3D_precomp, viewmatrix, projmatrix, cam_pos, tan_fovx, tan_fovy, kernel_size, prefiltered, out_color,
                                 out_coord, out_mcoord, out_depth, out_mdepth, out_alpha, out_normal, radii, require_coord, require_depth,
-                                debug, true, 0);
+                                debug, true, 0, ex);
         }
         slab_size = (uint32_t)slab;
         const SlabLayout KL(Tn, slab);
@@ -321,7 +324,7 @@ static int forward_impl(
     HIP_TRY(launch_blend_fwd(s, ba, require_coord != 0, require_depth != 0), "blend_fwd launch");
     DBG_SYNC("blend_fwd");
     prof_mark(s, ST_BLEND_FWD);
-    if (slab_pending && g_async_request) {
+    if (slab_pending && ex.defer_status) {
         g_pending.active = true; g_pending.slab = slab_size;
         if (g_prof.on) g_prof.calls++;
         return 0x7FFFFFFF;                       // "unknown yet": an upper bound that igs_rast_backward accepts as R
@@ -341,7 +344,7 @@ static int forward_impl(
                                 background, width, height, means3D, shs, colors_precomp, opacities, scales, scale_modifier, rotations,
                                 cov3D_precomp, viewmatrix, projmatrix, cam_pos, tan_fovx, tan_fovy, kernel_size, prefiltered, out_color,
                                 out_coord, out_mcoord, out_depth, out_mdepth, out_alpha, out_normal, radii, require_coord, require_depth,
-                                debug, radix, overflow);
+                                debug, radix, overflow, ex);
         }
         R = R_dev;
     }
@@ -368,7 +371,7 @@ extern "C" int igs_rast_forward(
                         background, width, height, means3D, shs, colors_precomp, opacities, scales, scale_modifier, rotations,
                         cov3D_precomp, viewmatrix, projmatrix, cam_pos, tan_fovx, tan_fovy, kernel_size, prefiltered, out_color,
                         out_coord, out_mcoord, out_depth, out_mdepth, out_alpha, out_normal, radii, require_coord, require_depth,
-                        debug, radix, 0);
+                        debug, radix, 0, FwdExtra());
 }
 
 // Asynchronous variant for callers that keep enqueueing work (the native refine step): identical to igs_rast_forward but
@@ -391,13 +394,12 @@ extern "C" int igs_rast_forward_async(
 {
     prof_new_frame();
     g_pending.active = false;
-    g_async_request = true;
+    FwdExtra ex; ex.defer_status = true;
     const int rc = forward_impl(stream, geometry_buffer, geometry_user, binning_buffer, binning_user, image_buffer, image_user, P, D, M,
                                 background, width, height, means3D, shs, colors_precomp, opacities, scales, scale_modifier, rotations,
                                 cov3D_precomp, viewmatrix, projmatrix, cam_pos, tan_fovx, tan_fovy, kernel_size, prefiltered, out_color,
                                 out_coord, out_mcoord, out_depth, out_mdepth, out_alpha, out_normal, radii, require_coord, require_depth,
-                                debug, false, 0);
-    g_async_request = false;
+                                debug, false, 0, ex);
     return rc;
 }
 extern "C" int igs_rast_forward_finish(void)
@@ -582,16 +584,16 @@ extern "C" int igs_refine_step(const igs_refine_step_args* a)
     for (int attempt = 0; attempt < 2; attempt++) {
         g_pending.active = false;
         f.prezeroed = 1;
-        g_zero_gacc = (float*)align_ptr((const char*)a->workspace);
-        g_zero_loss = dssim ? ssim_shards : (float*)((char*)g_zero_gacc + ws_gacc_bytes(a->P));
-        g_zero_loss2 = dssim ? ssim_shards + 1024 : nullptr;
-        g_async_request = attempt == 0;            // second attempt: synchronous forward, which sorts out its scratch sizes itself
-        g_raw_activations = true;
+        FwdExtra ex;
+        ex.zero_gacc = (float*)align_ptr((const char*)a->workspace);
+        ex.zero_loss = dssim ? ssim_shards : (float*)((char*)ex.zero_gacc + ws_gacc_bytes(a->P));
+        ex.zero_loss2 = dssim ? ssim_shards + 1024 : nullptr;
+        ex.defer_status = attempt == 0;            // second attempt: synchronous forward, which sorts out its scratch sizes itself
+        ex.raw_activations = true;
         const int R = forward_impl(a->stream, capture_alloc, &cg, capture_alloc, &cb, capture_alloc, &ci, a->P, a->D, a->M, a->background,
                                    a->width, a->height, xyz, shs, nullptr, opac, scal, 1.0f, rotn, nullptr, a->viewmatrix, a->projmatrix,
                                    a->cam_pos, a->tan_fovx, a->tan_fovy, 0.0f, 0, color, coord, mcoord, depth, mdepth, alpha, normal,
-                                   a->radii, a->require_coord, a->require_depth, 0, false, 0);
-        g_async_request = false; g_raw_activations = false; g_zero_gacc = nullptr; g_zero_loss = nullptr; g_zero_loss2 = nullptr;
+                                   a->radii, a->require_coord, a->require_depth, 0, false, 0, ex);
         if (R < 0) return R;
         f.guard_overflow = g_last_fwd.overflow; f.guard_prefilter = g_last_fwd.prefilter;
         if (dssim) {
