@@ -17,8 +17,13 @@
  *   - the three scratch buffers are opaque byte buffers grown through callbacks; they must stay alive and
  *     unmodified until the matching backward call, and P, R (= the value forward returned), W, H must be the same;
  *   - `stream` is a hipStream_t (pass the framework's current stream; NULL = default stream).  All work is
- *     enqueued on it.  forward performs ONE host synchronisation (a 4-byte read-back of the instance count,
- *     like rasterizer_impl.cu:354); backward performs none;
+ *     enqueued on it.  forward performs ONE host wait (for the 12-byte frame status {num_rendered, slab overflow, prefilter
+ *     flag} that the blend kernel posts into pinned host memory; the reference reads its count back at
+ *     rasterizer_impl.cu:354); backward performs none;
+ *   - threading: the library keeps a little state PER HOST THREAD (the pinned status slot, the per-tile slab size that worked
+ *     for the last frames, the pending frame of igs_rast_forward_async, the last error text); calls from different threads
+ *     do not interfere, a frame started on one thread must be finished / differentiated on the same thread.  The optional
+ *     stage profiler (igs_rast_profile_*) is process-wide and meant for single-threaded benchmarking;
  *   - image outputs of forward must be zero-filled by the caller when P == 0 (nothing is launched, as in
  *     rasterize_points.cu:90); for P > 0 every pixel of every output is written;
  *   - any of backward's seven upstream image gradients may be NULL, meaning all zeros (the output did not take part in
