@@ -83,6 +83,9 @@ def main():
     ap.add_argument("--height", type=int, default=1014)
     ap.add_argument("--cams", type=int, default=10)
     ap.add_argument("--loss", default="l1", choices=["l1", "l1_ssim"])
+    ap.add_argument("--lambda-depth-normal", type=float, default=0.0,
+                    help="add the RaDe-GS depth-normal regulariser with this weight (BASELINE cfg-5 uses 0.05): the blend backward\n"
+                         "then runs its <depth, normal> instance")
     ap.add_argument("--cpu-views", type=int, default=3, help="views timed on the CPU oracle (0 = skip)")
     ap.add_argument("--no-profile", action="store_true", help="do not record per-stage HIP events")
     ap.add_argument("--colour-only-forward", action="store_true",
@@ -127,7 +130,8 @@ def main():
     params = GaussianParams(raw, dev)
     if not args.no_spatial_sort:
         params.spatial_sort()              # once per frame, outside the timed region: Morton order of the positions
-    ref = Refiner(params, cams, gts, bg, loss=args.loss, world_size=world, rank=rank, seed=0)
+    ref = Refiner(params, cams, gts, bg, loss=args.loss, world_size=world, rank=rank, seed=0,
+                  lambda_depth_normal=args.lambda_depth_normal)
     ref.require_geometry = not args.colour_only_forward
 
     def barrier():
@@ -177,10 +181,11 @@ def main():
         }
         if stages and calls:
             R_avg = r_sum / calls
-            geo_bwd = args.loss != "l1" and False      # both losses only see the colour image: geometry gradients are absent
+            geo_bwd = False      # L1 / SSIM only see the colour image: geometry gradients are absent
             fused = args.loss == "l1"      # pure L1: the loss is evaluated inside blend_bwd (reads colour + gt instead of dL_dpix)
             geo_fwd = not args.colour_only_forward
-            ab = algorithmic_bytes(R_avg, args.width, args.height, geo_fwd, geo_fwd, geo_bwd, geo_bwd, geo_bwd, l1_fused=fused)
+            dn = args.lambda_depth_normal > 0      # depth-normal regulariser: depth + normal gradients present, coord absent
+            ab = algorithmic_bytes(R_avg, args.width, args.height, geo_fwd, geo_fwd, geo_bwd, dn, dn, l1_fused=fused)
             per = {k: (ms / cnt if cnt else 0.0) for k, (ms, cnt) in stages.items()}
             dom = "blend_bwd" if per.get("blend_bwd", 0) >= per.get("blend_fwd", 0) else "blend_fwd"
             ach = ab[dom] / (per[dom] * 1e-3) / 1e9 if per[dom] > 0 else 0.0
@@ -194,7 +199,8 @@ def main():
             out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
                                "algorithmic_bytes_per_launch": ab[dom], "avg_launch_ms": per[dom],
-                               "instance": ("blend_bwd<colour-only gradients%s>: R*40 + H*W*%d + R*100 bytes" % ((", L1 fused", 40) if fused else ("", 28)) if dom == "blend_bwd"
+                               "instance": (("blend_bwd<depth, normal gradients%s>: R*64 + H*W*%d + R*100 bytes" % ((", L1 fused", 68) if fused else ("", 56)) if dn else
+                                             "blend_bwd<colour-only gradients%s>: R*40 + H*W*%d + R*100 bytes" % ((", L1 fused", 40) if fused else ("", 28))) if dom == "blend_bwd"
                                             else "blend_fwd<coord,depth,normal>: R*100 + H*W*88 + 8*T bytes"),
                                "num_rendered_avg": R_avg,
                                "other": {"blend_fwd" if dom == "blend_bwd" else "blend_bwd": {

@@ -534,7 +534,8 @@ static char* capture_alloc(void* user, size_t n) { ScratchCapture* c = (ScratchC
 extern "C" size_t igs_refine_loss_scratch_bytes(int width, int height)
 {
     const size_t HW = (size_t)(width > 0 ? width : 0) * (size_t)(height > 0 ? height : 0);
-    return ((igs_ssim_l1_scratch_bytes(width, height) + 255) & ~(size_t)255) + 3 * HW * 4 + 256;
+    // { SSIM scratch | dL/dcolor 3 HW | depth-normal: dL/ddepth HW, dL/dmdepth HW, dL/dnormal 3 HW | 64 shards }
+    return ((igs_ssim_l1_scratch_bytes(width, height) + 255) & ~(size_t)255) + 3 * HW * 4 + 5 * HW * 4 + 4096 + 512;
 }
 
 extern "C" int igs_refine_step(const igs_refine_step_args* a)
@@ -562,15 +563,24 @@ extern "C" int igs_refine_step(const igs_refine_step_args* a)
     f.b1 = a->beta1; f.b2 = a->beta2; f.eps = a->eps; f.inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
     const float inv_n = 1.0f / (float)(3 * HW);
     const bool dssim = a->lambda_dssim > 0.f;
-    if (dssim && !a->loss_scratch) return fail(IGS_RAST_E_INVALID, "igs_refine_step: lambda_dssim > 0 needs loss_scratch");
+    const bool dn = a->lambda_depth_normal > 0.f;
+    if ((dssim || dn) && !a->loss_scratch) return fail(IGS_RAST_E_INVALID, "igs_refine_step: lambda_dssim / lambda_depth_normal > 0 need loss_scratch");
+    if (dn && !a->require_depth) return fail(IGS_RAST_E_INVALID, "igs_refine_step: the depth-normal regulariser needs require_depth");
     // scratch of the SSIM mode: { loss kernels' own scratch (maps + 2 x 64 shards) | dL/dcolor [3][H][W] }
     float* ssim_shards = nullptr; float* grad_img = nullptr;
+    float *dn_gd = nullptr, *dn_gm = nullptr, *dn_gn = nullptr, *dn_shards = nullptr;
+    if (dn) {
+        const size_t own = (igs_ssim_l1_scratch_bytes(a->width, a->height) + 255) & ~(size_t)255;
+        float* base = (float*)((char*)a->loss_scratch + own) + 3 * HW;
+        dn_gd = base; dn_gm = base + HW; dn_gn = base + 2 * HW; dn_shards = (float*)(((uintptr_t)(base + 5 * HW) + 255) & ~(uintptr_t)255);
+    }
     if (dssim) {
         const size_t own = (igs_ssim_l1_scratch_bytes(a->width, a->height) + 255) & ~(size_t)255;
         ssim_shards = (float*)((char*)a->loss_scratch + (((size_t)9 * HW * 4 + 255) & ~(size_t)255));
         grad_img = (float*)((char*)a->loss_scratch + own);
     }
     f.loss_out = a->loss_out; f.loss_shards2 = nullptr; f.loss_bias = 0.f; f.loss_scale2 = 0.f;
+    f.loss_shards3 = dn_shards; f.loss_scale3 = 1.0f;       // (the kernel's shards already carry weight * lambda / HW)
     if (dssim) {          // loss = lambda w (1 - mean ssim) + (1 - lambda) w mean|d|
         f.loss_shards = ssim_shards; f.loss_scale = -a->lambda_dssim * a->loss_weight * inv_n;
         f.loss_shards2 = ssim_shards + 1024; f.loss_scale2 = (1.f - a->lambda_dssim) * a->loss_weight * inv_n;
@@ -603,10 +613,19 @@ extern "C" int igs_refine_step(const igs_refine_step_args* a)
                 return fail(IGS_RAST_E_HIP, "ssim loss launch");
             prof_mark((hipStream_t)a->stream, ST_MEMSET);          // (the stage slot the fused step does not otherwise use: "loss")
         }
+        if (dn) {
+            // depth-normal regulariser on the maps just rendered: its three gradient maps switch the blend backward to the
+            // <depth, normal> instance
+            hipStream_t ms = (hipStream_t)a->stream;
+            HIP_TRY(hipMemsetAsync(dn_shards, 0, 4096, ms), "memset shards");
+            const float fx = a->width / (2.0f * a->tan_fovx), fy = a->height / (2.0f * a->tan_fovy);
+            HIP_TRY(launch_depth_normal(ms, a->width, a->height, fx, fy, depth, mdepth, normal, a->loss_weight * a->lambda_depth_normal,
+                                        a->depth_ratio > 0.f ? a->depth_ratio : 0.6f, dn_gd, dn_gm, dn_gn, dn_shards), "depth_normal launch");
+        }
         const int rc = backward_impl(a->stream, a->P, a->D, a->M, R, a->background, a->width, a->height, xyz, shs, nullptr, alpha, scal, 1.0f,
                                      rotn, nullptr, a->viewmatrix, a->projmatrix, a->cam_pos, a->tan_fovx, a->tan_fovy, 0.0f, a->radii,
-                                     normal, cg.last, cb.last, ci.last, dssim ? grad_img : nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
-                                     nullptr, a->workspace, a->dL_dmean2D, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
+                                     normal, cg.last, cb.last, ci.last, dssim ? grad_img : nullptr, nullptr, nullptr, dn_gd, dn_gm, nullptr,
+                                     dn_gn, a->workspace, a->dL_dmean2D, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
                                      a->require_coord, a->require_depth, 0, dssim ? nullptr : a->gt, color, l1_scale, &f);
         if (rc < 0) return rc;
         if (!g_pending.active) return R;           // synchronous forward: R is already the true count

@@ -180,11 +180,14 @@ struct RefineFuse {
     float lr_xyz, lr_rot, lr_sh, lr_opacity, lr_scale;                     // lr / bias_correction1 per group
     float b1, b2, eps, inv_sqrt_bc2;
     const uint32_t *guard_overflow, *guard_prefilter;                      // nonzero = the frame is invalid: touch nothing
-    // loss_out[0] = loss_bias + loss_scale * sum(loss_shards) + loss_scale2 * sum(loss_shards2)   (64 shards each, 16 floats apart)
-    const float* loss_shards; const float* loss_shards2; float* loss_out; float loss_scale, loss_scale2, loss_bias;
+    // loss_out[0] = loss_bias + sum_k loss_scale_k * sum(loss_shards_k)   (64 shards each, 16 floats apart; NULL = absent)
+    const float* loss_shards; const float* loss_shards2; const float* loss_shards3; float* loss_out;
+    float loss_scale, loss_scale2, loss_scale3, loss_bias;
     int prezeroed;                                                         // the accumulators were zero-filled by the forward
 };
 hipError_t launch_geom_bwd_adam(hipStream_t s, const GeomBwdArgs& a, const RefineFuse& f);
+hipError_t launch_depth_normal(hipStream_t s, int W, int H, float fx, float fy, const float* depth, const float* mdepth, const float* normal,
+                               float weight, float depth_ratio, float* g_depth, float* g_mdepth, float* g_normal, float* loss_shards);
 // 0.8 L1 + 0.2 (1 - SSIM)-style loss, forward + backward (loss_ops.hip); scratch: igs_ssim_l1_scratch_bytes
 hipError_t launch_ssim_l1(hipStream_t s, int W, int H, const float* pred, const float* gt, float lambda_dssim, float weight,
                           void* scratch, float* grad, bool zero_shards);

@@ -88,6 +88,7 @@ geom_bwd_kernel(const GBArgs args)
         if (blockIdx.x == 0 && threadIdx.x < 64 && fz.loss_out) {
             float v = fz.loss_scale * fz.loss_shards[16 * threadIdx.x];
             if (fz.loss_shards2) v += fz.loss_scale2 * fz.loss_shards2[16 * threadIdx.x];
+            if (fz.loss_shards3) v += fz.loss_scale3 * fz.loss_shards3[16 * threadIdx.x];
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
             if (threadIdx.x == 0) fz.loss_out[0] = fz.loss_bias + v;

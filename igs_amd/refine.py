@@ -236,10 +236,11 @@ class Refiner:
         self.render_fn = render if render_fn is None else render_fn
         self.adam_fn = params.adam_step if adam_fn is None else adam_fn
         self.l1 = L1Fused(params.device) if loss == "l1" else L1SsimFused(params.device, 1.0 - lambda_l1)
-        # RaDe-GS depth-normal regulariser (train.py:143-164; BASELINE cfg-5 uses 0.05): needs dL/d depth, mdepth, normal, so the
-        # step goes through the autograd Function (full backward instance) instead of the colour-only native paths
+        # RaDe-GS depth-normal regulariser (train.py:143-164; BASELINE cfg-5 uses 0.05): needs dL/d depth, mdepth, normal -- the
+        # fused step evaluates it in one HIP launch and runs the <depth, normal> backward instance; the unfused native path does
+        # not implement it (the autograd path does, through igs_amd/regularizers.py)
         self.lambda_depth_normal = float(lambda_depth_normal)
-        self.native = native and self.lambda_depth_normal == 0.0          # drive the C ABI directly instead of going through autograd
+        self.native = native          # drive the C ABI directly instead of going through autograd
         self.fused = fused            # ... and on a single GPU run the whole iteration as one library call (igs_refine_step)
         self.grad_img = None
         self.gen = torch.Generator().manual_seed(seed)      # same seed on every rank -> same view permutation
@@ -351,11 +352,13 @@ class Refiner:
         a.cam_pos = cam.camera_center.data_ptr()
         a.tan_fovx, a.tan_fovy = cam.tanfovx, cam.tanfovy
         a.gt, a.loss_weight = gt.data_ptr(), 1.0 / self.world_size      # gradients are averaged over the views of a step
-        if self.loss == "l1_ssim":
+        a.lambda_depth_normal, a.depth_ratio = self.lambda_depth_normal, 0.6
+        if self.loss == "l1_ssim" or self.lambda_depth_normal > 0.0:
             if getattr(self, "_loss_scratch_key", None) != (H, W):
                 self._loss_scratch_key = (H, W)
                 self._loss_scratch = torch.empty(L.igs_refine_loss_scratch_bytes(W, H), dtype=torch.uint8, device=dev)
-            a.lambda_dssim, a.loss_scratch = 1.0 - self.lambda_l1, self._loss_scratch.data_ptr()
+            a.lambda_dssim = (1.0 - self.lambda_l1) if self.loss == "l1_ssim" else 0.0
+            a.loss_scratch = self._loss_scratch.data_ptr()
         else:
             a.lambda_dssim, a.loss_scratch = 0.0, None
         a.out_images, a.radii = imgs.data_ptr(), radii.data_ptr()
@@ -410,12 +413,12 @@ class Refiner:
         if view is None:
             view = self._next_view()
         cam, gt = self.cams[view], self.gt[view]
-        native_ok = self.native and self.render_fn is render
+        native_ok = self.native and self.render_fn is render and (self.fused or self.lambda_depth_normal == 0.0)
         if native_ok and self.densify is not None and self.world_size == 1 and self.adam_fn == p.adam_step:
             # the reference updates the statistics after every backward and, on a densification iteration, rebuilds the
             # Gaussians BEFORE optimizer.step() -- which then finds no gradients and does nothing (infer_batch.py:308-324)
             if self._densify_due():
-                pkg = self._native_step(cam, gt)                    # gradients only, no Adam
+                pkg = self._fused_step(cam, gt, grads_only=True) if self.fused else self._native_step(cam, gt)    # gradients only, no Adam
                 self._densify_hooks(pkg, did_adam=False)
             else:
                 pkg = self._fused_step(cam, gt) if self.fused else self._native_then_adam(cam, gt)

@@ -235,7 +235,10 @@ typedef struct igs_refine_step_args {
     const float* gt;                          /* [3][H][W] device */
     float loss_weight;                        /* loss = loss_weight * ((1 - lambda_dssim) * mean|color - gt| + lambda_dssim * (1 - mean SSIM)) */
     float lambda_dssim;                       /* 0: pure L1 (fused into the blend backward); the reference uses 0.2 (loss_utils.py:34-63) */
-    void* loss_scratch;                       /* lambda_dssim > 0: igs_refine_loss_scratch_bytes(width, height) bytes, else NULL */
+    float lambda_depth_normal;                /* > 0 adds loss_weight * lambda_depth_normal * depth-normal regulariser (RaDe-GS train.py:143-160;
+                                                 needs require_depth): the backward then runs its <depth, normal> instance */
+    float depth_ratio;                        /* weight of the median-depth term of the regulariser (0 = the reference's 0.6) */
+    void* loss_scratch;                       /* lambda_dssim > 0 or lambda_depth_normal > 0: igs_refine_loss_scratch_bytes(width, height) bytes */
     float* out_images;                        /* [15][H][W]: color 3 | coord 3 | mcoord 3 | depth 1 | mdepth 1 | alpha 1 | normal 3 */
     int* radii;                               /* [P] */
     float* dL_dmean2D;                        /* [P][3] view-space gradient (densification statistic) or NULL */
@@ -253,6 +256,16 @@ size_t igs_refine_loss_scratch_bytes(int width, int height);
 size_t igs_ssim_l1_scratch_bytes(int width, int height);
 int igs_ssim_l1_loss_fwd_bwd(void* stream, int width, int height, const float* pred, const float* gt, float lambda_dssim, float weight,
                              void* scratch, float* grad, float* sums);
+
+/* RaDe-GS depth-normal consistency regulariser, value and gradients in one launch
+ * (submodules/RaDe-GS/utils/graphics_utils.py:97-126, train.py:143-160):
+ *   loss = weight * ((1 - depth_ratio) * mean(1 - normal . n(depth)) + depth_ratio * mean(1 - normal . n(mdepth))),
+ * n(d) = normalised cross product of the central differences of the back-projected depth map (zero on the image border).
+ * Writes dloss/ddepth [H][W], dloss/dmdepth [H][W], dloss/dnormal [3][H][W]; the loss value is left as 64 partial sums at
+ * loss_shards[16*s] (1024 floats, zero-filled here). */
+int igs_depth_normal_loss_fwd_bwd(void* stream, int width, int height, float tan_fovx, float tan_fovy, const float* depth,
+                                  const float* mdepth, const float* normal, float weight, float depth_ratio, float* g_depth,
+                                  float* g_mdepth, float* g_normal, float* loss_shards);
 
 /* Fused L1 loss forward + backward (igs/utils/loss_utils.py:17-18): grad[i] = sign(pred[i] - gt[i]) * scale, and
  * sum |pred - gt| is accumulated into 64 shards loss_sum[16*s], s = 0..63 (1024 floats, zeroed by the caller, summed by

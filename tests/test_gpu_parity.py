@@ -779,7 +779,7 @@ def test_depth_normal_regulariser_drives_the_full_backward(dev):
     assert float(params.leaves["shs"].grad.abs().max()) == 0.0                  # colour does not enter the regulariser
     # (2) refine steps with the regulariser switched on (lr of the geometry only, so that the colour loss cannot hide it)
     params = GaussianParams(raw, dev, lrs=dict(xyz=0.0, rotation=0.01, shs=0.0, opacity=0.0, scaling=0.005))
-    ref = Refiner(params, cams, gts, bg, loss="l1", lambda_depth_normal=1.0)
+    ref = Refiner(params, cams, gts, bg, loss="l1", lambda_depth_normal=1.0, native=False)      # autograd path (regularizers.py)
     vals = []
     for _ in range(12):
         ref.step(view=0)
@@ -934,3 +934,78 @@ def test_drop_in_ssim_matches_the_reference_formula(dev):
     assert float((a.grad - b.grad).abs().max()) < 2e-4 * float(b.grad.abs().max())
     m, mp = fused(x, gt, size_average=True)                       # fallback keeps the (mean, map) return
     assert mp.shape == (3, 90, 131) and abs(float(m.detach()) - float(vb.detach())) < 1e-5
+
+
+@pytest.mark.parametrize("shape", [(64, 80), (45, 37)])
+def test_fused_depth_normal_regulariser_matches_autograd(dev, shape):
+    """igs_depth_normal_loss_fwd_bwd (one launch: value + dL/ddepth, dL/dmdepth, dL/dnormal) against autograd through the PyTorch
+    restatement of RaDe-GS graphics_utils.py:97-126 / train.py:143-160 (igs_amd/regularizers.py)."""
+    import math
+    from igs_amd import _cabi
+    from igs_amd.camera import Camera
+    from igs_amd.regularizers import depth_normal_loss
+    H, W = shape
+    cam = Camera(torch.eye(4), 2 * math.atan(W / (2 * 55.0)), 2 * math.atan(H / (2 * 60.0)), (H, W))
+    g = torch.Generator().manual_seed(H + W)
+    yy, xx = torch.meshgrid(torch.arange(H).float(), torch.arange(W).float(), indexing="ij")
+    base = 3.0 + 0.01 * xx + 0.02 * yy + 0.3 * torch.sin(xx / 7.0) * torch.cos(yy / 5.0)
+    depth = (base + 0.02 * torch.randn(H, W, generator=g))[None].to(dev).requires_grad_(True)
+    mdepth = (base * 1.03 + 0.02 * torch.randn(H, W, generator=g))[None].to(dev).requires_grad_(True)
+    normal = torch.nn.functional.normalize(torch.randn(3, H, W, generator=g), dim=0).to(dev).requires_grad_(True)
+    loss = depth_normal_loss(dict(depth_pred=depth, mdepth=mdepth, normal=normal), cam)
+    loss.backward()
+    L = _cabi.lib()
+    gd, gm, gn = torch.empty(H, W, device=dev), torch.empty(H, W, device=dev), torch.empty(3, H, W, device=dev)
+    shards = torch.empty(1024, device=dev)
+    rc = L.igs_depth_normal_loss_fwd_bwd(torch.cuda.current_stream(dev).cuda_stream, W, H, cam.tanfovx, cam.tanfovy,
+                                         depth.data_ptr(), mdepth.data_ptr(), normal.data_ptr(), 1.0, 0.6, gd.data_ptr(), gm.data_ptr(),
+                                         gn.data_ptr(), shards.data_ptr())
+    assert rc == 0
+    val = float(shards[::16].sum().item())
+    assert abs(val - float(loss.item())) < 1e-5, (val, float(loss.item()))
+    for name, a, b in (("depth", gd, depth.grad[0]), ("mdepth", gm, mdepth.grad[0]), ("normal", gn, normal.grad)):
+        d = (a - b).abs().max().item()
+        assert d < 2e-4 * b.abs().max().item() + 1e-9, (name, d, b.abs().max().item())
+    assert float(gd[0].abs().max()) > 0 and float(gn[:, 0, :].abs().max()) == 0.0      # border pixels: n = 0
+
+
+def test_fused_step_with_depth_normal_regulariser(dev):
+    """BASELINE cfg-5 shape natively: igs_refine_step with lambda_depth_normal (regulariser in one HIP launch, <depth, normal>
+    backward instance, L1 or L1 + D-SSIM alongside) against the autograd step through igs_amd/regularizers.py."""
+    from igs_amd.refine import GaussianParams, Refiner, render
+    from igs_amd.scenes import perturbed_copy
+    raw, cams, bg = cfg1_scene(P=3000, size=128)
+    cams = [cams[0].to(dev)]
+    bg = bg.to(dev)
+    gt_raw = {k: v.to(dev) for k, v in perturbed_copy(raw, sigma=0.03).items()}
+    with torch.no_grad():
+        gts = [render(activate(gt_raw), cams[0], bg)["images_pred"].clone()]
+    for loss in ("l1", "l1_ssim"):
+        pa, pb = GaussianParams(raw, dev), GaussianParams(raw, dev)
+        ra = Refiner(pa, cams, gts, bg, loss=loss, lambda_depth_normal=0.05, fused=True)
+        rb = Refiner(pb, cams, gts, bg, loss=loss, lambda_depth_normal=0.05, native=False)
+        rb.torch_ssim = True
+        ra.adam_fn = lambda: None          # gradients only (the fused launches end in the flat gradient)
+        rb.adam_fn = lambda: None
+        pka = ra.step(view=0); rb.step(view=0)
+        for k in pa.leaves:
+            A, B = pa.leaves[k].grad.cpu().numpy(), pb.leaves[k].grad.cpu().numpy()
+            r = rel(A, B)
+            assert np.quantile(r, 0.99) < 5e-3 and np.median(r) < 1e-4, (loss, k, np.quantile(r, 0.99), np.median(r))
+        # loss value: colour term + 0.05 * regulariser
+        with torch.no_grad():
+            from igs_amd.refine import ssim
+            from igs_amd.regularizers import depth_normal_loss
+            pk = render(pb.activated(), cams[0], bg)
+            col = torch.abs(pk["images_pred"] - gts[0]).mean()
+            if loss == "l1_ssim":
+                col = 0.8 * col + 0.2 * (1.0 - ssim(pk["images_pred"], gts[0]))
+            ref_loss = float(col + 0.05 * depth_normal_loss(pk, cams[0]))
+        assert abs(float(pka["loss"].item()) - ref_loss) < 2e-5, (loss, float(pka["loss"].item()), ref_loss)
+    # and the in-place update variant runs and moves the geometry
+    pc = GaussianParams(raw, dev)
+    rc = Refiner(pc, cams, gts, bg, loss="l1_ssim", lambda_depth_normal=0.05)
+    before = pc.flat.clone()
+    for _ in range(3):
+        rc.step(view=0)
+    assert torch.isfinite(pc.flat).all() and float((pc.flat - before).abs().max()) > 0
