@@ -39,7 +39,7 @@ class SyntheticStream:
 
 
 def run_stream(raw, cams, bg, frames, refine_iterations=50, device="cuda", loss="l1_ssim", densify=None, source=None, lrs=None,
-               world_size=1, rank=0, spatial_sort=True, log=None):
+               world_size=1, rank=0, spatial_sort=True, log=None, lambda_depth_normal=0.0):
     """Refines `raw` through `frames` frames; returns a list of per-frame dicts {psnr_before, psnr_after, seconds, num_gaussians}.
     `source.next_frame()` supplies each frame's ground-truth images (default: SyntheticStream)."""
     dev = torch.device(device)
@@ -54,7 +54,8 @@ def run_stream(raw, cams, bg, frames, refine_iterations=50, device="cuda", loss=
         params = GaussianParams(cur, dev, lrs=lrs)
         if spatial_sort:
             params.spatial_sort()
-        ref = Refiner(params, cams, gts, bg, loss=loss, world_size=world_size, rank=rank, seed=f, densify=densify)
+        ref = Refiner(params, cams, gts, bg, loss=loss, world_size=world_size, rank=rank, seed=f, densify=densify,
+                      lambda_depth_normal=lambda_depth_normal)
         ref.start_frame()
         with torch.no_grad():
             p0 = float(psnr(render(params.activated(), cams[0], bg)["images_pred"], gts[0]))
