@@ -33,7 +33,7 @@ class RefineStepArgs(C.Structure):
                 ("gt", C.c_void_p), ("loss_weight", C.c_float), ("lambda_dssim", C.c_float), ("lambda_depth_normal", C.c_float), ("depth_ratio", C.c_float),
                 ("loss_scratch", C.c_void_p),
                 ("out_images", C.c_void_p), ("radii", C.c_void_p), ("dL_dmean2D", C.c_void_p), ("loss_out", C.c_void_p),
-                ("require_coord", C.c_int), ("require_depth", C.c_int)]
+                ("require_coord", C.c_int), ("require_depth", C.c_int), ("clamp_grads", C.c_float)]
 
 
 EXPORTS = ["igs_rast_version", "igs_rast_last_error", "igs_rast_forward", "igs_rast_backward_workspace_bytes",

@@ -560,6 +560,7 @@ extern "C" int igs_refine_step(const igs_refine_step_args* a)
     f.off_xyz = a->off_xyz; f.off_rot = a->off_rot; f.off_sh = a->off_sh; f.off_opacity = a->off_opacity; f.off_scale = a->off_scale;
     f.lr_xyz = (float)(a->lr_xyz / bc1); f.lr_rot = (float)(a->lr_rot / bc1); f.lr_sh = (float)(a->lr_sh / bc1);
     f.lr_opacity = (float)(a->lr_opacity / bc1); f.lr_scale = (float)(a->lr_scale / bc1);
+    f.clamp = a->clamp_grads;
     f.b1 = a->beta1; f.b2 = a->beta2; f.eps = a->eps; f.inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
     const float inv_n = 1.0f / (float)(3 * HW);
     const bool dssim = a->lambda_dssim > 0.f;

@@ -179,6 +179,7 @@ struct RefineFuse {
     size_t off_xyz, off_rot, off_sh, off_opacity, off_scale;               // group offsets (floats) into the three buffers
     float lr_xyz, lr_rot, lr_sh, lr_opacity, lr_scale;                     // lr / bias_correction1 per group
     float b1, b2, eps, inv_sqrt_bc2;
+    float clamp;                                                           // > 0: clamp dL/d(means3D, sh, opacity, scale, rotation) to +-clamp (clamp variant)
     const uint32_t *guard_overflow, *guard_prefilter;                      // nonzero = the frame is invalid: touch nothing
     // loss_out[0] = loss_bias + sum_k loss_scale_k * sum(loss_shards_k)   (64 shards each, 16 floats apart; NULL = absent)
     const float* loss_shards; const float* loss_shards2; const float* loss_shards3; float* loss_out;

@@ -407,6 +407,15 @@ geom_bwd_kernel(const GBArgs args)
             a.dL_dscale[3 * idx] = o_scale.x; a.dL_dscale[3 * idx + 1] = o_scale.y; a.dL_dscale[3 * idx + 2] = o_scale.z;
             a.dL_drot[4 * idx] = o_rot.x; a.dL_drot[4 * idx + 1] = o_rot.y; a.dL_drot[4 * idx + 2] = o_rot.z; a.dL_drot[4 * idx + 3] = o_rot.w;
         } else {
+            if (fz.clamp > 0.f) {       // diff_gaussian_rasterization_rade_clamp/__init__.py:156-162 (means2D is not clamped)
+                const float c = fz.clamp;
+                auto cl = [c](float x) { return fminf(fmaxf(x, -c), c); };
+                o_mean = make_float3(cl(o_mean.x), cl(o_mean.y), cl(o_mean.z));
+                o_opacity = cl(o_opacity);
+                o_scale = make_float3(cl(o_scale.x), cl(o_scale.y), cl(o_scale.z));
+                o_rot = make_float4(cl(o_rot.x), cl(o_rot.y), cl(o_rot.z), cl(o_rot.w));
+                if (dsh && sh_written) for (int k = 0; k < F; k++) dsh[k] = cl(dsh[k]);
+            }
             // ---- activation backward (gaussian_model.py:90-127) for this Gaussian's 11 small parameters ----
             const float g_xyz[3] = { o_mean.x, o_mean.y, o_mean.z };
             const float s_op = act_sigmoid(fz.param[fz.off_opacity + idx]);

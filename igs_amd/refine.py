@@ -138,7 +138,7 @@ class GaussianParams:
             raise RuntimeError("igs_adam_step_groups failed: %d" % rc)
 
 
-def render(params_act, cam, bg, sh_degree=3, require_coord=True, require_depth=True, means2D=None, debug=False):
+def render(params_act, cam, bg, sh_degree=3, require_coord=True, require_depth=True, means2D=None, debug=False, clamp=False):
     """`forward_single_view` (infer_batch.py:39-124) on an activated parameter dict."""
     settings = GaussianRasterizationSettings(
         image_height=int(cam.height), image_width=int(cam.width), tanfovx=cam.tanfovx, tanfovy=cam.tanfovy, kernel_size=0.0,
@@ -147,7 +147,10 @@ def render(params_act, cam, bg, sh_degree=3, require_coord=True, require_depth=T
         require_coord=require_coord, debug=debug)
     if means2D is None:
         means2D = torch.zeros_like(params_act["means3D"], requires_grad=True)
-    color, radii, coord, mcoord, depth, mdepth, alpha, normal = GaussianRasterizer(settings)(
+    Rast = GaussianRasterizer
+    if clamp:        # igs/models/gs.py:39 imports the clamp package (gradients clamped to +-15)
+        from .rasterizer import GaussianRasterizerClamp as Rast
+    color, radii, coord, mcoord, depth, mdepth, alpha, normal = Rast(settings)(
         means3D=params_act["means3D"], means2D=means2D, opacities=params_act["opacities"], shs=params_act["shs"],
         scales=params_act["scales"], rotations=params_act["rotations"])
     return dict(images_pred=color, depth_pred=depth, radii=radii, visibility_filter=radii > 0, viewspace_points=means2D,
@@ -351,7 +354,7 @@ class Refiner:
         a.viewmatrix, a.projmatrix = cam.world_view_transform.data_ptr(), cam.full_proj_transform.data_ptr()
         a.cam_pos = cam.camera_center.data_ptr()
         a.tan_fovx, a.tan_fovy = cam.tanfovx, cam.tanfovy
-        a.gt, a.loss_weight = gt.data_ptr(), 1.0 / self.world_size      # gradients are averaged over the views of a step
+        a.gt, a.loss_weight = gt.data_ptr(), getattr(self, "loss_scale", 1.0) / self.world_size      # gradients are averaged over the views of a step
         a.lambda_depth_normal, a.depth_ratio = self.lambda_depth_normal, 0.6
         if self.loss == "l1_ssim" or self.lambda_depth_normal > 0.0:
             if getattr(self, "_loss_scratch_key", None) != (H, W):
@@ -365,6 +368,7 @@ class Refiner:
         a.dL_dmean2D, a.loss_out = self._fused["m2d"].data_ptr(), self._fused["loss"].data_ptr()
         rq = 1 if getattr(self, "require_geometry", True) else 0      # the reference's loop always renders coord / depth / normal
         a.require_coord, a.require_depth = rq, rq
+        a.clamp_grads = 15.0 if getattr(self, "clamp", False) else 0.0
         with torch.cuda.device(dev):
             nr = L.igs_refine_step(C.byref(a))
         _rast._check(nr, "igs_refine_step")
@@ -438,7 +442,7 @@ class Refiner:
             return pkg
         p.zero_grad()
         act = p.activated()
-        pkg = self.render_fn(act, cam, self.bg)
+        pkg = self.render_fn(act, cam, self.bg, clamp=True) if (getattr(self, "clamp", False) and self.render_fn is render) else self.render_fn(act, cam, self.bg)
         img = pkg["images_pred"]
         if self.loss == "l1" and self.lambda_depth_normal == 0.0:
             if self.grad_img is None or self.grad_img.shape != img.shape:
@@ -458,7 +462,7 @@ class Refiner:
                 from .regularizers import depth_normal_loss
                 self.last_depth_normal_loss = depth_normal_loss(pkg, cam)
                 loss = loss + self.lambda_depth_normal * self.last_depth_normal_loss
-            (loss / self.world_size).backward()
+            (loss * getattr(self, "loss_scale", 1.0) / self.world_size).backward()
         if self.world_size > 1:
             import torch.distributed as dist
             dist.all_reduce(p.grad, op=dist.ReduceOp.SUM)      # one flat 59*P-float buffer over RCCL / xGMI

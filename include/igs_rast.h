@@ -244,6 +244,8 @@ typedef struct igs_refine_step_args {
     float* dL_dmean2D;                        /* [P][3] view-space gradient (densification statistic) or NULL */
     float* loss_out;                          /* device, 1 float: the loss value, or NULL */
     int require_coord, require_depth;
+    float clamp_grads;                        /* > 0: the rasterizer's gradients w.r.t. means3D / sh / opacities / scales / rotations are clamped to
+                                                 +-clamp_grads before they go on (diff_gaussian_rasterization_rade_clamp, 15); 0: off */
 } igs_refine_step_args;
 int igs_refine_step(const igs_refine_step_args* args);
 size_t igs_refine_loss_scratch_bytes(int width, int height);

@@ -1009,3 +1009,36 @@ def test_fused_step_with_depth_normal_regulariser(dev):
     for _ in range(3):
         rc.step(view=0)
     assert torch.isfinite(pc.flat).all() and float((pc.flat - before).abs().max()) > 0
+
+
+def test_fused_step_clamp_variant(dev):
+    """The clamp package's semantics (gradients w.r.t. means3D / sh / opacities / scales / rotations clamped to +-15 right
+    after the rasterizer, DGRC __init__.py:156-162) inside igs_refine_step, against the autograd path through
+    GaussianRasterizerClamp; the loss is scaled up so that the clamp actually bites."""
+    from igs_amd.refine import GaussianParams, Refiner, render
+    from igs_amd.scenes import perturbed_copy
+    raw, cams, bg = cfg1_scene(P=3000, size=128)
+    cams = [cams[0].to(dev)]
+    bg = bg.to(dev)
+    gt_raw = {k: v.to(dev) for k, v in perturbed_copy(raw, sigma=0.05).items()}
+    with torch.no_grad():
+        gts = [render(activate(gt_raw), cams[0], bg)["images_pred"].clone()]
+    pa, pb, pc = GaussianParams(raw, dev), GaussianParams(raw, dev), GaussianParams(raw, dev)
+    ra = Refiner(pa, cams, gts, bg, loss="l1", fused=True)
+    rb = Refiner(pb, cams, gts, bg, loss="l1_ssim", native=False)      # (autograd path with a torch loss; lambda_l1 = 1 makes it pure L1)
+    rc = Refiner(pc, cams, gts, bg, loss="l1", fused=True)
+    rb.lambda_l1 = 1.0
+    for r in (ra, rb, rc):
+        r.loss_scale = 3.0e6
+        r.adam_fn = lambda: None
+    ra.clamp = True; rb.clamp = True
+    ra.step(view=0); rb.step(view=0); rc.step(view=0)
+    ga, gb, gc = pa.grad.cpu().numpy(), pb.grad.cpu().numpy(), pc.grad.cpu().numpy()
+    assert np.abs(gc).max() > 100.0                                     # unclamped gradients are far beyond 15 ...
+    o, n = pa.spans["xyz"]
+    assert np.abs(ga[o:o + n]).max() <= 15.0 + 1e-4                     # ... the clamped ones are not (xyz and sh have no activation)
+    o, n = pa.spans["shs"]
+    assert np.abs(ga[o:o + n]).max() <= 15.0 + 1e-4
+    r = rel(ga, gb)
+    assert np.quantile(r, 0.99) < 5e-3 and np.median(r) < 1e-5, (np.quantile(r, 0.99), np.median(r))
+    assert (np.abs(ga - gc) > 1.0).sum() > 100                          # and the clamp changed many entries
