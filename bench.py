@@ -86,6 +86,7 @@ def main():
     ap.add_argument("--lambda-depth-normal", type=float, default=0.0,
                     help="add the RaDe-GS depth-normal regulariser with this weight (BASELINE cfg-5 uses 0.05): the blend backward\n"
                          "then runs its <depth, normal> instance")
+    ap.add_argument("--clamp", action="store_true", help="clamp variant of the rasterizer (gradients clamped to +-15; BASELINE cfg-5)")
     ap.add_argument("--cpu-views", type=int, default=3, help="views timed on the CPU oracle (0 = skip)")
     ap.add_argument("--no-profile", action="store_true", help="do not record per-stage HIP events")
     ap.add_argument("--colour-only-forward", action="store_true",
@@ -133,6 +134,7 @@ def main():
     ref = Refiner(params, cams, gts, bg, loss=args.loss, world_size=world, rank=rank, seed=0,
                   lambda_depth_normal=args.lambda_depth_normal)
     ref.require_geometry = not args.colour_only_forward
+    ref.clamp = args.clamp
 
     def barrier():
         if world > 1:
