@@ -48,6 +48,18 @@ def main():
     st, _, _ = _cabi.profile_read(reset=True)
     res["forward"] = {k: round(ms / c, 4) for k, (ms, c) in st.items() if c}
     res["num_rendered"] = nr
+    # BASELINE cfg-2: forward-only render, wall clock (includes the one host wait per frame of igs_rast_forward)
+    import time
+    _cabi.profile_enable(False)
+    for _ in range(10):
+        fwd()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(200):
+        fwd()
+    torch.cuda.synchronize()
+    res["forward_only_ms"] = round(1000 * (time.perf_counter() - t0) / 200, 4)
+    res["forward_only_gaussians_per_s"] = round(200000 / (res["forward_only_ms"] * 1e-3))
     print(json.dumps(res))
 
 if __name__ == "__main__":
