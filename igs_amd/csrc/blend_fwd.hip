@@ -102,14 +102,14 @@ blend_fwd_kernel(const BlendFwdArgs a)
                             const float c1 = q3.y + q4.z * dx + q4.w * dy;
                             const float c2 = q3.z + q5.x * dx + q5.y * dy;
                             Co0 += c0 * aT; Co1 += c1 * aT; Co2 += c2 * aT;
-                            mC0 = before_median ? c0 : mC0; mC1 = before_median ? c1 : mC1; mC2 = before_median ? c2 : mC2;
                         }
                         if constexpr (DEPTH) {
                             const float t = q2.y + (q2.z * dx + q2.w * dy);
                             Depth += t * aT;
-                            mDepth = before_median ? t : mDepth;
                         }
                         if constexpr (NORMAL) { N0 += q3.w * aT; N1 += q5.z * aT; N2 += q5.w * aT; }
+                        // only the index of the median splat is tracked here; its coordinate and depth are re-evaluated once
+                        // per pixel after the loop (forward.cu:640-652 stores them inside the loop)
                         max_contributor = before_median ? contributor : max_contributor;
                     }
                     weight += aT;
@@ -126,6 +126,24 @@ blend_fwd_kernel(const BlendFwdArgs a)
     if (inside) {
         const size_t HW = (size_t)a.H * a.W;
         const size_t pix = (size_t)a.W * py + px;
+        if constexpr (GEO) {
+            if (max_contributor != 0xFFFFFFFFu) {
+                const uint32_t id = a.point_list[range.x + max_contributor - 1];
+                const float4* src = (const float4*)(a.rec + (size_t)id * REC_F);
+                const float4 q0 = src[0];
+                const float dx = q0.x - pixfx, dy = q0.y - pixfy;
+                if constexpr (COORD) {
+                    const float4 q3 = src[3], q4 = src[4], q5 = src[5];
+                    mC0 = q3.x + q4.x * dx + q4.y * dy;
+                    mC1 = q3.y + q4.z * dx + q4.w * dy;
+                    mC2 = q3.z + q5.x * dx + q5.y * dy;
+                }
+                if constexpr (DEPTH) {
+                    const float4 q2 = src[2];
+                    mDepth = q2.y + (q2.z * dx + q2.w * dy);
+                }
+            }
+        }
         a.n_contrib[pix] = last_contributor;
         a.n_contrib[pix + HW] = max_contributor;
         a.out_color[pix] = C0 + T * a.bg[0];
