@@ -67,6 +67,21 @@ typedef struct { real x, y, z; } f3;
  * operand is really dL_dconic.w in the reference) so the remaining chain can be checked against autograd */
 static int g_flags = 0;
 void gsor_set_flags(int f) { g_flags = f; }
+/* per-Gaussian sums of the blend backward: double by default (rounded once at the end, see the header); with flag 2 the running
+ * sum is rounded to float after every add, i.e. the reference's float atomicAdd (backward.cu:878-1013) in ONE of its possible
+ * orders -- tests use the difference between the two as the sensitivity of a Gaussian's gradient to that rounding */
+#define ACCUM(x, v) do { (x) += (v); if (g_flags & 2) (x) = (double)(float)(x); } while (0)
+/* flag 4: every finished per-Gaussian sum is scaled by 1 + 2e-6 u, u in [-1,1] a hash of its index (and of flags >> 8, the sample number): the size of the rounding
+ * error a float atomicAdd accumulation over a few hundred partial sums leaves (any order).  The per-Gaussian backward that
+ * follows amplifies it by up to 1e5 for splats seen edge-on or from inside; tests use the shift as that Gaussian's sensitivity. */
+static double sum_jitter(size_t i, unsigned salt)
+{
+    if (!(g_flags & 4)) return 1.0;
+    if (((g_flags >> 4) & 15) && (unsigned)((g_flags >> 4) & 15) != salt) return 1.0;    /* bits 4..7: jitter one family of sums only */
+    uint64_t z = (uint64_t)i * 0x9E3779B97F4A7C15ull + (uint64_t)(salt + 16u * (unsigned)(g_flags >> 8)) * 0xBF58476D1CE4E5B9ull + 0x94D049BB133111EBull;
+    z ^= z >> 30; z *= 0xBF58476D1CE4E5B9ull; z ^= z >> 27; z *= 0x94D049BB133111EBull; z ^= z >> 31;
+    return 1.0 + 2e-6 * ((double)(z >> 11) / 9007199254740992.0 * 2.0 - 1.0);
+}
 
 /* ------------------------------------------------------------------ */
 /* small glm-like helpers                                              */
@@ -883,7 +898,7 @@ static void render_pixel_bwd(const gsor_state* s, int COORD, int DEPTH, int NORM
             accum_rec[ch] = last_alpha * last_color[ch] + (1.f - last_alpha) * accum_rec[ch];
             last_color[ch] = c;
             dL_dopa += (c - accum_rec[ch]) * dL_dpixel[ch];
-            A->colors[NCH*(size_t)id + ch] += dchannel_dcolor * dL_dpixel[ch];
+            ACCUM(A->colors[NCH*(size_t)id + ch], dchannel_dcolor * dL_dpixel[ch]);
         }
         real dL_dcoords[3] = {0,0,0}, dL_dt = 0;
         const real* cp = s->camera_planes + 6*(size_t)id;
@@ -900,9 +915,9 @@ static void render_pixel_bwd(const gsor_state* s, int COORD, int DEPTH, int NORM
                 if (contributor == (uint32_t)(max_contributor - 1)) dL_dcoords[ch] += dL_dpixel_mcoord[ch];
             }
             for (int ch = 0; ch < 3; ch++) {
-                A->view_points[3*(size_t)id + ch] += dL_dcoords[ch];
-                A->camera_planes[6*(size_t)id + 2*ch]     += dL_dcoords[ch] * dx / fx;
-                A->camera_planes[6*(size_t)id + 2*ch + 1] += dL_dcoords[ch] * dy / fy;
+                ACCUM(A->view_points[3*(size_t)id + ch], dL_dcoords[ch]);
+                ACCUM(A->camera_planes[6*(size_t)id + 2*ch], dL_dcoords[ch] * dx / fx);
+                ACCUM(A->camera_planes[6*(size_t)id + 2*ch + 1], dL_dcoords[ch] * dy / fy);
             }
         }
         if (DEPTH) {
@@ -912,16 +927,16 @@ static void render_pixel_bwd(const gsor_state* s, int COORD, int DEPTH, int NORM
             dL_dopa += (t - accum_t_rec) * dL_dpixel_t;
             dL_dt = dchannel_dcolor * dL_dpixel_t;
             if (contributor == (uint32_t)(max_contributor - 1)) dL_dt += dL_dpixel_mt;
-            A->ts[id] += dL_dt;
-            A->ray_planes[2*(size_t)id]     += dL_dt * dx / fx;
-            A->ray_planes[2*(size_t)id + 1] += dL_dt * dy / fy;
+            ACCUM(A->ts[id], dL_dt);
+            ACCUM(A->ray_planes[2*(size_t)id], dL_dt * dx / fx);
+            ACCUM(A->ray_planes[2*(size_t)id + 1], dL_dt * dy / fy);
         }
         if (NORMAL) for (int ch = 0; ch < 3; ch++) {
             const real c = s->normals[3*(size_t)id + ch];
             accum_normal_rec[ch] = last_alpha * last_normal[ch] + (1.f - last_alpha) * accum_normal_rec[ch];
             last_normal[ch] = c;
             dL_dopa += (c - accum_normal_rec[ch]) * dL_dpixel_normal[ch];
-            A->normals[3*(size_t)id + ch] += dchannel_dcolor * dL_dpixel_normal[ch];
+            ACCUM(A->normals[3*(size_t)id + ch], dchannel_dcolor * dL_dpixel_normal[ch]);
         }
         accum_alpha_rec = last_alpha + (1.f - last_alpha) * accum_alpha_rec;
         dL_dopa += (1 - accum_alpha_rec) * dL_dalpha;
@@ -941,13 +956,13 @@ static void render_pixel_bwd(const gsor_state* s, int COORD, int DEPTH, int NORM
             dL_ddely += dL_dcoords[0]*cp[1] + dL_dcoords[1]*cp[3] + dL_dcoords[2]*cp[5];
         }
         if (DEPTH) { dL_ddelx += dL_dt * rp[0]; dL_ddely += dL_dt * rp[1]; }
-        A->mean2D[3*(size_t)id]     += dL_ddelx * ddelx_dx;
-        A->mean2D[3*(size_t)id + 1] += dL_ddely * ddely_dy;
-        A->mean2D[3*(size_t)id + 2] += FABS(dL_dG * dG_ddelx * ddelx_dx) + FABS(dL_dG * dG_ddely * ddely_dy);
-        A->conic[4*(size_t)id]     += -0.5f * gdx * dx * dL_dG;
-        A->conic[4*(size_t)id + 1] += -0.5f * gdx * dy * dL_dG;
-        A->conic[4*(size_t)id + 3] += -0.5f * gdy * dy * dL_dG;
-        A->opacity[id] += G * dL_dopa;
+        ACCUM(A->mean2D[3*(size_t)id], dL_ddelx * ddelx_dx);
+        ACCUM(A->mean2D[3*(size_t)id + 1], dL_ddely * ddely_dy);
+        ACCUM(A->mean2D[3*(size_t)id + 2], FABS(dL_dG * dG_ddelx * ddelx_dx) + FABS(dL_dG * dG_ddely * ddely_dy));
+        ACCUM(A->conic[4*(size_t)id], -0.5f * gdx * dx * dL_dG);
+        ACCUM(A->conic[4*(size_t)id + 1], -0.5f * gdx * dy * dL_dG);
+        ACCUM(A->conic[4*(size_t)id + 3], -0.5f * gdy * dy * dL_dG);
+        ACCUM(A->opacity[id], G * dL_dopa);
     }
 }
 
@@ -1209,12 +1224,12 @@ void gsor_backward(const gsor_state* s, const real* bg, const real* means3D, con
     }
     real* f_view_points = xcalloc((size_t)P*3, sizeof(real)); real* f_ts = xcalloc(P, sizeof(real)); real* f_cp = xcalloc((size_t)P*6, sizeof(real));
     real* f_rp = xcalloc((size_t)P*2, sizeof(real)); real* f_nrm = xcalloc((size_t)P*3, sizeof(real)); real* f_conic = xcalloc((size_t)P*4, sizeof(real));
-    for (size_t i = 0; i < (size_t)P*3; i++) { dL_dmean2D[i] = (real)A.mean2D[i]; dL_dcolor[i] = (real)A.colors[i];
-                                               f_view_points[i] = (real)A.view_points[i]; f_nrm[i] = (real)A.normals[i]; }
-    for (size_t i = 0; i < (size_t)P*4; i++) f_conic[i] = (real)A.conic[i];
-    for (size_t i = 0; i < (size_t)P; i++) { dL_dopacity[i] = (real)A.opacity[i]; f_ts[i] = (real)A.ts[i]; }
-    for (size_t i = 0; i < (size_t)P*6; i++) f_cp[i] = (real)A.camera_planes[i];
-    for (size_t i = 0; i < (size_t)P*2; i++) f_rp[i] = (real)A.ray_planes[i];
+    for (size_t i = 0; i < (size_t)P*3; i++) { dL_dmean2D[i] = (real)(A.mean2D[i] * sum_jitter(i, 1)); dL_dcolor[i] = (real)(A.colors[i] * sum_jitter(i, 2));
+                                               f_view_points[i] = (real)(A.view_points[i] * sum_jitter(i, 3)); f_nrm[i] = (real)(A.normals[i] * sum_jitter(i, 4)); }
+    for (size_t i = 0; i < (size_t)P*4; i++) f_conic[i] = (real)(A.conic[i] * sum_jitter(i, 5));
+    for (size_t i = 0; i < (size_t)P; i++) { dL_dopacity[i] = (real)(A.opacity[i] * sum_jitter(i, 6)); f_ts[i] = (real)(A.ts[i] * sum_jitter(i, 7)); }
+    for (size_t i = 0; i < (size_t)P*6; i++) f_cp[i] = (real)(A.camera_planes[i] * sum_jitter(i, 8));
+    for (size_t i = 0; i < (size_t)P*2; i++) f_rp[i] = (real)(A.ray_planes[i] * sum_jitter(i, 9));
     free(A.mean2D); free(A.conic); free(A.opacity); free(A.colors); free(A.view_points); free(A.ts);
     free(A.camera_planes); free(A.ray_planes); free(A.normals);
     if (dbg_view_points) memcpy(dbg_view_points, f_view_points, (size_t)P*3*sizeof(real));

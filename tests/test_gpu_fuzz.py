@@ -1,0 +1,137 @@
+"""Randomised parity soak: random scenes (sizes, ragged images, camera poses, scale / opacity distributions, SH degree,
+kernel_size, output instances) through the C ABI against the CPU oracle.  Index work bit-exact, images and gradients at the
+bars of test_gpu_parity.py.  The regular suite runs a dozen seeds; `IGS_FUZZ_SEEDS=300 pytest tests/test_gpu_fuzz.py -m gpu`
+is the soak (last soak: see DESIGN.md section 2).
+"""
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from igs_amd.camera import Camera, look_at_c2w
+from igs_amd.scenes import activate
+from test_gpu_parity import (KEYS, GNAMES, hip_forward, hip_backward, oracle_forward, oracle_backward, rand_grads, check_images, check_grads, dev)  # noqa: F401
+
+pytestmark = pytest.mark.gpu
+
+N_SEEDS = int(os.environ.get("IGS_FUZZ_SEEDS", "12"))
+FIRST = int(os.environ.get("IGS_FUZZ_FIRST", "0"))
+
+
+def random_case(seed):
+    rng = np.random.default_rng(1000 + seed)
+    gen = torch.Generator().manual_seed(1000 + seed)
+    P = int(rng.choice([0, 1, 7, 300, 2000, 5000, 9000]))
+    W, H = int(rng.integers(9, 300)), int(rng.integers(9, 300))
+    extent = float(rng.choice([0.5, 1.5, 4.0]))
+    log_scale_lo = float(rng.choice([-6.0, -4.0, -2.5]))          # up to very large splats (hundreds of tiles each)
+    raw = dict(
+        xyz=(torch.rand(P, 3, generator=gen) * 2.0 - 1.0) * extent,
+        scaling=torch.rand(P, 3, generator=gen) * 2.5 + log_scale_lo,
+        rotation=torch.randn(P, 4, generator=gen),
+        opacity=torch.randn(P, 1, generator=gen) * float(rng.choice([0.5, 1.5, 4.0])) + float(rng.choice([-2.0, 0.0, 3.0])),
+        shs=torch.randn(P, 16, 3, generator=gen) * float(rng.choice([0.02, 0.3])),
+    )
+    if P:
+        raw["shs"][:, 0, :] = torch.randn(P, 3, generator=gen)
+    # camera somewhere around the cloud (sometimes inside it: near-plane culling, huge projected splats)
+    dist = float(rng.choice([0.3, 2.0, 5.0])) * extent
+    d = rng.standard_normal(3); d /= np.linalg.norm(d)
+    eye = (d * dist).tolist()
+    target = (rng.standard_normal(3) * 0.2 * extent).tolist()
+    c2w = look_at_c2w(eye, target)
+    fovx, fovy = math.radians(float(rng.uniform(25, 100))), math.radians(float(rng.uniform(25, 100)))
+    cam = Camera.from_c2w(c2w, (fovx, fovy), (H, W))
+    bg = torch.tensor(rng.uniform(0, 1, 3), dtype=torch.float)
+    req = [(True, True), (True, False), (False, True), (False, False)][int(rng.integers(0, 4))]
+    deg = int(rng.integers(0, 4))
+    kernel_size = float(rng.choice([0.0, 0.0, 0.1, 0.3]))
+    return raw, cam, bg, req, deg, kernel_size
+
+
+def oracle_gradients_f64(a, cam, bg, req, deg, ks, grads):
+    from oracle import c_oracle as co
+    co.set_precision("float64")
+    try:
+        a64 = {k: v.double() for k, v in a.items()}
+        nr, oo, st = co.rasterize_forward(bg.double(), a64["means3D"], None, a64["opacities"], a64["scales"], a64["rotations"], 1.0, None,
+                                          cam.world_view_transform.double(), cam.full_proj_transform.double(), cam.tanfovx, cam.tanfovy, ks,
+                                          cam.height, cam.width, a64["shs"], deg, cam.camera_center.double(), require_coord=req[0], require_depth=req[1])
+        return co.rasterize_backward(st, bg.double(), a64["means3D"], None, a64["scales"], a64["rotations"], None,
+                                     cam.world_view_transform.double(), cam.full_proj_transform.double(), cam.camera_center.double(),
+                                     a64["shs"], oo["alpha"], oo["normal"], *[np.asarray(grads[k], np.float64) for k in KEYS])
+    finally:
+        co.set_precision("float32")
+
+
+@pytest.mark.parametrize("seed", range(FIRST, FIRST + N_SEEDS))
+def test_random_scene_matches_oracle(dev, seed):
+    from igs_amd import rasterizer as R
+    raw, cam, bg, req, deg, ks = random_case(seed)
+    a = activate(raw)
+    P = a["means3D"].shape[0]
+    out, ad, mats = hip_forward(a, cam, bg, dev, req, deg=deg, kernel_size=ks)
+    nr_o, oo, st = oracle_forward(a, cam, bg, req, deg=deg, kernel_size=ks)
+    nr, radii = out[0], out[8]
+    print("fuzz seed %d: P %d, %dx%d, req %s, deg %d, kernel_size %.1f, num_rendered %d" % (seed, P, cam.width, cam.height, req, deg, ks, nr_o))
+    assert nr == nr_o, (nr, nr_o)
+    np.testing.assert_array_equal(radii.cpu().numpy(), oo["radii"])
+    if P and nr:
+        it = st.intermediates()
+        d = R.debug_dump(P, nr, cam.width, cam.height, out[9], out[10], out[11])
+        np.testing.assert_array_equal(d["tiles_touched"].cpu().numpy().astype(np.uint32), it["tiles_touched"])
+        np.testing.assert_array_equal(d["point_list"].cpu().numpy().astype(np.uint32), it["point_list"])
+        np.testing.assert_array_equal(d["ranges"].cpu().numpy().astype(np.uint32), it["ranges"])
+        # contributor counts follow the blend thresholds: exact except where an expf last-bit difference flips one (check_images' `flips`)
+        nc = d["n_contrib"].cpu().numpy().astype(np.uint32)
+        assert (nc != it["n_contrib"]).mean() <= 5e-4, (nc != it["n_contrib"]).mean()
+    check_images(out, oo, flips=5e-4)
+    if P == 0:
+        return
+    grads = rand_grads(oo, seed)
+    gout = hip_backward(out, ad, mats, cam, bg, dev, grads, req, deg=deg, kernel_size=ks)
+    gr = oracle_backward(st, oo, a, cam, bg, grads, deg=deg)
+    try:
+        if P >= 300 and nr:
+            check_grads(gout, gr, bulk=0.94, p99=3e-2, worst=1.0)
+        else:       # a handful of Gaussians: element-wise, against the largest gradient of the tensor
+            for n, t in zip(GNAMES, gout):
+                A, B = t.cpu().numpy().reshape(gr[n].shape), gr[n]
+                assert np.abs(A - B).max() <= 2e-3 * max(np.abs(B).max(), 1e-6), n
+    except AssertionError as e:
+        # Ill-conditioned Gaussians?  The reference divides by T_final = 1 - sum(alpha T) behind saturated pixels (backward.cu:706,857),
+        # and with kernel_size = 0 its coef backward (backward.cu:367-375) adds dL_dsqrtcoef * (c/det1 - det0 c/det1^2) -- zero in
+        # exact arithmetic, in float the rounding residue of two equal terms times a 2-D covariance entry: for a splat hundreds of
+        # tiles wide the last bits of the per-Gaussian sums -- float atomicAdd in the reference, in any order -- decide the
+        # result (seen here: five back-to-back launches on identical inputs give three different dL_dmeans3D for one Gaussian, and
+        # the oracle itself lands on different ones of them on two x86 hosts).  Certificate: the oracle with every finished
+        # per-Gaussian sum scaled by 1 + 2e-6 u (flag 4: the rounding a float atomic accumulation leaves) moves such a Gaussian's
+        # gradient by `e_acc`; the HIP result has to stay within a small multiple of that + the oracle's own distance from a
+        # float64 evaluation everywhere, and at most 2 % of the Gaussians may need the allowance.
+        from oracle import c_oracle as co
+        g64 = oracle_gradients_f64(a, cam, bg, req, deg, ks, grads)
+        shifts = {n: np.zeros(P) for n in GNAMES}
+        try:
+            for sample in range(8):         # the gradient of such a Gaussian jumps between a few plateaus: sample the jitter
+                co.set_flags(4 + 256 * sample)
+                gj = oracle_backward(st, oo, a, cam, bg, grads, deg=deg)
+                for n in GNAMES:
+                    shifts[n] = np.maximum(shifts[n], np.abs(gj[n].astype(np.float64) - gr[n]).reshape(P, -1).max(1))
+        finally:
+            co.set_flags(0)
+        touchy = np.zeros(P, bool)
+        for n, t in zip(GNAMES, gout):
+            A = t.cpu().numpy().reshape(gr[n].shape).astype(np.float64).reshape(P, -1)
+            G, G32 = g64[n].reshape(P, -1), gr[n].astype(np.float64).reshape(P, -1)
+            scale = max(np.abs(G).max(), 1e-30)
+            e_hip, e_or, e_acc = np.abs(A - G).max(1), np.abs(G32 - G).max(1), shifts[n]
+            bad = e_hip > 5.0 * e_or + 5.0 * e_acc + 2e-3 * scale
+            if bad.any():
+                g = int(np.argmax(np.where(bad, e_hip, 0)))
+                raise AssertionError("%s: Gaussian %d (radius %d): hip %s f64 %s, |f32-f64| %.3g, sum-jitter shift %.3g [%s]" % (
+                    n, g, oo["radii"][g], A[g][:6], G[g][:6], e_or[g], e_acc[g], str(e)[:60]))
+            touchy |= e_hip > 5.0 * e_or + 2e-3 * scale
+        assert touchy.mean() <= 0.02 or touchy.sum() <= 1, touchy.mean()
+        print("fuzz seed %d: %d ill-conditioned Gaussian(s) (the oracle moves as much when its sums are jittered by 2e-6)" % (seed, touchy.sum()))
