@@ -243,7 +243,8 @@ __device__ __forceinline__ void cov2d_ctx(Cov2DCtx& c, float3 mean, const float*
         for (int j = 0; j < 3; j++)
             B[i][j] = c.A[i][0] * c.Sigma.m[0][j] + c.A[i][1] * c.Sigma.m[1][j] + c.A[i][2] * c.Sigma.m[2][j];
     c.cov2[0] = B[0][0] * c.A[0][0] + B[0][1] * c.A[0][1] + B[0][2] * c.A[0][2];
-    c.cov2[1] = B[0][0] * c.A[1][0] + B[0][1] * c.A[1][1] + B[0][2] * c.A[1][2];
+    // cov[0][1] of glm = column 0, row 1 = (row 1 of A Sigma) . (row 0 of A): the transposed product rounds differently in the last bit
+    c.cov2[1] = B[1][0] * c.A[0][0] + B[1][1] * c.A[0][1] + B[1][2] * c.A[0][2];
     c.cov2[2] = B[1][0] * c.A[1][0] + B[1][1] * c.A[1][1] + B[1][2] * c.A[1][2];
     // the 1e-6 literals are double in the reference: max(1e-6, float) -> double -> float
     const double d0 = (double)(c.cov2[0] * c.cov2[2] - c.cov2[1] * c.cov2[1]);

@@ -195,7 +195,9 @@ def rasterize_backward(state, bg, means3D, colors_precomp, scales, rotations, co
 
 
 def set_flags(flags):
-    """bit 0: drop the d(coef)/d(cov2D) terms in the backward (test-only, see rast_oracle.c)."""
+    """bit 0: drop the d(coef)/d(cov2D) terms in the backward; bit 1 (2): keep the per-Gaussian sums of the blend backward in
+    float like the reference's atomicAdd (default: double, rounded once); bit 2 (4): scale every finished sum by 1 + 2e-6 u,
+    u a hash of (index, flags >> 8); bits 4..7: jitter only that family of sums.  Test-only, see rast_oracle.c."""
     lib().gsor_set_flags(int(flags))
 
 
