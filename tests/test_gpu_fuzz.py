@@ -23,8 +23,10 @@ FIRST = int(os.environ.get("IGS_FUZZ_FIRST", "0"))
 def random_case(seed):
     rng = np.random.default_rng(1000 + seed)
     gen = torch.Generator().manual_seed(1000 + seed)
-    P = int(rng.choice([0, 1, 7, 300, 2000, 5000, 9000]))
+    P = int(rng.choice([0, 1, 7, 300, 2000, 5000, 9000, 20000]))
     W, H = int(rng.integers(9, 300)), int(rng.integers(9, 300))
+    if P == 20000:          # every splat on a handful of tiles: lists beyond the in-LDS tile sorts (global radix fallback)
+        W, H = int(rng.integers(9, 64)), int(rng.integers(9, 64))
     extent = float(rng.choice([0.5, 1.5, 4.0]))
     log_scale_lo = float(rng.choice([-6.0, -4.0, -2.5]))          # up to very large splats (hundreds of tiles each)
     raw = dict(
@@ -51,17 +53,31 @@ def random_case(seed):
     return raw, cam, bg, req, deg, kernel_size
 
 
-def oracle_gradients_f64(a, cam, bg, req, deg, ks, grads):
+def random_modes(seed, P):
+    """Optional inputs of the rasterizer (forward.cu:283-300,394): precomputed colours, precomputed 3-D covariance, scale modifier."""
+    rng = np.random.default_rng(77000 + seed)
+    gen = torch.Generator().manual_seed(77000 + seed)
+    colors = torch.rand(P, 3, generator=gen) if rng.random() < 0.15 else None
+    use_cov = rng.random() < 0.15
+    scale_modifier = float(rng.choice([1.0, 1.0, 1.0, 0.6, 1.7]))
+    return colors, use_cov, scale_modifier
+
+
+def oracle_gradients_f64(a, cam, bg, req, deg, ks, grads, colors=None, cov=None, scale_modifier=1.0):
     from oracle import c_oracle as co
     co.set_precision("float64")
     try:
         a64 = {k: v.double() for k, v in a.items()}
-        nr, oo, st = co.rasterize_forward(bg.double(), a64["means3D"], None, a64["opacities"], a64["scales"], a64["rotations"], 1.0, None,
+        c64 = None if colors is None else colors.double()
+        v64 = None if cov is None else cov.double()
+        sc, ro = (None, None) if cov is not None else (a64["scales"], a64["rotations"])
+        sh = None if colors is not None else a64["shs"]
+        nr, oo, st = co.rasterize_forward(bg.double(), a64["means3D"], c64, a64["opacities"], sc, ro, scale_modifier, v64,
                                           cam.world_view_transform.double(), cam.full_proj_transform.double(), cam.tanfovx, cam.tanfovy, ks,
-                                          cam.height, cam.width, a64["shs"], deg, cam.camera_center.double(), require_coord=req[0], require_depth=req[1])
-        return co.rasterize_backward(st, bg.double(), a64["means3D"], None, a64["scales"], a64["rotations"], None,
+                                          cam.height, cam.width, sh, deg, cam.camera_center.double(), require_coord=req[0], require_depth=req[1])
+        return co.rasterize_backward(st, bg.double(), a64["means3D"], c64, sc, ro, v64,
                                      cam.world_view_transform.double(), cam.full_proj_transform.double(), cam.camera_center.double(),
-                                     a64["shs"], oo["alpha"], oo["normal"], *[np.asarray(grads[k], np.float64) for k in KEYS])
+                                     sh, oo["alpha"], oo["normal"], *[np.asarray(grads[k], np.float64) for k in KEYS])
     finally:
         co.set_precision("float32")
 
@@ -72,10 +88,18 @@ def test_random_scene_matches_oracle(dev, seed):
     raw, cam, bg, req, deg, ks = random_case(seed)
     a = activate(raw)
     P = a["means3D"].shape[0]
-    out, ad, mats = hip_forward(a, cam, bg, dev, req, deg=deg, kernel_size=ks)
-    nr_o, oo, st = oracle_forward(a, cam, bg, req, deg=deg, kernel_size=ks)
+    colors, use_cov, sm = random_modes(seed, P)
+    cov = None
+    if use_cov and P:           # the covariance the scale / rotation path would build (cov3D of the oracle's own state), handed in precomputed
+        _, _, st0 = oracle_forward(a, cam, bg, req, deg=deg, kernel_size=ks, scale_modifier=sm)
+        cov = torch.from_numpy(st0.intermediates()["cov3D"].copy())
+    kw = dict(deg=deg, kernel_size=ks, colors=colors, cov=cov, scale_modifier=sm)
+    okw = dict(deg=deg, kernel_size=ks, colors=None if colors is None else colors.numpy(), cov=None if cov is None else cov.numpy(), scale_modifier=sm)
+    out, ad, mats = hip_forward(a, cam, bg, dev, req, **kw)
+    nr_o, oo, st = oracle_forward(a, cam, bg, req, **okw)
     nr, radii = out[0], out[8]
-    print("fuzz seed %d: P %d, %dx%d, req %s, deg %d, kernel_size %.1f, num_rendered %d" % (seed, P, cam.width, cam.height, req, deg, ks, nr_o))
+    print("fuzz seed %d: P %d, %dx%d, req %s, deg %d, kernel_size %.1f, colours %s, cov %s, scale_modifier %.1f, num_rendered %d" % (
+        seed, P, cam.width, cam.height, req, deg, ks, colors is not None, cov is not None, sm, nr_o))
     assert nr == nr_o, (nr, nr_o)
     np.testing.assert_array_equal(radii.cpu().numpy(), oo["radii"])
     if P and nr:
@@ -91,13 +115,16 @@ def test_random_scene_matches_oracle(dev, seed):
     if P == 0:
         return
     grads = rand_grads(oo, seed)
-    gout = hip_backward(out, ad, mats, cam, bg, dev, grads, req, deg=deg, kernel_size=ks)
-    gr = oracle_backward(st, oo, a, cam, bg, grads, deg=deg)
+    gout = hip_backward(out, ad, mats, cam, bg, dev, grads, req, **kw)
+    obk = dict(deg=deg, colors=okw["colors"], cov=okw["cov"])
+    gr = oracle_backward(st, oo, a, cam, bg, grads, **obk)
     try:
         if P >= 300 and nr:
             check_grads(gout, gr, bulk=0.94, p99=3e-2, worst=1.0)
         else:       # a handful of Gaussians: element-wise, against the largest gradient of the tensor
             for n, t in zip(GNAMES, gout):
+                if gr[n].size == 0:
+                    continue
                 A, B = t.cpu().numpy().reshape(gr[n].shape), gr[n]
                 assert np.abs(A - B).max() <= 2e-3 * max(np.abs(B).max(), 1e-6), n
     except AssertionError as e:
@@ -113,18 +140,22 @@ def test_random_scene_matches_oracle(dev, seed):
         # such a Gaussian's gradient by `e_acc`; the HIP result has to stay within a small multiple of that + the oracle's own
         # distance from a float64 evaluation everywhere, and at most 2 % of the Gaussians may need the allowance.
         from oracle import c_oracle as co
-        g64 = oracle_gradients_f64(a, cam, bg, req, deg, ks, grads)
+        g64 = oracle_gradients_f64(a, cam, bg, req, deg, ks, grads, colors, cov, sm)
         shifts = {n: np.zeros(P) for n in GNAMES}
         try:
             for sample in range(24):        # the gradient of such a Gaussian jumps between a few plateaus: sample the jitter
                 co.set_flags(2 + 4 + 256 * sample)
-                gj = oracle_backward(st, oo, a, cam, bg, grads, deg=deg)
+                gj = oracle_backward(st, oo, a, cam, bg, grads, **obk)
                 for n in GNAMES:
+                    if gr[n].size == 0:
+                        continue
                     shifts[n] = np.maximum(shifts[n], np.abs(gj[n].astype(np.float64) - gr[n]).reshape(P, -1).max(1))
         finally:
             co.set_flags(0)
         touchy = np.zeros(P, bool)
         for n, t in zip(GNAMES, gout):
+            if gr[n].size == 0:
+                continue
             A = t.cpu().numpy().reshape(gr[n].shape).astype(np.float64).reshape(P, -1)
             G, G32 = g64[n].reshape(P, -1), gr[n].astype(np.float64).reshape(P, -1)
             scale = max(np.abs(G).max(), 1e-30)

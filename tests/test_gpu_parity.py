@@ -35,34 +35,34 @@ def dev():
     return torch.device("cuda:0")
 
 
-def hip_forward(a, cam, bg, dev, req=(True, True), deg=3, colors=None, cov=None, debug=True, kernel_size=0.0, prefiltered=False):
+def hip_forward(a, cam, bg, dev, req=(True, True), deg=3, colors=None, cov=None, debug=True, kernel_size=0.0, prefiltered=False, scale_modifier=1.0):
     from igs_amd import rasterizer as R
     ad = {k: v.to(dev) for k, v in a.items()}
     V, Pm, cc = cam.world_view_transform.to(dev), cam.full_proj_transform.to(dev), cam.camera_center.to(dev)
     out = R.rasterize_gaussians(bg.to(dev), ad["means3D"], E if colors is None else colors.to(dev), ad["opacities"],
-                                E if cov is not None else ad["scales"], E if cov is not None else ad["rotations"], 1.0,
+                                E if cov is not None else ad["scales"], E if cov is not None else ad["rotations"], scale_modifier,
                                 E if cov is None else cov.to(dev), V, Pm, cam.tanfovx, cam.tanfovy, kernel_size, cam.height,
                                 cam.width, E if colors is not None else ad["shs"], deg, cc, prefiltered, req[0], req[1], debug)
     return out, ad, (V, Pm, cc)
 
 
-def hip_backward(out, ad, mats, cam, bg, dev, grads, req=(True, True), deg=3, colors=None, cov=None, kernel_size=0.0):
+def hip_backward(out, ad, mats, cam, bg, dev, grads, req=(True, True), deg=3, colors=None, cov=None, kernel_size=0.0, scale_modifier=1.0):
     from igs_amd import rasterizer as R
     nr, color, coord, mcoord, alpha, normal, depth, mdepth, radii, gb, bb, ib = out
     V, Pm, cc = mats
     gt = {k: torch.from_numpy(v).to(dev) for k, v in grads.items()}
     return R.rasterize_gaussians_backward(bg.to(dev), ad["means3D"], radii, E if colors is None else colors.to(dev),
-                                          E if cov is not None else ad["scales"], E if cov is not None else ad["rotations"], 1.0,
+                                          E if cov is not None else ad["scales"], E if cov is not None else ad["rotations"], scale_modifier,
                                           E if cov is None else cov.to(dev), V, Pm, cam.tanfovx, cam.tanfovy, kernel_size,
                                           gt["color"], gt["coord"], gt["mcoord"], gt["depth"], gt["mdepth"], gt["alpha"], gt["normal"],
                                           normal, E if colors is not None else ad["shs"], deg, cc, gb, nr, bb, ib, alpha, req[0], req[1], True)
 
 
-def oracle_forward(a, cam, bg, req=(True, True), deg=3, colors=None, cov=None, kernel_size=0.0):
+def oracle_forward(a, cam, bg, req=(True, True), deg=3, colors=None, cov=None, kernel_size=0.0, scale_modifier=1.0):
     from oracle import c_oracle as co
     co.set_precision("float32")
     return co.rasterize_forward(bg, a["means3D"], colors, a["opacities"], None if cov is not None else a["scales"],
-                                None if cov is not None else a["rotations"], 1.0, cov, cam.world_view_transform,
+                                None if cov is not None else a["rotations"], scale_modifier, cov, cam.world_view_transform,
                                 cam.full_proj_transform, cam.tanfovx, cam.tanfovy, kernel_size, cam.height, cam.width,
                                 None if colors is not None else a["shs"], deg, cam.camera_center, require_coord=req[0], require_depth=req[1])
 
@@ -96,6 +96,9 @@ def check_images(out, oo, tol=1e-4, flips=2e-4):
 
 def check_grads(gout, gr, bulk=0.96, p99=1e-2, worst=0.25):
     for n, t in zip(GNAMES, gout):
+        if gr[n].size == 0:     # dL_dsh with precomputed colours
+            assert t.numel() == 0, n
+            continue
         A = t.cpu().numpy().reshape(gr[n].shape)
         assert not np.isnan(A).any(), n
         r = rel(A, gr[n])
