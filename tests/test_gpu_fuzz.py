@@ -168,3 +168,42 @@ def test_random_scene_matches_oracle(dev, seed):
             touchy |= e_hip > 5.0 * e_or + 2e-3 * scale
         assert touchy.mean() <= 0.02 or touchy.sum() <= 2, touchy.mean()
         print("fuzz seed %d: %d ill-conditioned Gaussian(s) (the oracle moves as much with float sums + 2e-6 jitter)" % (seed, touchy.sum()))
+
+
+N_REFINE = int(os.environ.get("IGS_FUZZ_REFINE_SEEDS", "8"))
+
+
+@pytest.mark.parametrize("seed", range(FIRST, FIRST + N_REFINE))
+def test_random_scene_fused_refine_step_matches_unfused(dev, seed):
+    """`igs_refine_step` (raw activations, zero-fill, fused loss, gradients-only ending) against the unfused native step on random
+    scenes: ragged images, one Gaussian to thousands, cameras inside the cloud (slab overflow -> second attempt), both losses,
+    with and without the depth-normal regulariser.  Splat sizes are kept moderate: the rounding-residue Gaussians of the test
+    above would make two runs of the SAME kernels disagree."""
+    from igs_amd.refine import GaussianParams, Refiner
+    raw, cam, bg, req, deg, ks = random_case(5000 + seed)
+    P = raw["xyz"].shape[0]
+    if P == 0:
+        pytest.skip("the refine step needs at least one Gaussian")
+    rng = np.random.default_rng(9000 + seed)
+    gen = torch.Generator().manual_seed(9000 + seed)
+    raw["scaling"] = torch.rand(P, 3, generator=gen) * 2.0 - 5.5
+    cams = [cam.to(dev)]
+    gts = [torch.rand(3, cam.height, cam.width, generator=gen).to(dev)]
+    loss = ["l1", "l1_ssim"][int(rng.integers(0, 2))]
+    ldn = float(rng.choice([0.0, 0.0, 0.05]))
+    pa, pb = GaussianParams(raw, dev), GaussianParams(raw, dev)
+    ra = Refiner(pa, cams, gts, bg.to(dev), loss=loss, native=True, fused=True, lambda_depth_normal=ldn)
+    rb = Refiner(pb, cams, gts, bg.to(dev), loss=loss, native=True, fused=False, lambda_depth_normal=ldn)
+    ra.adam_fn = lambda: None
+    rb.adam_fn = lambda: None
+    before = pa.flat.clone()
+    pka = ra.step(view=0); pkb = rb.step(view=0)
+    print("fuzz refine seed %d: P %d, %dx%d, loss %s, lambda_dn %.2f" % (seed, P, cam.width, cam.height, loss, ldn))
+    assert torch.equal(pa.flat, before) and pa.step_count == 0
+    assert torch.equal(pka["radii"], pkb["radii"])
+    np.testing.assert_allclose(pka["images_pred"].detach().cpu().numpy(), pkb["images_pred"].detach().cpu().numpy(), atol=2e-5)
+    for k in pa.leaves:
+        A, B = pa.leaves[k].grad.cpu().numpy().astype(np.float64), pb.leaves[k].grad.cpu().numpy().astype(np.float64)
+        scale = max(np.abs(B).max(), 1e-30)
+        close = np.abs(A - B) <= 2e-3 * np.abs(B) + 2e-4 * scale
+        assert close.mean() >= (0.98 if P >= 300 else 0.85), (k, close.mean(), np.abs(A - B).max(), scale)
