@@ -92,6 +92,9 @@ def main():
     ap.add_argument("--colour-only-forward", action="store_true",
                     help="NOT the reference configuration: render colour only (require_coord = require_depth = False); the L1 / SSIM\n"
                          "losses never look at the other outputs, so the refined parameters are the same")
+    ap.add_argument("--viewspace-grad", action="store_true",
+                    help="also produce dL/d(screen-space mean) with its absolute-gradient column (only the densification statistics\n"
+                         "read it; the refine loop without densification does not)")
     ap.add_argument("--no-spatial-sort", action="store_true", help="keep the Gaussians in the (random) order of the synthetic scene")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse the\n"
                     "N > 1 code path on a box with fewer GPUs than ranks)")
@@ -135,6 +138,7 @@ def main():
                   lambda_depth_normal=args.lambda_depth_normal)
     ref.require_geometry = not args.colour_only_forward
     ref.clamp = args.clamp
+    ref.want_viewspace_grad = args.viewspace_grad
 
     def barrier():
         if world > 1:

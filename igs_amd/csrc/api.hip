@@ -477,6 +477,7 @@ static int backward_impl(
     ba.dL_dmdepth = dL_dpix_mdepth; ba.dL_dalpha = dL_dalphas; ba.dL_dnormal = dL_dpixel_normals;
     ba.gacc = gacc;
     ba.l1_gt = l1_gt; ba.l1_color = l1_color; ba.l1_scale = l1_scale; ba.l1_loss = loss_shards;
+    ba.want_absgrad = (fuse && !dL_dmean2D) ? 0 : 1;
     bool gacc_compact = false;
     if (R > 0) {
         HIP_TRY(launch_blend_bwd(s, ba, require_coord != 0, require_depth != 0, &gacc_compact), "blend_bwd launch");

@@ -25,7 +25,7 @@
 //  0..2  sum w*dL/dpix_ch            3..5  Sv = sum dLc_ch          6..8 Sx = sum dLc_ch*dx     9..11 Sy = sum dLc_ch*dy
 //  12    St = sum dLt   13 Stx   14 Sty   15..17 sum w*dL/dnormal_ch
 //  18 Q0 = sum q  19 Qx  20 Qy  21 Qxx  22 Qxy  23 Qyy  (q = dL/dG * G)   24 Z = abs-sum for dL_dmean2D.z
-template <bool COORD, bool DEPTH, bool NORMAL>
+template <bool COORD, bool DEPTH, bool NORMAL, bool ABS = true>
 __global__ void __launch_bounds__(256)
 blend_bwd_kernel(const BlendBwdArgs a)
 {
@@ -35,7 +35,7 @@ blend_bwd_kernel(const BlendBwdArgs a)
     __shared__ uint32_t chunk_id[BCHUNK];
     __shared__ uint64_t quad_bits[4][2];                // [quad][staging wave pair]: BCHUNK = 2 x 64 splats
     __shared__ int wave_max[4];
-    constexpr int NROWS = 10 + (COORD ? 9 : 0) + (DEPTH ? 3 : 0) + (NORMAL ? 3 : 0);   // live moments of this instance
+    constexpr int NROWS = 9 + (ABS ? 1 : 0) + (COORD ? 9 : 0) + (DEPTH ? 3 : 0) + (NORMAL ? 3 : 0);   // live moments of this instance
     // floats per row of the per-wave transpose buffer: 16-byte aligned rows, row starts spread over all banks for the b128 reads
     // (16 rows x 4 banks), and rows r, r+1 -- which the compiler pairs into one ds_write2_b32 -- 36 banks apart instead of 4
     constexpr int RED_STRIDE = NROWS <= 16 ? 100 : 68;
@@ -224,8 +224,6 @@ blend_bwd_kernel(const BlendBwdArgs a)
                 const float dL_dG = valid ? q1.y * dL_dopa : 0.f;
                 const float q = dL_dG * G;
                 const float qdx = q * dx, qdy = q * dy;
-                const float gxa = q0.z * qdx + q0.w * qdy;      // -dL/d(delx) of the Gaussian term
-                const float gya = q1.x * qdy + q0.w * qdx;
 
                 // ---- transpose-reduce over the 64 pixels of the wave: row r of `myred` = the 64 per-lane values of one LIVE
                 // moment (rows are compacted per template instance: 25 with every branch on, 10 for colour-only gradients)
@@ -241,7 +239,11 @@ blend_bwd_kernel(const BlendBwdArgs a)
                 if constexpr (NORMAL) { col[(r++) * RED_STRIDE] = w * gn0; col[(r++) * RED_STRIDE] = w * gn1; col[(r++) * RED_STRIDE] = w * gn2; }
                 col[(r++) * RED_STRIDE] = q; col[(r++) * RED_STRIDE] = qdx; col[(r++) * RED_STRIDE] = qdy;
                 col[(r++) * RED_STRIDE] = qdx * dx; col[(r++) * RED_STRIDE] = qdx * dy; col[(r++) * RED_STRIDE] = qdy * dy;
-                col[(r++) * RED_STRIDE] = fabsf(gxa * halfW) + fabsf(gya * halfH);
+                if constexpr (ABS) {
+                    const float gxa = q0.z * qdx + q0.w * qdy;      // -dL/d(delx) of the Gaussian term
+                    const float gya = q1.x * qdy + q0.w * qdx;
+                    col[(r++) * RED_STRIDE] = fabsf(gxa * halfW) + fabsf(gya * halfH);
+                }
                 // LPR lanes share a row (each sums 64/LPR columns), then LPR partials are combined across lanes
                 float part = 0.f;
                 if (rrow < NROWS) {
@@ -274,7 +276,9 @@ hipError_t launch_blend_bwd(hipStream_t s, const BlendBwdArgs& a, bool coord, bo
     if (C) { if (D) { if (N) LAUNCH(true, true, true); else LAUNCH(true, true, false); }
              else   { if (N) LAUNCH(true, false, true); else LAUNCH(true, false, false); } }
     else   { if (D) { if (N) LAUNCH(false, true, true); else LAUNCH(false, true, false); }
-             else   { if (N) LAUNCH(false, false, true); else LAUNCH(false, false, false); } }
+             else   { if (N) LAUNCH(false, false, true);
+                      else if (a.want_absgrad) LAUNCH(false, false, false);
+                      else hipLaunchKernelGGL((blend_bwd_kernel<false, false, false, false>), grid, block, 0, s, a); } }
 #undef LAUNCH
     return hipGetLastError();
 }

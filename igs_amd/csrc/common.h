@@ -156,6 +156,9 @@ struct BlendBwdArgs {
     float* gacc;
     // refine step: L1 loss fused in -- dL_dpix = l1_scale * sign(l1_color - l1_gt), sum |l1_color - l1_gt| -> 64 shards l1_loss[16*s]
     const float *l1_color, *l1_gt; float l1_scale; float* l1_loss;
+    // 0: nobody reads dL_dmean2D.z (the absolute screen-space gradient sum the densification statistics use): the colour-only
+    // instance then drops that moment (its |.| terms, one LDS row, one atomic lane per row)
+    int want_absgrad = 1;
 };
 hipError_t launch_blend_bwd(hipStream_t s, const BlendBwdArgs& a, bool coord, bool depth, bool* compact_layout);
 

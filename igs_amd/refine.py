@@ -252,6 +252,9 @@ class Refiner:
         self.torch_ssim = False       # autograd path: use the PyTorch SSIM (five grouped convolutions) instead of the fused one
         # optional densify-and-prune (configs/demo.yaml:57-62): a DensifyConfig; statistics and iteration counter per frame
         self.densify = densify
+        # fused step: also return dL/d(screen-space mean) with its absolute-gradient column (what the densification statistics read);
+        # off = the colour-only blend backward drops that moment
+        self.want_viewspace_grad = densify is not None
         self.iteration = 0
         self.densify_state = None
         self.densify_gen = None
@@ -365,7 +368,7 @@ class Refiner:
         else:
             a.lambda_dssim, a.loss_scratch = 0.0, None
         a.out_images, a.radii = imgs.data_ptr(), radii.data_ptr()
-        a.dL_dmean2D, a.loss_out = self._fused["m2d"].data_ptr(), self._fused["loss"].data_ptr()
+        a.dL_dmean2D, a.loss_out = (self._fused["m2d"].data_ptr() if self.want_viewspace_grad else None), self._fused["loss"].data_ptr()
         rq = 1 if getattr(self, "require_geometry", True) else 0      # the reference's loop always renders coord / depth / normal
         a.require_coord, a.require_depth = rq, rq
         a.clamp_grads = 15.0 if getattr(self, "clamp", False) else 0.0
@@ -375,7 +378,7 @@ class Refiner:
         if not grads_only:
             p.step_count += 1
         self.last_num_rendered = nr
-        return dict(images_pred=imgs[0:3], radii=radii, visibility_filter=None, viewspace_points=self._fused["m2d"],
+        return dict(images_pred=imgs[0:3], radii=radii, visibility_filter=None, viewspace_points=self._fused["m2d"] if self.want_viewspace_grad else None,
                     alpha=imgs[11:12], depth_pred=imgs[9:10], normal=imgs[12:15], loss=self._fused["loss"])
 
     def start_frame(self):

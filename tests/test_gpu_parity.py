@@ -552,6 +552,7 @@ def test_fused_refine_step_equals_unfused_step(dev):
             # both start every step from the same state: Adam turns rounding-level gradient differences (float-atomic order) of
             # near-zero gradients into +-lr steps, so free-running trajectories drift apart by design
             pa.flat.copy_(pb.flat); pa.exp_avg.copy_(pb.exp_avg); pa.exp_avg_sq.copy_(pb.exp_avg_sq)
+            ra.want_viewspace_grad = it % 2 == 0            # odd steps: the blend-backward instance without the |gradient| moment
             pka = ra.step(view=v)
             if it == 0:
                 assert L.igs_rast_get_slab_hint() > 64
@@ -564,8 +565,11 @@ def test_fused_refine_step_equals_unfused_step(dev):
             #  can flip a hard alpha threshold on a handful of pixels)
             dimg = np.abs(pka["images_pred"].cpu().numpy() - pkb["images_pred"].cpu().numpy())
             assert (dimg > 2e-6).mean() < 2e-4 and dimg.max() < 1e-2, ((dimg > 2e-6).mean(), dimg.max())
-            r = rel(pka["viewspace_points"].cpu().numpy(), pkb["viewspace_points"].cpu().numpy())
-            assert np.quantile(r, 0.99) < 1e-3 and np.median(r) < 1e-5, (np.quantile(r, 0.99), np.median(r))   # saturated scene: 1/T_final noise
+            if ra.want_viewspace_grad:
+                r = rel(pka["viewspace_points"].cpu().numpy(), pkb["viewspace_points"].cpu().numpy())
+                assert np.quantile(r, 0.99) < 1e-3 and np.median(r) < 1e-5, (np.quantile(r, 0.99), np.median(r))   # saturated scene: 1/T_final noise
+            else:
+                assert pka["viewspace_points"] is None
             for name, x, y in (("param", pa.flat, pb.flat), ("exp_avg", pa.exp_avg, pb.exp_avg), ("exp_avg_sq", pa.exp_avg_sq, pb.exp_avg_sq)):
                 x, y = x.cpu().numpy(), y.cpu().numpy()
                 if name == "param":
