@@ -241,7 +241,8 @@ typedef struct igs_refine_step_args {
     void* loss_scratch;                       /* lambda_dssim > 0 or lambda_depth_normal > 0: igs_refine_loss_scratch_bytes(width, height) bytes */
     float* out_images;                        /* [15][H][W]: color 3 | coord 3 | mcoord 3 | depth 1 | mdepth 1 | alpha 1 | normal 3 */
     int* radii;                               /* [P] */
-    float* dL_dmean2D;                        /* [P][3] view-space gradient (densification statistic) or NULL */
+    float* dL_dmean2D;                        /* [P][3] view-space gradient (densification statistic) or NULL = not wanted: the
+                                                 blend backward then leaves out the |gradient| sum nothing else reads */
     float* loss_out;                          /* device, 1 float: the loss value, or NULL */
     int require_coord, require_depth;
     float clamp_grads;                        /* > 0: the rasterizer's gradients w.r.t. means3D / sh / opacities / scales / rotations are clamped to
