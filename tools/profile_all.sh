@@ -1,7 +1,7 @@
 set -e
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/prof_r01f
+O=$R/gpurun_out/prof_r01g
 rm -rf $O && mkdir -p $O
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $R/bench.py --steps 50 --warmup 10 --cpu-views 0 > $O/bench_under_rocprof.log 2>&1
 echo stats done
