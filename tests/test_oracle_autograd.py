@@ -166,3 +166,28 @@ def test_float32_backward_close_to_autograd_in_bulk():
     for k in g_auto:
         r = _rel(g_auto[k], g_c[k])
         assert (r > 1e-3).mean() < 0.05 and r.max() < 0.2, (k, r.max(), (r > 1e-3).mean())
+
+
+def test_sum_rounding_flags_are_small_perturbations_on_a_benign_scene():
+    """Flags 2 (per-Gaussian sums kept in float, like the reference's atomicAdd) and 4 (finished sums scaled by 1 + 2e-6 u) are
+    the conditioning probes of tests/test_gpu_fuzz.py: on a well-conditioned scene they move the blend sums by rounding-level
+    amounts only, different samples differ, and flag 0 is untouched by having used them."""
+    co.set_precision("float32")
+    raw, cam = _scene(800, 64, torch.float32)
+    bg = torch.tensor([0.2, 0.4, 0.6])
+    grads = _grads(64, np.float32)
+    try:
+        co.set_flags(0); base = _run_c(raw, cam, bg, grads)[3]
+        co.set_flags(2); facc = _run_c(raw, cam, bg, grads)[3]
+        co.set_flags(4); j0 = _run_c(raw, cam, bg, grads)[3]
+        co.set_flags(4 + 256); j1 = _run_c(raw, cam, bg, grads)[3]
+        co.set_flags(0); again = _run_c(raw, cam, bg, grads)[3]
+    finally:
+        co.set_flags(0)
+    for k in ("means2D", "colors", "opacity"):                    # the sums themselves (no per-Gaussian chain behind them)
+        scale = np.abs(base[k]).max()
+        assert np.array_equal(base[k], again[k]), k
+        for other in (facc, j0, j1):
+            d = np.abs(other[k] - base[k]).max()
+            assert 0 < d < 2e-5 * scale, (k, d, scale)
+        assert not np.array_equal(j0[k], j1[k]), k
