@@ -60,7 +60,9 @@ def random_modes(seed, P):
     colors = torch.rand(P, 3, generator=gen) if rng.random() < 0.15 else None
     use_cov = rng.random() < 0.15
     scale_modifier = float(rng.choice([1.0, 1.0, 1.0, 0.6, 1.7]))
-    return colors, use_cov, scale_modifier
+    short_sh = rng.random() < 0.25          # only the (deg+1)^2 coefficients the active degree needs (M < 16)
+    debug = rng.random() < 0.5              # debug = synchronise and check after every launch (auxiliary.h:404-411); off = as in production
+    return colors, use_cov, scale_modifier, short_sh, debug
 
 
 def oracle_gradients_f64(a, cam, bg, req, deg, ks, grads, colors=None, cov=None, scale_modifier=1.0):
@@ -88,18 +90,20 @@ def test_random_scene_matches_oracle(dev, seed):
     raw, cam, bg, req, deg, ks = random_case(seed)
     a = activate(raw)
     P = a["means3D"].shape[0]
-    colors, use_cov, sm = random_modes(seed, P)
+    colors, use_cov, sm, short_sh, debug = random_modes(seed, P)
+    if short_sh:
+        a["shs"] = a["shs"][:, :(deg + 1) ** 2].contiguous()
     cov = None
     if use_cov and P:           # the covariance the scale / rotation path would build (cov3D of the oracle's own state), handed in precomputed
         _, _, st0 = oracle_forward(a, cam, bg, req, deg=deg, kernel_size=ks, scale_modifier=sm)
         cov = torch.from_numpy(st0.intermediates()["cov3D"].copy())
     kw = dict(deg=deg, kernel_size=ks, colors=colors, cov=cov, scale_modifier=sm)
     okw = dict(deg=deg, kernel_size=ks, colors=None if colors is None else colors.numpy(), cov=None if cov is None else cov.numpy(), scale_modifier=sm)
-    out, ad, mats = hip_forward(a, cam, bg, dev, req, **kw)
+    out, ad, mats = hip_forward(a, cam, bg, dev, req, debug=debug, **kw)
     nr_o, oo, st = oracle_forward(a, cam, bg, req, **okw)
     nr, radii = out[0], out[8]
-    print("fuzz seed %d: P %d, %dx%d, req %s, deg %d, kernel_size %.1f, colours %s, cov %s, scale_modifier %.1f, num_rendered %d" % (
-        seed, P, cam.width, cam.height, req, deg, ks, colors is not None, cov is not None, sm, nr_o))
+    print("fuzz seed %d: P %d, %dx%d, req %s, deg %d, kernel_size %.1f, colours %s, cov %s, scale_modifier %.1f, M %d, debug %s, num_rendered %d" % (
+        seed, P, cam.width, cam.height, req, deg, ks, colors is not None, cov is not None, sm, a["shs"].shape[1], debug, nr_o))
     assert nr == nr_o, (nr, nr_o)
     np.testing.assert_array_equal(radii.cpu().numpy(), oo["radii"])
     if P and nr:
@@ -136,14 +140,14 @@ def test_random_scene_matches_oracle(dev, seed):
         # the oracle itself lands on different ones of them on two x86 hosts).  Sums of a splat that covers the whole image also
         # cancel heavily (net = 1e-3 of the sum of magnitudes), so a float accumulation is only good to 1e-3 there.  Certificate:
         # the oracle with its per-Gaussian sums kept in float like the reference's atomics (flag 2; default: double, rounded
-        # once) and every finished sum scaled by 1 + 2e-6 u (flag 4, 24 samples of u: the result jumps between plateaus) moves
+        # once) and every finished sum scaled by 1 + 2e-6 u (flag 4, 48 samples of u: the result jumps between plateaus) moves
         # such a Gaussian's gradient by `e_acc`; the HIP result has to stay within a small multiple of that + the oracle's own
         # distance from a float64 evaluation everywhere, and at most 2 % of the Gaussians may need the allowance.
         from oracle import c_oracle as co
         g64 = oracle_gradients_f64(a, cam, bg, req, deg, ks, grads, colors, cov, sm)
         shifts = {n: np.zeros(P) for n in GNAMES}
         try:
-            for sample in range(24):        # the gradient of such a Gaussian jumps between a few plateaus: sample the jitter
+            for sample in range(48):        # the gradient of such a Gaussian jumps between a few plateaus: sample the jitter
                 co.set_flags(2 + 4 + 256 * sample)
                 gj = oracle_backward(st, oo, a, cam, bg, grads, **obk)
                 for n in GNAMES:
