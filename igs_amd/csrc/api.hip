@@ -562,6 +562,7 @@ extern "C" int igs_refine_step(const igs_refine_step_args* a)
     f.lr_xyz = (float)(a->lr_xyz / bc1); f.lr_rot = (float)(a->lr_rot / bc1); f.lr_sh = (float)(a->lr_sh / bc1);
     f.lr_opacity = (float)(a->lr_opacity / bc1); f.lr_scale = (float)(a->lr_scale / bc1);
     f.clamp = a->clamp_grads;
+    f.color_out = a->color_grad_out;
     f.b1 = a->beta1; f.b2 = a->beta2; f.eps = a->eps; f.inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
     const float inv_n = 1.0f / (float)(3 * HW);
     const bool dssim = a->lambda_dssim > 0.f;
@@ -671,5 +672,16 @@ extern "C" int igs_rast_debug_dump(void* stream, int P, int R, int width, int he
                                          point_list, (uint32_t)(R > 0 ? R : 0)), "dump lists");
         if (n_contrib) HIP_TRY(hipMemcpyAsync(n_contrib, i + IL.n_contrib, HW * 8, hipMemcpyDeviceToDevice, s), "dump n_contrib");
     }
+    return 0;
+}
+
+extern "C" int igs_sh_grad_from_view_colors(void* stream, int P, int D, int M, int n_views, const float* means3D, const float* campos,
+                                            const float* color_grads, float clamp_grads, float* dL_dsh)
+{
+    if (P < 0 || M < 0 || M > 16 || D < 0 || D > 3 || n_views < 0 || n_views > IGS_MAX_EXCHANGE_VIEWS)
+        return fail(IGS_RAST_E_INVALID, "igs_sh_grad_from_view_colors: bad sizes (at most 64 views)");
+    if (P == 0 || M == 0) return 0;
+    if (!means3D || !dL_dsh || (n_views > 0 && (!campos || !color_grads))) return fail(IGS_RAST_E_INVALID, "igs_sh_grad_from_view_colors: NULL pointer");
+    HIP_TRY(launch_sh_grad_views((hipStream_t)stream, P, D, M, n_views, means3D, campos, color_grads, clamp_grads, dL_dsh), "sh_grad_views launch");
     return 0;
 }

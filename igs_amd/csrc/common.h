@@ -188,8 +188,13 @@ struct RefineFuse {
     const float* loss_shards; const float* loss_shards2; const float* loss_shards3; float* loss_out;
     float loss_scale, loss_scale2, loss_scale3, loss_bias;
     int prezeroed;                                                         // the accumulators were zero-filled by the forward
+    float* color_out = nullptr;                                            // [P][3] non-NULL: also write dL/d(colour) of this view (clamped channels and
+                                                                           // invisible Gaussians zero): what the N > 1 exchange gathers instead of dL/dSH
 };
 hipError_t launch_geom_bwd_adam(hipStream_t s, const GeomBwdArgs& a, const RefineFuse& f);
+#define IGS_MAX_EXCHANGE_VIEWS 64
+hipError_t launch_sh_grad_views(hipStream_t s, int P, int D, int M, int V, const float* means3D, const float* campos_host, const float* gc,
+                                float clamp, float* dsh_out);
 hipError_t launch_depth_normal(hipStream_t s, int W, int H, float fx, float fy, const float* depth, const float* mdepth, const float* normal,
                                float weight, float depth_ratio, float* g_depth, float* g_mdepth, float* g_normal, float* loss_shards);
 // 0.8 L1 + 0.2 (1 - SSIM)-style loss, forward + backward (loss_ops.hip); scratch: igs_ssim_l1_scratch_bytes

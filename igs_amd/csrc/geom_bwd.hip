@@ -72,6 +72,76 @@ __device__ __forceinline__ float3 sh_backward(int deg, int M, const float* __res
     return dnormvdv(dir_orig, dL_ddir);
 }
 
+// N > 1 exchange: dL/dSH of a step = sum over the views of basis(direction_v) x dL/dcolour_v.  The ranks
+// gather the 3-float colour gradients of every view (12 bytes per Gaussian and view) instead of all-reducing the 48-float SH
+// gradients, and every rank rebuilds the sum here, views in rank order -- the same bits everywhere.  The basis expressions
+// and the order of operations are those of sh_backward above (W(k, b): b * g, then clamp for the clamp variant, then the sum).
+struct ShViewCams { float pos[3 * IGS_MAX_EXCHANGE_VIEWS]; };
+__global__ void __launch_bounds__(128)
+sh_grad_views_kernel(int P, int D, int M, int V, const float* __restrict__ means3D, const ShViewCams cams,
+                     const float* __restrict__ gc, float clamp, float* __restrict__ dsh_out)
+{
+    const float* campos = cams.pos;
+    const int idx = blockIdx.x * 128 + threadIdx.x;
+    if (idx >= P) return;
+    float acc[48];
+#pragma unroll
+    for (int k = 0; k < 48; k++) acc[k] = 0.f;
+    const float3 mean = make_float3(means3D[3 * (size_t)idx], means3D[3 * (size_t)idx + 1], means3D[3 * (size_t)idx + 2]);
+    for (int v = 0; v < V; v++) {
+        const float* gp = gc + ((size_t)v * P + idx) * 3;
+        const float3 g = make_float3(gp[0], gp[1], gp[2]);
+        if (g.x == 0.f && g.y == 0.f && g.z == 0.f) continue;          // not seen by this view: exact zeros
+        const float3 dir = mean - make_float3(campos[3 * v], campos[3 * v + 1], campos[3 * v + 2]);
+        const float len = sqrtf(dot3(dir, dir));
+        const float x = dir.x / len, y = dir.y / len, z = dir.z / len;
+        float b[16];
+#pragma unroll
+        for (int k = 0; k < 16; k++) b[k] = 0.f;
+        b[0] = BSH_C0;
+        if (D > 0) {
+            b[1] = -BSH_C1 * y; b[2] = BSH_C1 * z; b[3] = -BSH_C1 * x;
+            if (D > 1) {
+                const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+                b[4] = BSH_C2[0] * xy; b[5] = BSH_C2[1] * yz; b[6] = BSH_C2[2] * (2.f * zz - xx - yy); b[7] = BSH_C2[3] * xz;
+                b[8] = BSH_C2[4] * (xx - yy);
+                if (D > 2) {
+                    b[9] = BSH_C3[0] * y * (3.f * xx - yy); b[10] = BSH_C3[1] * xy * z; b[11] = BSH_C3[2] * y * (4.f * zz - xx - yy);
+                    b[12] = BSH_C3[3] * z * (2.f * zz - 3.f * xx - 3.f * yy); b[13] = BSH_C3[4] * x * (4.f * zz - xx - yy);
+                    b[14] = BSH_C3[5] * z * (xx - yy); b[15] = BSH_C3[6] * x * (xx - 3.f * yy);
+                }
+            }
+        }
+        const int used = (D + 1) * (D + 1);
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            if (k < used && k < M) {
+                float t0 = b[k] * g.x, t1 = b[k] * g.y, t2 = b[k] * g.z;
+                if (clamp > 0.f) { t0 = fminf(fmaxf(t0, -clamp), clamp); t1 = fminf(fmaxf(t1, -clamp), clamp); t2 = fminf(fmaxf(t2, -clamp), clamp); }
+                acc[3 * k] += t0; acc[3 * k + 1] += t1; acc[3 * k + 2] += t2;
+            }
+        }
+    }
+    float* dst = dsh_out + (size_t)idx * M * 3;
+    if (M == 16 && (((uintptr_t)dsh_out) & 15) == 0) {
+#pragma unroll
+        for (int k = 0; k < 12; k++) ((float4*)dst)[k] = make_float4(acc[4 * k], acc[4 * k + 1], acc[4 * k + 2], acc[4 * k + 3]);
+        return;
+    }
+#pragma unroll
+    for (int k = 0; k < 16; k++)
+        if (k < M) { dst[3 * k] = acc[3 * k]; dst[3 * k + 1] = acc[3 * k + 1]; dst[3 * k + 2] = acc[3 * k + 2]; }
+}
+
+hipError_t launch_sh_grad_views(hipStream_t s, int P, int D, int M, int V, const float* means3D, const float* campos_host, const float* gc,
+                                float clamp, float* dsh_out)
+{
+    ShViewCams cams;                                  // camera centres travel in the kernel arguments: no device buffer, no copy
+    for (int i = 0; i < 3 * V; i++) cams.pos[i] = campos_host[i];
+    hipLaunchKernelGGL(sh_grad_views_kernel, dim3((P + 127) / 128), dim3(128), 0, s, P, D, M, V, means3D, cams, gc, clamp, dsh_out);
+    return hipGetLastError();
+}
+
 struct GBArgs { GeomBwdArgs a; RefineFuse f; };
 
 #ifndef GEOM_WAVES_PER_EU
@@ -358,6 +428,13 @@ geom_bwd_kernel(const GBArgs args)
             const float3 dm = sh_backward(a.D, a.M, a.shs + (size_t)idx * a.M * 3, dir_orig, clamped, o_color, dsh);
             o_mean = o_mean + dm;
             sh_written = true;
+            if constexpr (FUSED) {
+                if (fz.color_out) {
+                    fz.color_out[3 * (size_t)idx] = (clamped & 1u) ? 0.f : o_color.x;
+                    fz.color_out[3 * (size_t)idx + 1] = (clamped & 2u) ? 0.f : o_color.y;
+                    fz.color_out[3 * (size_t)idx + 2] = (clamped & 4u) ? 0.f : o_color.z;
+                }
+            }
         }
         if (a.scales) {       // computeCov3D backward (backward.cu:492-555)
             float3 sc = make_float3(a.scales[3 * idx], a.scales[3 * idx + 1], a.scales[3 * idx + 2]);
@@ -392,6 +469,11 @@ geom_bwd_kernel(const GBArgs args)
             o_rot.z = 2 * x * (X_(1, 0) + X_(0, 1)) + 2 * r * (X_(2, 0) - X_(0, 2)) + 2 * z * (X_(1, 2) + X_(2, 1)) - 4 * y * (X_(2, 2) + X_(0, 0));
             o_rot.w = 2 * r * (X_(0, 1) - X_(1, 0)) + 2 * x * (X_(2, 0) + X_(0, 2)) + 2 * y * (X_(1, 2) + X_(2, 1)) - 4 * z * (X_(1, 1) + X_(0, 0));
 #undef X_
+        }
+    }
+    if constexpr (FUSED) {
+        if (active && fz.color_out && !sh_written) {
+            fz.color_out[3 * (size_t)idx] = 0.f; fz.color_out[3 * (size_t)idx + 1] = 0.f; fz.color_out[3 * (size_t)idx + 2] = 0.f;
         }
     }
     if (active) {
@@ -559,6 +641,9 @@ geom_bwd_kernel(const GBArgs args)
             small_group(fz.off_opacity, 1, 7, fz.lr_opacity);
             small_group(fz.off_scale, 3, 8, fz.lr_scale);
         }
+        // N > 1 colour exchange: the SH gradient of the step is rebuilt from the gathered colour gradients, this view's is not needed
+        const bool skip_sh = FUSED && fz.grad_out && fz.color_out;
+        if (!skip_sh) {
         const int total = ng * F;
         float* dst = FUSED ? fz.param + fz.off_sh + (size_t)g0 * F : a.dL_dsh + (size_t)g0 * F;
         float* dst_m = FUSED ? fz.exp_avg + fz.off_sh + (size_t)g0 * F : nullptr;
@@ -607,6 +692,7 @@ geom_bwd_kernel(const GBArgs args)
                 if (k >= F) { k -= F; g++; }
             }
         }
+        }      // !skip_sh
         }      // !fast_done
     }
     if (grp + (int)gridDim.x < ngroups) __syncthreads();          // the LDS rows are reused by the next group

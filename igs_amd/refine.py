@@ -23,7 +23,8 @@ from . import _cabi
 from . import rasterizer as _rast
 from .rasterizer import GaussianRasterizationSettings, GaussianRasterizer
 
-GROUPS = (("xyz", 3), ("rotation", 4), ("shs", 48), ("opacity", 1), ("scaling", 3))
+# the 11 "small" floats first, SH last: the multi-GPU exchange reduces the small groups as ONE contiguous range
+GROUPS = (("xyz", 3), ("rotation", 4), ("opacity", 1), ("scaling", 3), ("shs", 48))
 DEFAULT_LRS = dict(xyz=0.0016, rotation=0.01, shs=0.0025, opacity=0.05, scaling=0.005)      # configs/demo.yaml:64-69
 
 
@@ -255,6 +256,9 @@ class Refiner:
         # fused step: also return dL/d(screen-space mean) with its absolute-gradient column (what the densification statistics read);
         # off = the colour-only blend backward drops that moment
         self.want_viewspace_grad = densify is not None
+        # N > 1: "colors" = gather the per-view colour gradients and rebuild dL/dSH locally (_colour_exchange_step);
+        # "gradients" = one all-reduce of the flat gradient
+        self.exchange = "colors"
         self.iteration = 0
         self.densify_state = None
         self.densify_gen = None
@@ -268,6 +272,7 @@ class Refiner:
             if not self.order:
                 self.order = torch.randperm(len(self.cams), generator=self.gen).tolist()
             picks.append(self.order.pop())
+        self.last_picks = picks          # the views of every rank this step (same permutation everywhere)
         return picks[self.rank]
 
     def _native_step(self, cam, gt, defer=True):
@@ -326,7 +331,7 @@ class Refiner:
         return dict(images_pred=color, radii=radii, visibility_filter=None, viewspace_points=outs["means2D"], alpha=alpha,
                     depth_pred=depth, normal=normal)
 
-    def _fused_step(self, cam, gt, grads_only=False):
+    def _fused_step(self, cam, gt, grads_only=False, color_out=None):
         """Single-GPU step entirely inside the library: `igs_refine_step` (include/igs_rast.h) -- activations, render, L1,
         backward and the Adam update in 7 launches; no gradient array is materialised."""
         import ctypes as C
@@ -372,6 +377,7 @@ class Refiner:
         rq = 1 if getattr(self, "require_geometry", True) else 0      # the reference's loop always renders coord / depth / normal
         a.require_coord, a.require_depth = rq, rq
         a.clamp_grads = 15.0 if getattr(self, "clamp", False) else 0.0
+        a.color_grad_out = color_out.data_ptr() if color_out is not None else None
         with torch.cuda.device(dev):
             nr = L.igs_refine_step(C.byref(a))
         _rast._check(nr, "igs_refine_step")
@@ -415,8 +421,45 @@ class Refiner:
         self.adam_fn()
         return pkg
 
+    def _colour_exchange_step(self, cam, gt, picks):
+        """N > 1: the step's gradient with 3.4x fewer bytes on the wire than an all-reduce of the flat buffer.  dL/dSH (48 of the 59
+        floats per Gaussian) is linear in the per-view colour gradient: sum_v basis(dir_v) x dL/dcolour_v.  So the ranks all-gather
+        the [P,3] colour gradients (12 B per Gaussian and view), every rank rebuilds the SH gradient of the whole step itself
+        (`igs_sh_grad_from_view_colors`, views in rank order: identical bits everywhere), and only the 11 small-group floats go
+        through all-reduces.  At N = 8, 200k Gaussians: 19 MB gathered + 8.8 MB reduced instead of 47 MB reduced."""
+        import torch.distributed as dist
+        p = self.params
+        L = _cabi.lib()
+        P, N, dev = p.P, self.world_size, p.device
+        if getattr(self, "_gc", None) is None or self._gc.shape[1] != P:
+            self._gc = torch.zeros((N, P, 3), dtype=torch.float32, device=dev)
+            self._gc_mine = torch.zeros((P, 3), dtype=torch.float32, device=dev)
+            self._campos_host = {}
+        pkg = self._fused_step(cam, gt, grads_only=True, color_out=self._gc_mine)
+        if dist.get_backend() == "nccl":
+            dist.all_gather_into_tensor(self._gc.view(-1), self._gc_mine.view(-1))      # RCCL: straight into the [N,P,3] buffer
+        else:
+            dist.all_gather(list(self._gc.unbind(0)), self._gc_mine)
+        import ctypes as C
+        for v in picks:
+            if v not in self._campos_host:          # (one device read per camera, the first time it is used)
+                self._campos_host[v] = [float(x) for x in self.cams[v].camera_center.reshape(3).tolist()]
+        campos = (C.c_float * (3 * N))(*[x for v in picks for x in self._campos_host[v]])
+        (sh0, shn) = p.spans["shs"]
+        rc = L.igs_sh_grad_from_view_colors(torch.cuda.current_stream(dev).cuda_stream, P, 3, 16, N, p.flat.data_ptr() + 4 * p.spans["xyz"][0],
+                                            C.cast(campos, C.c_void_p), self._gc.data_ptr(), 15.0 if getattr(self, "clamp", False) else 0.0,
+                                            p.grad.data_ptr() + 4 * sh0)
+        _rast._check(rc, "igs_sh_grad_from_view_colors")
+        if sh0 > 0:
+            dist.all_reduce(p.grad[:sh0], op=dist.ReduceOp.SUM)             # xyz | rotation | opacity | scaling: 11 floats per Gaussian
+        if sh0 + shn < p.grad.numel():
+            dist.all_reduce(p.grad[sh0 + shn:], op=dist.ReduceOp.SUM)
+        self.adam_fn()
+        return pkg
+
     def step(self, view=None):
         p = self.params
+        explicit_view = view
         if view is None:
             view = self._next_view()
         cam, gt = self.cams[view], self.gt[view]
@@ -437,6 +480,9 @@ class Refiner:
             return self._fused_step(cam, gt)
         if native_ok:
             # N > 1 (or an injected optimiser): the same fused launches, ending in the flat gradient instead of the update
+            picks = getattr(self, "last_picks", None) if explicit_view is None else None
+            if self.world_size > 1 and self.fused and self.exchange == "colors" and picks is not None:
+                return self._colour_exchange_step(cam, gt, picks)
             pkg = self._fused_step(cam, gt, grads_only=True) if self.fused else self._native_step(cam, gt)
             if self.world_size > 1:
                 import torch.distributed as dist

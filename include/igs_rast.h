@@ -247,8 +247,19 @@ typedef struct igs_refine_step_args {
     int require_coord, require_depth;
     float clamp_grads;                        /* > 0: the rasterizer's gradients w.r.t. means3D / sh / opacities / scales / rotations are clamped to
                                                  +-clamp_grads before they go on (diff_gaussian_rasterization_rade_clamp, 15); 0: off */
+    float* color_grad_out;                    /* [P][3] or NULL: dL/d(colour) of this view per Gaussian (clamped channels and unseen Gaussians
+                                                 zero) -- what the ranks of a multi-GPU step gather instead of all-reducing dL/dSH */
 } igs_refine_step_args;
 int igs_refine_step(const igs_refine_step_args* args);
+
+/* Multi-GPU refine step (extension; views are sharded over the ranks): dL/dSH of the step = sum over its views of
+ * basis(direction_v) x dL/dcolour_v (backward.cu:21-140, the W(k, b) rows of the SH backward).  Every rank all-gathers the
+ * 3-float colour gradients of all views (`color_grad_out` of igs_refine_step: 12 bytes per Gaussian and view instead of a
+ * 192-byte SH gradient in an all-reduce) and rebuilds the sum itself, views in the order given -- identical bits on every rank.
+ *   campos [n_views][3] in HOST memory (read before the call returns; n_views <= 64), color_grads [n_views][P][3] and means3D on the
+ *   device, dL_dsh [P][M][3] (overwritten), clamp_grads as in igs_refine_step. */
+int igs_sh_grad_from_view_colors(void* stream, int P, int D, int M, int n_views, const float* means3D, const float* campos,
+                                 const float* color_grads, float clamp_grads, float* dL_dsh);
 size_t igs_refine_loss_scratch_bytes(int width, int height);
 
 /* Photometric loss of the refine loop, forward + backward in two launches (igs/utils/loss_utils.py:17-63; infer_batch.py:300-306):

@@ -1049,3 +1049,66 @@ def test_fused_step_clamp_variant(dev):
     r = rel(ga, gb)
     assert np.quantile(r, 0.99) < 5e-3 and np.median(r) < 1e-5, (np.quantile(r, 0.99), np.median(r))
     assert (np.abs(ga - gc) > 1.0).sum() > 100                          # and the clamp changed many entries
+
+
+@pytest.mark.parametrize("clamp", [False, True])
+def test_colour_gradient_exchange_rebuilds_the_sh_gradient_of_all_views(dev, clamp):
+    """N > 1 step (Refiner._colour_exchange_step): the per-view colour gradients written by the fused step + `igs_sh_grad_from_
+    view_colors` must give the sum of the per-view SH gradients the all-reduce would have formed -- emulated here with three views
+    in one process (the collective itself is covered by the gloo tests and the driver's multi-GPU run)."""
+    from igs_amd.refine import GaussianParams, Refiner, render
+    from igs_amd.scenes import perturbed_copy
+    from igs_amd import _cabi
+    L = _cabi.lib()
+    raw, cams, bg = sear_steak_like_scene(P=20000, n_cams=3, width=320, height=240, focal=180.0)
+    cams = [c.to(dev) for c in cams]
+    bg = bg.to(dev)
+    gt_raw = {k: v.to(dev) for k, v in perturbed_copy(raw, sigma=0.05).items()}
+    with torch.no_grad():
+        gts = [render(activate(gt_raw), c, bg)["images_pred"].clone() for c in cams]
+    p = GaussianParams(raw, dev)
+    r = Refiner(p, cams, gts, bg, loss="l1_ssim", native=True, fused=True, world_size=3)      # (world_size only scales the loss by 1/3 here)
+    P = p.P
+    sh0, shn = p.spans["shs"]
+    if clamp:                                      # scale the loss until the +-15 clamp bites on some SH coefficients
+        r._fused_step(cams[0], gts[0], grads_only=True)
+        r.loss_scale = 60.0 / float(p.grad[sh0:sh0 + shn].abs().max())
+    r.clamp = clamp
+    gc = torch.zeros((3, P, 3), device=dev)
+    ref_sh = torch.zeros(shn, device=dev)
+    for v in range(3):
+        r._fused_step(cams[v], gts[v], grads_only=True)                      # reference: this view's full flat gradient
+        ref_sh += p.grad[sh0:sh0 + shn]
+        small = torch.cat((p.grad[:sh0], p.grad[sh0 + shn:])).clone()
+        p.grad[sh0:sh0 + shn].fill_(float("nan"))
+        r._fused_step(cams[v], gts[v], grads_only=True, color_out=gc[v])     # exchange mode: colour gradient out, SH span left alone
+        assert torch.isnan(p.grad[sh0:sh0 + shn]).all()
+        small2 = torch.cat((p.grad[:sh0], p.grad[sh0 + shn:]))
+        assert float((small2 - small).abs().max()) <= 2e-2 * float(small.abs().max())      # (float-atomic order between two runs, section 2 of DESIGN.md)
+    import ctypes as C
+    campos = (C.c_float * 9)(*[float(x) for c in cams for x in c.camera_center.reshape(3).tolist()])      # host memory
+    out = torch.full((shn,), float("nan"), device=dev)
+    rc = L.igs_sh_grad_from_view_colors(torch.cuda.current_stream(dev).cuda_stream, P, 3, 16, 3, p.flat.data_ptr() + 4 * p.spans["xyz"][0],
+                                        C.cast(campos, C.c_void_p), gc.data_ptr(), 15.0 if clamp else 0.0, out.data_ptr())
+    assert rc == 0
+    A, B = out.cpu().numpy(), ref_sh.cpu().numpy()
+    assert np.isfinite(A).all()
+    if clamp:
+        assert (np.abs(B) >= 14.9).any()           # the clamp is active in this scene
+    # same products, same clamp, same order of the three additions: equal up to the last bit of the additions
+    assert np.abs(A - B).max() <= 2e-6 * max(np.abs(B).max(), 1e-30), np.abs(A - B).max()
+    assert (gc.abs().sum(dim=2) > 0).float().mean() > 0.2 and (gc.abs().sum(dim=2) == 0).any()      # seen and unseen Gaussians both occur
+
+
+def test_two_rank_colour_exchange_equals_flat_allreduce(dev):
+    """Two ranks (gloo, both on this GPU) through Refiner.step(): the colour-gradient exchange and the flat all-reduce leave the
+    same gradient and parameters, and the replicas stay bit-identical (tools/check_exchange.py; with RCCL the driver's run)."""
+    import os, socket, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(root, "tools", "check_exchange.py"), "--backend", "gloo"],
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300, env=env, cwd=root)
+    assert r.returncode == 0 and "EXCHANGE_CHECK_OK" in r.stdout, r.stdout[-2000:]
