@@ -685,3 +685,17 @@ extern "C" int igs_sh_grad_from_view_colors(void* stream, int P, int D, int M, i
     HIP_TRY(launch_sh_grad_views((hipStream_t)stream, P, D, M, n_views, means3D, campos, color_grads, clamp_grads, dL_dsh), "sh_grad_views launch");
     return 0;
 }
+
+extern "C" int igs_adam_sh_from_view_colors(void* stream, int P, int D, int M, int n_views, const float* means3D, const float* campos,
+                                            const float* color_grads, float clamp_grads, float* param_sh, float* exp_avg_sh, float* exp_avg_sq_sh,
+                                            float lr, float beta1, float beta2, float eps, float bias_correction1, float bias_correction2_sqrt)
+{
+    if (P < 0 || M < 0 || M > 16 || D < 0 || D > 3 || n_views < 0 || n_views > IGS_MAX_EXCHANGE_VIEWS)
+        return fail(IGS_RAST_E_INVALID, "igs_adam_sh_from_view_colors: bad sizes (at most 64 views)");
+    if (P == 0 || M == 0) return 0;
+    if (!means3D || !param_sh || !exp_avg_sh || !exp_avg_sq_sh || (n_views > 0 && (!campos || !color_grads)))
+        return fail(IGS_RAST_E_INVALID, "igs_adam_sh_from_view_colors: NULL pointer");
+    HIP_TRY(launch_sh_adam_views((hipStream_t)stream, P, D, M, n_views, means3D, campos, color_grads, clamp_grads, param_sh, exp_avg_sh, exp_avg_sq_sh,
+                                 lr / bias_correction1, beta1, beta2, eps, 1.0f / bias_correction2_sqrt), "sh_adam_views launch");
+    return 0;
+}

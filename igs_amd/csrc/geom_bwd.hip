@@ -77,18 +77,22 @@ __device__ __forceinline__ float3 sh_backward(int deg, int M, const float* __res
 // gradients, and every rank rebuilds the sum here, views in rank order -- the same bits everywhere.  The basis expressions
 // and the order of operations are those of sh_backward above (W(k, b): b * g, then clamp for the clamp variant, then the sum).
 struct ShViewCams { float pos[3 * IGS_MAX_EXCHANGE_VIEWS]; };
+struct ShAdam { float *param, *exp_avg, *exp_avg_sq; float lr_over_bc1, b1, b2, eps, inv_sqrt_bc2; };     // SH spans ([P][M][3]) of the optimiser state
+template <bool ADAM>
 __global__ void __launch_bounds__(128)
 sh_grad_views_kernel(int P, int D, int M, int V, const float* __restrict__ means3D, const ShViewCams cams,
-                     const float* __restrict__ gc, float clamp, float* __restrict__ dsh_out)
+                     const float* __restrict__ gc, float clamp, float* __restrict__ dsh_out, const ShAdam ad)
 {
     const float* campos = cams.pos;
     const int idx = blockIdx.x * 128 + threadIdx.x;
-    if (idx >= P) return;
+    const bool live = idx < P;
+    if (!ADAM && !live) return;                       // (the ADAM variant has a workgroup barrier further down)
     float acc[48];
 #pragma unroll
     for (int k = 0; k < 48; k++) acc[k] = 0.f;
-    const float3 mean = make_float3(means3D[3 * (size_t)idx], means3D[3 * (size_t)idx + 1], means3D[3 * (size_t)idx + 2]);
-    for (int v = 0; v < V; v++) {
+    const size_t ci = live ? (size_t)idx : 0;
+    const float3 mean = make_float3(means3D[3 * ci], means3D[3 * ci + 1], means3D[3 * ci + 2]);
+    for (int v = 0; v < (live ? V : 0); v++) {
         const float* gp = gc + ((size_t)v * P + idx) * 3;
         const float3 g = make_float3(gp[0], gp[1], gp[2]);
         if (g.x == 0.f && g.y == 0.f && g.z == 0.f) continue;          // not seen by this view: exact zeros
@@ -122,6 +126,53 @@ sh_grad_views_kernel(int P, int D, int M, int V, const float* __restrict__ means
             }
         }
     }
+    if constexpr (ADAM) {
+        // the Adam update of the workgroup's 128 Gaussians right here (the rebuilt gradient never goes to HBM): rows through LDS
+        // (49-float padded), then one coalesced float4 sweep over the contiguous 128 x 3M span of param / exp_avg / exp_avg_sq
+        __shared__ float rows[128 * 49];
+        const int F = 3 * M;
+#pragma unroll
+        for (int k = 0; k < 48; k++)
+            if (k < F) rows[threadIdx.x * 49 + k] = acc[k];
+        __syncthreads();
+        const int g0 = blockIdx.x * 128, ng = min(128, P - g0);
+        const size_t base = (size_t)g0 * F;
+        const int total = ng * F;
+        const bool al = ((F & 3) == 0) && ((((uintptr_t)(ad.param + base)) | ((uintptr_t)(ad.exp_avg + base)) | ((uintptr_t)(ad.exp_avg_sq + base))) & 15) == 0;
+        const int total4 = al ? total >> 2 : 0;
+        float4* P4p = (float4*)(ad.param + base); float4* M4p = (float4*)(ad.exp_avg + base); float4* V4p = (float4*)(ad.exp_avg_sq + base);
+        for (int i0 = threadIdx.x; i0 < total4; i0 += 2 * 128) {
+            const int i1 = i0 + 128;
+            const bool two = i1 < total4;
+            float4 Pa = P4p[i0], Ma = M4p[i0], Va = V4p[i0], Pb, Mb, Vb;
+            if (two) { Pb = P4p[i1]; Mb = M4p[i1]; Vb = V4p[i1]; }
+            {
+                const int f = 4 * i0, g = f / F, k = f - g * F;
+                const float* sp = rows + g * 49 + k;
+                adam_update(Pa.x, Ma.x, Va.x, sp[0], ad.lr_over_bc1, ad.b1, ad.b2, ad.eps, ad.inv_sqrt_bc2);
+                adam_update(Pa.y, Ma.y, Va.y, sp[1], ad.lr_over_bc1, ad.b1, ad.b2, ad.eps, ad.inv_sqrt_bc2);
+                adam_update(Pa.z, Ma.z, Va.z, sp[2], ad.lr_over_bc1, ad.b1, ad.b2, ad.eps, ad.inv_sqrt_bc2);
+                adam_update(Pa.w, Ma.w, Va.w, sp[3], ad.lr_over_bc1, ad.b1, ad.b2, ad.eps, ad.inv_sqrt_bc2);
+                P4p[i0] = Pa; M4p[i0] = Ma; V4p[i0] = Va;
+            }
+            if (two) {
+                const int f = 4 * i1, g = f / F, k = f - g * F;
+                const float* sp = rows + g * 49 + k;
+                adam_update(Pb.x, Mb.x, Vb.x, sp[0], ad.lr_over_bc1, ad.b1, ad.b2, ad.eps, ad.inv_sqrt_bc2);
+                adam_update(Pb.y, Mb.y, Vb.y, sp[1], ad.lr_over_bc1, ad.b1, ad.b2, ad.eps, ad.inv_sqrt_bc2);
+                adam_update(Pb.z, Mb.z, Vb.z, sp[2], ad.lr_over_bc1, ad.b1, ad.b2, ad.eps, ad.inv_sqrt_bc2);
+                adam_update(Pb.w, Mb.w, Vb.w, sp[3], ad.lr_over_bc1, ad.b1, ad.b2, ad.eps, ad.inv_sqrt_bc2);
+                P4p[i1] = Pb; M4p[i1] = Mb; V4p[i1] = Vb;
+            }
+        }
+        for (int e = 4 * total4 + threadIdx.x; e < total; e += 128) {
+            const int g = e / F, k = e - g * F;
+            float pp = ad.param[base + e], mm = ad.exp_avg[base + e], vv = ad.exp_avg_sq[base + e];
+            adam_update(pp, mm, vv, rows[g * 49 + k], ad.lr_over_bc1, ad.b1, ad.b2, ad.eps, ad.inv_sqrt_bc2);
+            ad.param[base + e] = pp; ad.exp_avg[base + e] = mm; ad.exp_avg_sq[base + e] = vv;
+        }
+        return;
+    }
     float* dst = dsh_out + (size_t)idx * M * 3;
     if (M == 16 && (((uintptr_t)dsh_out) & 15) == 0) {
 #pragma unroll
@@ -138,7 +189,19 @@ hipError_t launch_sh_grad_views(hipStream_t s, int P, int D, int M, int V, const
 {
     ShViewCams cams;                                  // camera centres travel in the kernel arguments: no device buffer, no copy
     for (int i = 0; i < 3 * V; i++) cams.pos[i] = campos_host[i];
-    hipLaunchKernelGGL(sh_grad_views_kernel, dim3((P + 127) / 128), dim3(128), 0, s, P, D, M, V, means3D, cams, gc, clamp, dsh_out);
+    hipLaunchKernelGGL(sh_grad_views_kernel<false>, dim3((P + 127) / 128), dim3(128), 0, s, P, D, M, V, means3D, cams, gc, clamp, dsh_out, ShAdam());
+    return hipGetLastError();
+}
+
+hipError_t launch_sh_adam_views(hipStream_t s, int P, int D, int M, int V, const float* means3D, const float* campos_host, const float* gc,
+                                float clamp, float* param_sh, float* exp_avg_sh, float* exp_avg_sq_sh, float lr_over_bc1, float b1, float b2,
+                                float eps, float inv_sqrt_bc2)
+{
+    ShViewCams cams;
+    for (int i = 0; i < 3 * V; i++) cams.pos[i] = campos_host[i];
+    ShAdam ad; ad.param = param_sh; ad.exp_avg = exp_avg_sh; ad.exp_avg_sq = exp_avg_sq_sh;
+    ad.lr_over_bc1 = lr_over_bc1; ad.b1 = b1; ad.b2 = b2; ad.eps = eps; ad.inv_sqrt_bc2 = inv_sqrt_bc2;
+    hipLaunchKernelGGL(sh_grad_views_kernel<true>, dim3((P + 127) / 128), dim3(128), 0, s, P, D, M, V, means3D, cams, gc, clamp, (float*)nullptr, ad);
     return hipGetLastError();
 }
 

@@ -52,8 +52,9 @@ class GaussianParams:
         self.flat, self.exp_avg, self.exp_avg_sq = flat, exp_avg, exp_avg_sq
         self.grad = torch.zeros(flat.numel(), dtype=torch.float32, device=self.device)
         self.spans, self.leaves = {}, {}
-        if hasattr(self, "_adam_groups"):
-            del self._adam_groups
+        for key in ("_adam_groups", "_adam_groups_small"):
+            if hasattr(self, key):
+                delattr(self, key)
         o = 0
         for name, k in GROUPS:
             n = k * P
@@ -118,21 +119,24 @@ class GaussianParams:
     def zero_grad(self):
         self.grad.zero_()
 
-    def adam_step(self):
-        """torch.optim.Adam semantics, all parameter groups in one fused HIP launch."""
+    def adam_step(self, skip_sh=False):
+        """torch.optim.Adam semantics, all parameter groups in one fused HIP launch (`skip_sh`: every group but the SH
+        coefficients -- the multi-GPU exchange updates those itself, igs_adam_sh_from_view_colors)."""
         L = _cabi.lib()
         self.step_count += 1
         b1, b2 = self.betas
         bc1 = 1.0 - b1 ** self.step_count
         bc2s = math.sqrt(1.0 - b2 ** self.step_count)
         stream = torch.cuda.current_stream(self.device).cuda_stream
-        if not hasattr(self, "_adam_groups"):
+        key = "_adam_groups_small" if skip_sh else "_adam_groups"
+        if not hasattr(self, key):
             import ctypes as C
-            k = len(GROUPS)
-            self._adam_groups = ((C.c_size_t * k)(*[self.spans[n][0] for n, _ in GROUPS]),
-                                 (C.c_size_t * k)(*[self.spans[n][1] for n, _ in GROUPS]),
-                                 (C.c_float * k)(*[self.lrs[n] for n, _ in GROUPS]), k)
-        off, cnt, lrs, k = self._adam_groups
+            names = [n for n, _ in GROUPS if not (skip_sh and n == "shs")]
+            k = len(names)
+            setattr(self, key, ((C.c_size_t * k)(*[self.spans[n][0] for n in names]),
+                                (C.c_size_t * k)(*[self.spans[n][1] for n in names]),
+                                (C.c_float * k)(*[self.lrs[n] for n in names]), k))
+        off, cnt, lrs, k = getattr(self, key)
         rc = L.igs_adam_step_groups(stream, k, off, cnt, lrs, self.flat.data_ptr(), self.grad.data_ptr(), self.exp_avg.data_ptr(),
                                     self.exp_avg_sq.data_ptr(), b1, b2, self.eps, bc1, bc2s)
         if rc != 0:
@@ -446,8 +450,26 @@ class Refiner:
                 self._campos_host[v] = [float(x) for x in self.cams[v].camera_center.reshape(3).tolist()]
         campos = (C.c_float * (3 * N))(*[x for v in picks for x in self._campos_host[v]])
         (sh0, shn) = p.spans["shs"]
-        rc = L.igs_sh_grad_from_view_colors(torch.cuda.current_stream(dev).cuda_stream, P, 3, 16, N, p.flat.data_ptr() + 4 * p.spans["xyz"][0],
-                                            C.cast(campos, C.c_void_p), self._gc.data_ptr(), 15.0 if getattr(self, "clamp", False) else 0.0,
+        clamp = 15.0 if getattr(self, "clamp", False) else 0.0
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        if self.adam_fn == p.adam_step:
+            # the library's own optimiser: the SH update straight from the gathered colours (no SH gradient in HBM), the 11 small
+            # floats through the all-reduce and the grouped Adam launch
+            b1, b2 = p.betas
+            t = p.step_count + 1
+            rc = L.igs_adam_sh_from_view_colors(stream, P, 3, 16, N, p.flat.data_ptr() + 4 * p.spans["xyz"][0], C.cast(campos, C.c_void_p),
+                                                self._gc.data_ptr(), clamp, p.flat.data_ptr() + 4 * sh0, p.exp_avg.data_ptr() + 4 * sh0,
+                                                p.exp_avg_sq.data_ptr() + 4 * sh0, p.lrs["shs"], b1, b2, p.eps, 1.0 - b1 ** t,
+                                                math.sqrt(1.0 - b2 ** t))
+            _rast._check(rc, "igs_adam_sh_from_view_colors")
+            if sh0 > 0:
+                dist.all_reduce(p.grad[:sh0], op=dist.ReduceOp.SUM)
+            if sh0 + shn < p.grad.numel():
+                dist.all_reduce(p.grad[sh0 + shn:], op=dist.ReduceOp.SUM)
+            p.adam_step(skip_sh=True)
+            return pkg
+        rc = L.igs_sh_grad_from_view_colors(stream, P, 3, 16, N, p.flat.data_ptr() + 4 * p.spans["xyz"][0],
+                                            C.cast(campos, C.c_void_p), self._gc.data_ptr(), clamp,
                                             p.grad.data_ptr() + 4 * sh0)
         _rast._check(rc, "igs_sh_grad_from_view_colors")
         if sh0 > 0:

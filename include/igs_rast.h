@@ -260,6 +260,12 @@ int igs_refine_step(const igs_refine_step_args* args);
  *   device, dL_dsh [P][M][3] (overwritten), clamp_grads as in igs_refine_step. */
 int igs_sh_grad_from_view_colors(void* stream, int P, int D, int M, int n_views, const float* means3D, const float* campos,
                                  const float* color_grads, float clamp_grads, float* dL_dsh);
+/* The same sum applied directly as the Adam update of the SH coefficients (torch.optim.Adam semantics as igs_adam_step_groups:
+ * lr / bias_correction1, sqrt(v) / bias_correction2_sqrt + eps); param_sh / exp_avg_sh / exp_avg_sq_sh = the [P][M][3] SH spans of
+ * the optimiser state.  The rebuilt gradient is never written to memory. */
+int igs_adam_sh_from_view_colors(void* stream, int P, int D, int M, int n_views, const float* means3D, const float* campos,
+                                 const float* color_grads, float clamp_grads, float* param_sh, float* exp_avg_sh, float* exp_avg_sq_sh,
+                                 float lr, float beta1, float beta2, float eps, float bias_correction1, float bias_correction2_sqrt);
 size_t igs_refine_loss_scratch_bytes(int width, int height);
 
 /* Photometric loss of the refine loop, forward + backward in two launches (igs/utils/loss_utils.py:17-63; infer_batch.py:300-306):
