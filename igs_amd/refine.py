@@ -503,7 +503,7 @@ class Refiner:
         if native_ok:
             # N > 1 (or an injected optimiser): the same fused launches, ending in the flat gradient instead of the update
             picks = getattr(self, "last_picks", None) if explicit_view is None else None
-            if self.world_size > 1 and self.fused and self.exchange == "colors" and picks is not None:
+            if 1 < self.world_size <= 64 and self.fused and self.exchange == "colors" and picks is not None:      # (the library takes at most 64 views)
                 return self._colour_exchange_step(cam, gt, picks)
             pkg = self._fused_step(cam, gt, grads_only=True) if self.fused else self._native_step(cam, gt)
             if self.world_size > 1:
