@@ -527,7 +527,7 @@ extern "C" int igs_rast_backward(
 
 // ---------------------------------------------------------------------------------------------------------------------
 // One refine iteration on one view, single GPU (infer_batch.py:279-324 with the L1 loss): activations -> render -> L1 ->
-// backward -> Adam, 7 launches, no gradient array in HBM, no host wait before the last launch is enqueued.
+// backward -> Adam, 6 launches, no gradient array in HBM, no host wait before the last launch is enqueued.
 // ---------------------------------------------------------------------------------------------------------------------
 struct ScratchCapture { igs_rast_alloc_fn fn; void* user; char* last; };
 static char* capture_alloc(void* user, size_t n) { ScratchCapture* c = (ScratchCapture*)user; c->last = c->fn(c->user, n); return c->last; }

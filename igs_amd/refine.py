@@ -337,7 +337,7 @@ class Refiner:
 
     def _fused_step(self, cam, gt, grads_only=False, color_out=None):
         """Single-GPU step entirely inside the library: `igs_refine_step` (include/igs_rast.h) -- activations, render, L1,
-        backward and the Adam update in 7 launches; no gradient array is materialised."""
+        backward and the Adam update in 6 launches; no gradient array is materialised."""
         import ctypes as C
         p = self.params
         L = _cabi.lib()

@@ -212,8 +212,10 @@ int igs_adam_step_groups(void* stream, int ngroups, const size_t* offset, const 
  * Everything is enqueued on `stream` without a host wait; the gradients never reach HBM (the per-Gaussian backward kernel
  * applies the update itself).  `param` / `exp_avg` / `exp_avg_sq` are flat fp32 buffers holding the five groups at the given
  * float offsets: xyz [P][3], rotation [P][4] (raw quaternion), shs [P][M][3], opacity [P] (logit), scale [P][3] (log).
- * Multi-GPU runs need the gradients for the all-reduce: with `grad_out` set the same 6 launches end in the flat gradient
- * instead of the update (then all-reduce it and call igs_adam_step_groups).
+ * Multi-GPU runs need the gradients for the exchange: with `grad_out` set the same 6 launches end in the flat gradient
+ * instead of the update (then all-reduce it and call igs_adam_step_groups -- or, with `color_grad_out` set as well, gather the
+ * per-view colour gradients, all-reduce only the 11 small-group floats, and let igs_adam_sh_from_view_colors update the SH
+ * coefficients: the SH span of `grad_out` is then left untouched).
  * Returns num_rendered or a negative error code. */
 typedef struct igs_refine_step_args {
     void* stream;
