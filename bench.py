@@ -183,7 +183,9 @@ def main():
                                    "%d train cams @%dx%d, per step and rank one view: fwd + %s loss + bwd + Adam"
                                    % (P, args.cams, args.width, args.height, "L1" if args.loss == "l1" else "0.8*L1+0.2*(1-SSIM)"),
                        "points": P, "width": args.width, "height": args.height, "views": args.cams, "loss": args.loss,
-                       "parallelism": "views sharded over %d rank(s), RCCL all-gather of the per-view colour gradients + all-reduce of the 11 small-group gradients (DESIGN.md section 6)" % world},
+                       "parallelism": ("one GPU: the whole step inside igs_refine_step, no exchange" if world == 1 else
+                                       "views sharded over %d ranks, one view per rank and step; RCCL all-gather of the per-view colour "
+                                       "gradients + all-reduce of the 11 small-group gradients (DESIGN.md section 6)" % world)},
         }
         if stages and calls:
             R_avg = r_sum / calls
