@@ -70,7 +70,9 @@ def main():
         import time
         raw, cams, bg = sear_steak_like_scene(P=200000, n_cams=10, width=1352, height=1014)
         cams = [c.to(dev) for c in cams]; bg = bg.to(dev)
-        gts = [torch.rand(3, 1014, 1352, device=dev) for _ in cams]
+        gt_raw = {k: v.to(dev) for k, v in perturbed_copy(raw).items()}          # ground truth as in bench.py
+        with torch.no_grad():
+            gts = [render(activate(gt_raw), c, bg)["images_pred"].clone() for c in cams]
         for mode in ("gradients", "colors"):
             p = GaussianParams(raw, dev); p.spatial_sort()
             r = Refiner(p, cams, gts, bg, loss="l1", world_size=world, rank=rank, seed=3)
