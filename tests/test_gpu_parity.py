@@ -1098,6 +1098,25 @@ def test_colour_gradient_exchange_rebuilds_the_sh_gradient_of_all_views(dev, cla
     # same products, same clamp, same order of the three additions: equal up to the last bit of the additions
     assert np.abs(A - B).max() <= 2e-6 * max(np.abs(B).max(), 1e-30), np.abs(A - B).max()
     assert (gc.abs().sum(dim=2) > 0).float().mean() > 0.2 and (gc.abs().sum(dim=2) == 0).any()      # seen and unseen Gaussians both occur
+    # the same sum applied as the Adam update of the SH coefficients (igs_adam_sh_from_view_colors) = torch.optim.Adam's formula on `out`
+    import math
+    g = torch.Generator().manual_seed(3)
+    m0 = (torch.randn(shn, generator=g) * 1e-3).to(dev); v0 = (torch.rand(shn, generator=g) * 1e-6).to(dev)
+    p.exp_avg[sh0:sh0 + shn].copy_(m0); p.exp_avg_sq[sh0:sh0 + shn].copy_(v0)
+    w0 = p.flat[sh0:sh0 + shn].clone()
+    b1, b2, eps, lr, t = 0.9, 0.999, 1e-15, 2.5e-3, 7
+    bc1, bc2s = 1.0 - b1 ** t, math.sqrt(1.0 - b2 ** t)
+    rc = L.igs_adam_sh_from_view_colors(torch.cuda.current_stream(dev).cuda_stream, P, 3, 16, 3, p.flat.data_ptr() + 4 * p.spans["xyz"][0],
+                                        C.cast(campos, C.c_void_p), gc.data_ptr(), 15.0 if clamp else 0.0, p.flat.data_ptr() + 4 * sh0,
+                                        p.exp_avg.data_ptr() + 4 * sh0, p.exp_avg_sq.data_ptr() + 4 * sh0, lr, b1, b2, eps, bc1, bc2s)
+    assert rc == 0
+    omb1, omb2 = float(np.float32(1) - np.float32(b1)), float(np.float32(1) - np.float32(b2))      # the kernel forms 1 - beta in float
+    m1 = b1 * m0 + omb1 * out
+    v1 = b2 * v0 + omb2 * out * out
+    w1 = w0 - (lr / bc1) * m1 / (v1.sqrt() / bc2s + eps)
+    torch.testing.assert_close(p.exp_avg[sh0:sh0 + shn], m1, rtol=1e-5, atol=1e-6 * float(m1.abs().max()))
+    torch.testing.assert_close(p.exp_avg_sq[sh0:sh0 + shn], v1, rtol=1e-5, atol=1e-6 * float(v1.abs().max()))
+    torch.testing.assert_close(p.flat[sh0:sh0 + shn], w1, rtol=1e-5, atol=1e-6)
 
 
 def test_two_rank_colour_exchange_equals_flat_allreduce(dev):
