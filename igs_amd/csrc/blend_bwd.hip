@@ -38,7 +38,9 @@ blend_bwd_kernel(const BlendBwdArgs a)
     constexpr int NROWS = 9 + (ABS ? 1 : 0) + (COORD ? 9 : 0) + (DEPTH ? 3 : 0) + (NORMAL ? 3 : 0);   // live moments of this instance
     // floats per row of the per-wave transpose buffer: 16-byte aligned rows, row starts spread over all banks for the b128 reads
     // (16 rows x 4 banks), and rows r, r+1 -- which the compiler pairs into one ds_write2_b32 -- 36 banks apart instead of 4
-    constexpr int RED_STRIDE = NROWS <= 16 ? 100 : 68;
+    // ... for the colour-only instance; the instances with geometry (13..25 rows, 12 KB of staged records) are LDS-occupancy
+    // bound instead: <depth, normal> 38 KB -> 4 workgroups per CU with stride 100, 30 KB -> 5 with stride 68 (151 -> 140 us)
+    constexpr int RED_STRIDE = GEO ? 68 : 100;
     __shared__ __attribute__((aligned(16))) float red[4][NROWS * RED_STRIDE];
 
     uint32_t tile;
@@ -275,7 +277,9 @@ hipError_t launch_blend_bwd(hipStream_t s, const BlendBwdArgs& a, bool coord, bo
 #define LAUNCH(c, d, n) hipLaunchKernelGGL((blend_bwd_kernel<c, d, n>), grid, block, 0, s, a)
     if (C) { if (D) { if (N) LAUNCH(true, true, true); else LAUNCH(true, true, false); }
              else   { if (N) LAUNCH(true, false, true); else LAUNCH(true, false, false); } }
-    else   { if (D) { if (N) LAUNCH(false, true, true); else LAUNCH(false, true, false); }
+    else   { if (D) { if (N) { if (a.want_absgrad) LAUNCH(false, true, true);
+                               else hipLaunchKernelGGL((blend_bwd_kernel<false, true, true, false>), grid, block, 0, s, a); }
+                      else LAUNCH(false, true, false); }
              else   { if (N) LAUNCH(false, false, true);
                       else if (a.want_absgrad) LAUNCH(false, false, false);
                       else hipLaunchKernelGGL((blend_bwd_kernel<false, false, false, false>), grid, block, 0, s, a); } }
