@@ -40,7 +40,9 @@ class RefineStepArgs(C.Structure):
 EXPORTS = ["igs_rast_version", "igs_rast_last_error", "igs_rast_forward", "igs_rast_backward_workspace_bytes",
            "igs_rast_forward_async", "igs_rast_forward_finish", "igs_rast_set_slab_hint", "igs_rast_get_slab_hint", "igs_rast_backward", "igs_rast_mark_visible", "igs_rast_debug_dump",
            "igs_rast_profile_enable", "igs_rast_profile_read", "igs_adam_step", "igs_adam_step_groups", "igs_densify_stats", "igs_densify_remap", "igs_refine_step", "igs_refine_loss_scratch_bytes", "igs_ssim_l1_scratch_bytes", "igs_ssim_l1_loss_fwd_bwd", "igs_depth_normal_loss_fwd_bwd", "igs_l1_loss_fwd_bwd", "igs_activate_fwd", "igs_activate_bwd",
-           "igs_sh_grad_from_view_colors", "igs_adam_sh_from_view_colors"]
+           "igs_sh_grad_from_view_colors", "igs_adam_sh_from_view_colors", "igs_rast_last_backward_instance", "igs_refine_step_args_size"]
+
+VERSION = 2       # IGS_RAST_VERSION this binding was written against (include/igs_rast.h)
 
 STAGES = ["preprocess", "depth_sort", "scan", "emit", "tile_sort", "ranges", "blend_fwd", "memset", "blend_bwd", "geom_bwd"]
 
@@ -52,8 +54,13 @@ def lib():
     try:
         path = _build.build()
     except Exception as e:  # noqa: BLE001
-        if os.path.exists(_build.LIB):
-            path = _build.LIB          # stale but present (e.g. no hipcc on this box): use what travelled
+        # no hipcc on this box (or the build failed): the library that travelled with the tree is used only if it was built from
+        # exactly these sources -- a stale one with another igs_refine_step_args layout would corrupt memory instead of failing
+        if os.path.exists(_build.LIB) and not _build.needs_build():
+            path = _build.LIB
+        elif os.path.exists(_build.LIB):
+            raise RuntimeError("igs_amd: libigs_rast.so is present but was built from other sources (build.stamp does not match) "
+                               "and rebuilding it failed: %s" % e)
         else:
             raise RuntimeError("igs_amd: the HIP extension libigs_rast.so is missing and could not be built: %s" % e)
     # Load order matters: the library needs libamdhip64, and so does PyTorch, which ships its own copy.  Whichever is mapped
@@ -63,6 +70,14 @@ def lib():
     import torch  # noqa: F401
     L = C.CDLL(path)
     L.igs_rast_version.restype = _i
+    if L.igs_rast_version() != VERSION:
+        raise RuntimeError("igs_amd: libigs_rast.so reports C-ABI version %d, this binding needs %d" % (L.igs_rast_version(), VERSION))
+    L.igs_refine_step_args_size.restype = C.c_size_t
+    if L.igs_refine_step_args_size() != C.sizeof(RefineStepArgs):
+        raise RuntimeError("igs_amd: igs_refine_step_args is %d bytes in the library, %d in the binding"
+                           % (L.igs_refine_step_args_size(), C.sizeof(RefineStepArgs)))
+    L.igs_rast_last_backward_instance.restype = _i
+    L.igs_rast_last_backward_instance.argtypes = []
     L.igs_rast_last_error.restype = C.c_char_p
     L.igs_rast_forward.restype = _i
     L.igs_rast_forward.argtypes = ([_vp, ALLOC_FN, _vp, ALLOC_FN, _vp, ALLOC_FN, _vp, _i, _i, _i, _vp, _i, _i]
@@ -119,6 +134,14 @@ def lib():
         L.igs_adam_sh_from_view_colors.argtypes = [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _f, _vp, _vp, _vp, _f, _f, _f, _f, _f, _f]
     _LIB = L
     return L
+
+
+def last_backward_instance():
+    """{coord, depth, normal, absgrad} of the blend-backward instance the last backward on this thread launched, or None."""
+    b = lib().igs_rast_last_backward_instance()
+    if b < 0:
+        return None
+    return dict(coord=bool(b & 1), depth=bool(b & 2), normal=bool(b & 4), absgrad=bool(b & 8))
 
 
 def last_error():

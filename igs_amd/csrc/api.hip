@@ -7,6 +7,7 @@
 #include <stdio.h>
 #include <string.h>
 #include <stdlib.h>
+#include <time.h>
 
 static thread_local char g_err[512] = "";
 static int fail(int code, const char* what, hipError_t e = hipSuccess)
@@ -18,37 +19,61 @@ static int fail(int code, const char* what, hipError_t e = hipSuccess)
 #define HIP_TRY(expr, what) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return fail(IGS_RAST_E_HIP, what, e_); } while (0)
 #define DBG_SYNC(what) do { if (debug) { hipError_t e_ = hipStreamSynchronize(s); if (e_ != hipSuccess) return fail(IGS_RAST_E_HIP, what, e_); } } while (0)
 
-// pinned 4-byte read-back slot + event, one per host thread and device
-struct HostSlot { int device = -1; uint32_t* pinned = nullptr; uint32_t* pinned_dev = nullptr; hipEvent_t ev = nullptr; };
-static thread_local HostSlot g_slot;
+// pinned status slot + event: one per host thread AND device, kept until the thread ends (a blend kernel still running on the
+// device used before may yet post into its slot, so switching devices never frees one)
+struct HostSlot { uint32_t* pinned = nullptr; uint32_t* pinned_dev = nullptr; hipEvent_t ev = nullptr; };
+#define IGS_MAX_DEVICES 64
+struct HostSlots {
+    HostSlot slot[IGS_MAX_DEVICES];
+    ~HostSlots() { for (auto& h : slot) if (h.pinned) { (void)hipHostFree(h.pinned); (void)hipEventDestroy(h.ev); } }
+};
+static thread_local HostSlots g_slots;
+static thread_local HostSlot g_slot;                // the current device's slot (a copy of the table entry)
 static thread_local hipStream_t g_status_stream = nullptr;
 static thread_local uint32_t g_host_seq = 0;      // sequence number of the last status the blend kernel was asked to post
 static int ensure_slot()
 {
     int dev = 0;
     HIP_TRY(hipGetDevice(&dev), "hipGetDevice");
-    if (g_slot.device == dev && g_slot.pinned) return 0;
-    if (g_slot.pinned) { (void)hipHostFree(g_slot.pinned); (void)hipEventDestroy(g_slot.ev); g_slot = HostSlot(); }
-    HIP_TRY(hipHostMalloc((void**)&g_slot.pinned, (COUNTER_SHARDS + 1) * COUNTER_SHARD_STRIDE * 4, hipHostMallocDefault), "hipHostMalloc");
-    HIP_TRY(hipHostGetDevicePointer((void**)&g_slot.pinned_dev, g_slot.pinned, 0), "hipHostGetDevicePointer");
-    HIP_TRY(hipEventCreateWithFlags(&g_slot.ev, hipEventDisableTiming), "hipEventCreate");
-    g_slot.device = dev;
+    if (dev < 0 || dev >= IGS_MAX_DEVICES) return fail(IGS_RAST_E_INVALID, "device ordinal out of range");
+    HostSlot& h = g_slots.slot[dev];
+    if (!h.pinned) {
+        HIP_TRY(hipHostMalloc((void**)&h.pinned, (COUNTER_SHARDS + 1) * COUNTER_SHARD_STRIDE * 4, hipHostMallocDefault), "hipHostMalloc");
+        HIP_TRY(hipHostGetDevicePointer((void**)&h.pinned_dev, h.pinned, 0), "hipHostGetDevicePointer");
+        HIP_TRY(hipEventCreateWithFlags(&h.ev, hipEventDisableTiming), "hipEventCreate");
+    }
+    g_slot = h;
     return 0;
+}
+
+static double now_s() { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return (double)t.tv_sec + 1e-9 * (double)t.tv_nsec; }
+static double wait_limit_s()
+{
+    static double lim = -1.0;
+    if (lim < 0.0) { const char* e = getenv("IGS_RAST_WAIT_TIMEOUT_S"); lim = e ? atof(e) : 10.0; if (!(lim > 0.0)) lim = 10.0; }
+    return lim;
 }
 
 // Waits until the blend kernel of the current slab-binned frame has posted {R, overflow, prefilter flag} into pinned host
 // memory: a poll on the sequence word instead of an event -- an event record between blend_fwd and blend_bwd costs the stream
 // a ~6 us bubble per step, and the first workgroup posts at the START of the kernel, so the host is released earlier too.
+// Bounded: a stream that reports an error, a stream that drains without the post, or IGS_RAST_WAIT_TIMEOUT_S (default 10)
+// seconds of wall clock without it all end the wait with IGS_RAST_E_HIP.
 static int wait_status(hipStream_t s)
 {
     volatile uint32_t* seq = (volatile uint32_t*)&g_slot.pinned[3];
+    double t0 = 0.0;
     for (long spins = 0;; spins++) {
         if (__atomic_load_n(seq, __ATOMIC_ACQUIRE) == g_host_seq) return 0;
-        if ((spins & 0xFFFF) == 0xFFFF) {
+        if ((spins & 0x3FFF) == 0x3FFF) {
             const hipError_t q = hipStreamQuery(s);
-            if (q != hipSuccess && q != hipErrorNotReady) return fail(IGS_RAST_E_HIP, "stream error while waiting for the frame status");
+            if (q != hipSuccess && q != hipErrorNotReady) return fail(IGS_RAST_E_HIP, "stream error while waiting for the frame status", q);
             if (q == hipSuccess && __atomic_load_n(seq, __ATOMIC_ACQUIRE) != g_host_seq)
                 return fail(IGS_RAST_E_HIP, "the frame status was never posted");
+            const double t = now_s();
+            if (t0 == 0.0) t0 = t;
+            else if (t - t0 > wait_limit_s())
+                return fail(IGS_RAST_E_HIP, "timed out waiting for the frame status (IGS_RAST_WAIT_TIMEOUT_S)");
         }
     }
 }
@@ -364,6 +389,7 @@ extern "C" int igs_rast_forward(
     float* out_color, float* out_coord, float* out_mcoord, float* out_depth, float* out_mdepth, float* out_alpha,
     float* out_normal, int* radii, int require_coord, int require_depth, int debug)
 {
+    if (g_pending.active) return fail(IGS_RAST_E_INVALID, "igs_rast_forward: an asynchronous forward is pending on this thread; call igs_rast_forward_finish() first");
     prof_new_frame();
     const char* e = getenv("IGS_BINNING");                    // "radix" forces the global-sort path (tests)
     const bool radix = e && strcmp(e, "radix") == 0;
@@ -392,8 +418,9 @@ extern "C" int igs_rast_forward_async(
     float* out_color, float* out_coord, float* out_mcoord, float* out_depth, float* out_mdepth, float* out_alpha,
     float* out_normal, int* radii, int require_coord, int require_depth, int debug)
 {
+    // the status slot is single: a second frame must not be started before the first one's count has been collected
+    if (g_pending.active) return fail(IGS_RAST_E_INVALID, "igs_rast_forward_async: the previous asynchronous forward has not been finished (igs_rast_forward_finish)");
     prof_new_frame();
-    g_pending.active = false;
     FwdExtra ex; ex.defer_status = true;
     const int rc = forward_impl(stream, geometry_buffer, geometry_user, binning_buffer, binning_user, image_buffer, image_user, P, D, M,
                                 background, width, height, means3D, shs, colors_precomp, opacities, scales, scale_modifier, rotations,
@@ -421,6 +448,12 @@ extern "C" int igs_rast_forward_finish(void)
 
 extern "C" void igs_rast_set_slab_hint(unsigned slots_per_tile) { g_hint.slab = slots_per_tile > TILE_SORT_BIG ? TILE_SORT_BIG : slots_per_tile; }
 extern "C" unsigned igs_rast_get_slab_hint(void) { return g_hint.slab; }
+
+// which blend_bwd_kernel<COORD, DEPTH, NORMAL, ABS> the last backward on this thread launched: bit 0 coord, 1 depth, 2 normal,
+// 3 abs-gradient moment; -1 = none (R == 0 / no backward yet).  Tests use it to prove that absent upstream gradients select
+// the cheaper instance.
+static thread_local int g_last_bwd_instance = -1;
+extern "C" int igs_rast_last_backward_instance(void) { return g_last_bwd_instance; }
 
 // l1_gt != NULL: L1 loss fused into the blend backward (dL_dpix ignored); fuse != NULL: activation backward + Adam fused into
 // the per-Gaussian backward (no gradient outputs except the optional dL_dmean2D).
@@ -479,8 +512,9 @@ static int backward_impl(
     ba.l1_gt = l1_gt; ba.l1_color = l1_color; ba.l1_scale = l1_scale; ba.l1_loss = loss_shards;
     ba.want_absgrad = (fuse && !dL_dmean2D) ? 0 : 1;
     bool gacc_compact = false;
+    g_last_bwd_instance = -1;
     if (R > 0) {
-        HIP_TRY(launch_blend_bwd(s, ba, require_coord != 0, require_depth != 0, &gacc_compact), "blend_bwd launch");
+        HIP_TRY(launch_blend_bwd(s, ba, require_coord != 0, require_depth != 0, &gacc_compact, &g_last_bwd_instance), "blend_bwd launch");
         DBG_SYNC("blend_bwd");
         prof_mark(s, ST_BLEND_BWD);
     }
@@ -539,9 +573,12 @@ extern "C" size_t igs_refine_loss_scratch_bytes(int width, int height)
     return ((igs_ssim_l1_scratch_bytes(width, height) + 255) & ~(size_t)255) + 3 * HW * 4 + 5 * HW * 4 + 4096 + 512;
 }
 
+extern "C" size_t igs_refine_step_args_size(void) { return sizeof(igs_refine_step_args); }
+
 extern "C" int igs_refine_step(const igs_refine_step_args* a)
 {
     if (!a) return fail(IGS_RAST_E_INVALID, "igs_refine_step: NULL args");
+    if (g_pending.active) return fail(IGS_RAST_E_INVALID, "igs_refine_step: an asynchronous forward is pending on this thread; call igs_rast_forward_finish() first");
     if (a->P <= 0 || a->M <= 0 || a->width <= 0 || a->height <= 0 || (a->step < 1 && !a->grad_out))
         return fail(IGS_RAST_E_INVALID, "igs_refine_step: bad sizes");
     if (!a->param || (!a->grad_out && (!a->exp_avg || !a->exp_avg_sq)) || !a->gt || !a->out_images || !a->radii || !a->workspace || !a->background)

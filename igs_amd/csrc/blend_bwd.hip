@@ -263,7 +263,7 @@ blend_bwd_kernel(const BlendBwdArgs a)
     }
 }
 
-hipError_t launch_blend_bwd(hipStream_t s, const BlendBwdArgs& a, bool coord, bool depth, bool* compact_layout)
+hipError_t launch_blend_bwd(hipStream_t s, const BlendBwdArgs& a, bool coord, bool depth, bool* compact_layout, int* instance_bits)
 {
     const dim3 grid(tile_grid_blocks(a.gx, a.gy)), block(256);
     // The reference instantiates (COORD, DEPTH, NORMAL) from require_coord / require_depth alone (backward.cu:1153-1160).
@@ -274,6 +274,7 @@ hipError_t launch_blend_bwd(hipStream_t s, const BlendBwdArgs& a, bool coord, bo
     const bool D = depth && (a.dL_ddepth || a.dL_dmdepth);
     const bool N = (coord || depth) && a.dL_dnormal;
     if (compact_layout) *compact_layout = !C && !D && !N;
+    if (instance_bits) *instance_bits = (C ? 1 : 0) | (D ? 2 : 0) | (N ? 4 : 0) | ((C || (D && !N) || (!D && N) || a.want_absgrad) ? 8 : 0);
 #define LAUNCH(c, d, n) hipLaunchKernelGGL((blend_bwd_kernel<c, d, n>), grid, block, 0, s, a)
     if (C) { if (D) { if (N) LAUNCH(true, true, true); else LAUNCH(true, true, false); }
              else   { if (N) LAUNCH(true, false, true); else LAUNCH(true, false, false); } }

@@ -160,7 +160,7 @@ struct BlendBwdArgs {
     // instance then drops that moment (its |.| terms, one LDS row, one atomic lane per row)
     int want_absgrad = 1;
 };
-hipError_t launch_blend_bwd(hipStream_t s, const BlendBwdArgs& a, bool coord, bool depth, bool* compact_layout);
+hipError_t launch_blend_bwd(hipStream_t s, const BlendBwdArgs& a, bool coord, bool depth, bool* compact_layout, int* instance_bits = nullptr);
 
 struct GeomBwdArgs {
     int P, D, M, W, H;

@@ -43,6 +43,24 @@ class DensifyState:
             raise RuntimeError("igs_densify_stats failed: %d" % rc)
 
 
+def reduce_state(state, world_size):
+    """N > 1 (views sharded over ranks): every rank has accumulated the statistics of ITS views; before the densification decision
+    the accumulators are summed over ranks and the radii maximised (`xyz_gradient_accum` / `denom` are sums of
+    per-view terms, gaussian_model.py:865-868; `max_radii2D` is a running maximum, infer_batch.py:311), which leaves identical
+    tensors on every rank -- so the plan below, with identically seeded split sampling, is identical everywhere and the replicas
+    stay in lock-step without a broadcast.  A rank's loss carries the factor 1/N of the step's mean over views, so its screen-space
+    gradient norms are multiplied back by N here: the accumulated statistic is then the per-view one the reference's
+    `densify_grad_threshold` was chosen for."""
+    if world_size <= 1:
+        return state
+    import torch.distributed as dist
+    dist.all_reduce(state.grad_accum, op=dist.ReduceOp.SUM)
+    dist.all_reduce(state.denom, op=dist.ReduceOp.SUM)
+    dist.all_reduce(state.max_radii, op=dist.ReduceOp.MAX)
+    state.grad_accum.mul_(float(world_size))
+    return state
+
+
 def build_rotation(q):
     """submodules/RaDe-GS/utils/general_utils.py build_rotation (normalises the quaternion, (w, x, y, z))."""
     q = q / torch.sqrt((q * q).sum(dim=1, keepdim=True))

@@ -34,6 +34,8 @@ def _ptr(t):
 def _prep(t, device, what):
     if t is None or t.numel() == 0:
         return None
+    if t.dtype is torch.float32 and t.device == device and t.is_contiguous():      # (the common case, kept cheap)
+        return t
     if t.device != device:
         raise RasterizerError("%s must live on %s (got %s)" % (what, device, t.device))
     if t.dtype != torch.float32:
@@ -77,6 +79,52 @@ class RasterBuffers:
         return self.imgs, self.radii, self.scratch
 
 
+class _ScratchPool:
+    """Scratch for the autograd binding.  The reference allocates three fresh byte tensors per forward
+    (rasterize_points.cu:80-87); here a {geometry, binning, image, backward workspace} set is leased per
+    (P, H, W, device, stream) and handed back when the autograd node that saved it dies (after `loss.backward()` /
+    when the graph is dropped; at once under `torch.no_grad()`), so a render loop allocates nothing after its second
+    iteration.  A set is never shared between two live graphs.  Outputs (images, radii, gradients) are always fresh tensors."""
+
+    KEEP = 4
+
+    def __init__(self):
+        self.free = {}
+
+    def acquire(self, key):
+        lst = self.free.get(key)
+        if lst:
+            return lst.pop()
+        dev = key[3]
+        ws = torch.empty(_cabi.lib().igs_rast_backward_workspace_bytes(key[0]), dtype=torch.uint8, device=dev)
+        return (_Scratch(dev, True), _Scratch(dev, True), _Scratch(dev, True), ws)
+
+    def release(self, key, item):
+        lst = self.free.setdefault(key, [])
+        if len(lst) < self.KEEP:
+            lst.append(item)
+        if len(self.free) > 8:            # sizes come and go (densification): forget the oldest keys
+            for k in list(self.free)[:-8]:
+                del self.free[k]
+
+
+_POOL = _ScratchPool()
+
+
+class _Lease:
+    """Returns its scratch set to the pool when the owning autograd context is garbage-collected."""
+    __slots__ = ("key", "item")
+
+    def __init__(self, key):
+        self.key, self.item = key, _POOL.acquire(key)
+
+    def __del__(self):
+        try:
+            _POOL.release(self.key, self.item)
+        except Exception:  # noqa: BLE001  (interpreter shutdown)
+            pass
+
+
 def _check(rc, what):
     if rc < 0:
         raise RasterizerError("%s failed (%d): %s" % (what, rc, _cabi.last_error()))
@@ -85,11 +133,12 @@ def _check(rc, what):
 
 def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp, viewmatrix,
                         projmatrix, tan_fovx, tan_fovy, kernel_size, image_height, image_width, sh, degree, campos,
-                        prefiltered, require_coord, require_depth, debug, buffers=None, defer=False):
+                        prefiltered, require_coord, require_depth, debug, buffers=None, defer=False, scratch=None):
     """`_C.rasterize_gaussians` (RasterizeGaussiansCUDA, DGR/rasterize_points.cu:35-133).
 
     Returns (num_rendered, color, coord, mcoord, alpha, normal, depth, mdepth, radii, geomBuffer, binningBuffer, imgBuffer).
-    `buffers` (extension) is a RasterBuffers object whose image / radii / scratch tensors are reused across calls.
+    `buffers` (extension) is a RasterBuffers object whose image / radii / scratch tensors are reused across calls;
+    `scratch` (extension) a (geometry, binning, image) triple of _Scratch objects to use instead of fresh byte tensors.
     `defer=True` (extension) does not wait for the instance count: num_rendered is then an upper bound (accepted by
     rasterize_gaussians_backward) and `rasterize_finish()` must be called before the results are trusted."""
     if means3D.dim() != 2 or means3D.size(1) != 3:
@@ -113,7 +162,7 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
         else:
             imgs = (torch.empty if P > 0 else torch.zeros)((15, H, W), dtype=torch.float32, device=dev)
             radii = torch.empty((P,), dtype=torch.int32, device=dev) if P > 0 else torch.zeros((0,), dtype=torch.int32, device=dev)
-            geom, binning, img = _Scratch(dev), _Scratch(dev), _Scratch(dev)
+            geom, binning, img = scratch[:3] if scratch is not None else (_Scratch(dev), _Scratch(dev), _Scratch(dev))
         color, coord, mcoord = imgs[0:3], imgs[3:6], imgs[6:9]
         depth, mdepth, alpha, normal = imgs[9:10], imgs[10:11], imgs[11:12], imgs[12:15]
         rendered = 0
@@ -140,17 +189,13 @@ def rasterize_finish():
     return rc
 
 
-def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rotations, scale_modifier, cov3D_precomp,
-                                 viewmatrix, projmatrix, tan_fovx, tan_fovy, kernel_size, dL_dout_color, dL_dout_coord,
-                                 dL_dout_mcoord, dL_dout_depth, dL_dout_mdepth, dL_dout_alpha, dL_dout_normal, normalmap, sh,
-                                 degree, campos, geomBuffer, R, binningBuffer, imageBuffer, alphas, require_coord,
-                                 require_depth, debug, out=None, workspace=None):
-    """`_C.rasterize_gaussians_backward` (RasterizeGaussiansBackwardCUDA, DGR/rasterize_points.cu:135-246).
-
-    Returns (dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations).
-    Extensions over the reference: any upstream gradient may be None (= zeros: the output was not used by the loss);
-    `out` may name preallocated contiguous destination tensors by those eight names (e.g. spans of a flat gradient
-    buffer), `workspace` a reusable uint8 scratch tensor."""
+def _backward(background, means3D, radii, colors, scales, rotations, scale_modifier, cov3D_precomp,
+              viewmatrix, projmatrix, tan_fovx, tan_fovy, kernel_size, dL_dout_color, dL_dout_coord,
+              dL_dout_mcoord, dL_dout_depth, dL_dout_mdepth, dL_dout_alpha, dL_dout_normal, normalmap, sh,
+              degree, campos, geomBuffer, R, binningBuffer, imageBuffer, alphas, require_coord,
+              require_depth, debug, out=None, workspace=None):
+    """Body of `rasterize_gaussians_backward`; also returns the dense block that holds the seven small gradients
+    (m2d 3 | colors 3 | opacity 1 | means3D 3 | scales 3 | rot 4 | cov3D 6 floats per Gaussian) for the fused NaN check."""
     L = _cabi.lib()
     dev = means3D.device
     P = means3D.size(0)
@@ -161,8 +206,6 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
         f32 = dict(dtype=torch.float32, device=dev)
         alloc = torch.empty if P > 0 else torch.zeros
         dL_dsh = alloc((P, M, 3), **f32)
-        # one allocation for the other per-Gaussian gradients, carved into dense [P,k] arrays:
-        # m2d 3 | colors 3 | opacity 1 | means3D 3 | cov3D 6 | scales 3 | rot 4
         block = alloc((23 * P,), **f32)
         o = 0
         def carve(k):
@@ -171,7 +214,7 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
             o += k * P
             return t
         dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D = carve(3), carve(3), carve(1), carve(3)
-        dL_dcov3D, dL_dscales, dL_drotations = carve(6), carve(3), carve(4)
+        dL_dscales, dL_drotations, dL_dcov3D = carve(3), carve(4), carve(6)
         if out:
             dL_dmeans2D = out.get("means2D", dL_dmeans2D); dL_dcolors = out.get("colors", dL_dcolors)
             dL_dopacity = out.get("opacity", dL_dopacity); dL_dmeans3D = out.get("means3D", dL_dmeans3D)
@@ -199,7 +242,24 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
                 _ptr(dL_dmeans2D), _ptr(dL_dcolors), _ptr(dL_dopacity), _ptr(dL_dmeans3D), _ptr(dL_dcov3D), _ptr(dL_dsh),
                 _ptr(dL_dscales), _ptr(dL_drotations), int(bool(require_coord)), int(bool(require_depth)), int(bool(debug)))
             _check(rc, "igs_rast_backward")
-    return (dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations)
+    return (dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations), block
+
+
+def rasterize_gaussians_backward(*args, **kw):
+    """`_C.rasterize_gaussians_backward` (RasterizeGaussiansBackwardCUDA, DGR/rasterize_points.cu:135-246), same 32 positional
+    arguments (background, means3D, radii, colors, scales, rotations, scale_modifier, cov3D_precomp, viewmatrix, projmatrix,
+    tan_fovx, tan_fovy, kernel_size, dL_dout_color, dL_dout_coord, dL_dout_mcoord, dL_dout_depth, dL_dout_mdepth, dL_dout_alpha,
+    dL_dout_normal, normalmap, sh, degree, campos, geomBuffer, R, binningBuffer, imageBuffer, alphas, require_coord,
+    require_depth, debug).
+
+    Returns (dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations).
+    Extensions over the reference: any upstream gradient may be None (= zeros: the output was not used by the loss);
+    `out=` may name preallocated contiguous destination tensors by those eight names (e.g. spans of a flat gradient
+    buffer), `workspace=` a reusable uint8 scratch tensor."""
+    return _backward(*args, **kw)[0]
+
+
+last_backward_instance = _cabi.last_backward_instance
 
 
 def mark_visible(means3D, viewmatrix, projmatrix):
@@ -258,19 +318,28 @@ def _make_function(clamp_grads):
                     raster_settings.image_width, sh, raster_settings.sh_degree, raster_settings.campos,
                     raster_settings.prefiltered, raster_settings.require_coord, raster_settings.require_depth,
                     raster_settings.debug)
+            # outputs that take no part in the loss arrive in backward as None (not as zero-filled tensors): the C ABI reads
+            # NULL as zeros and then runs the cheapest blend-backward instance that covers the gradients actually present
+            ctx.set_materialize_grads(False)
+            lease = None
+            if means3D.is_cuda and means3D.dim() == 2:
+                dev = means3D.device
+                lease = _Lease((means3D.size(0), int(raster_settings.image_height), int(raster_settings.image_width), dev,
+                                torch.cuda.current_stream(dev).cuda_stream))
             if raster_settings.debug:
                 cpu_args = cpu_deep_copy_tuple(args)
                 try:
-                    out = rasterize_gaussians(*args)
+                    out = rasterize_gaussians(*args, scratch=lease.item if lease else None)
                 except Exception as ex:
                     torch.save(cpu_args, "snapshot_fw.dump")
                     print("\nAn error occured in forward. Please forward snapshot_fw.dump for debugging.")
                     raise ex
             else:
-                out = rasterize_gaussians(*args)
+                out = rasterize_gaussians(*args, scratch=lease.item if lease else None)
             num_rendered, color, coord, mcoord, alpha, normal, depth, mdepth, radii, geomBuffer, binningBuffer, imgBuffer = out
             ctx.raster_settings = raster_settings
             ctx.num_rendered = num_rendered
+            ctx.lease = lease               # the scratch set goes back to the pool when this context dies
             ctx.save_for_backward(colors_precomp, means3D, scales, rotations, cov3Ds_precomp, normal, radii, sh, geomBuffer,
                                   binningBuffer, imgBuffer, alpha)
             ctx.mark_non_differentiable(radii)
@@ -282,27 +351,23 @@ def _make_function(clamp_grads):
             raster_settings = ctx.raster_settings
             (colors_precomp, means3D, scales, rotations, cov3Ds_precomp, normal, radii, sh, geomBuffer, binningBuffer, imgBuffer,
              alpha) = ctx.saved_tensors
-            H, W = raster_settings.image_height, raster_settings.image_width
-
-            def z(g, c):   # autograd hands None for outputs that did not take part in the loss: NULL = zeros in the C ABI
-                return g
-
             args = (raster_settings.bg, means3D, radii, colors_precomp, scales, rotations, raster_settings.scale_modifier,
                     cov3Ds_precomp, raster_settings.viewmatrix, raster_settings.projmatrix, raster_settings.tanfovx,
-                    raster_settings.tanfovy, raster_settings.kernel_size, z(grad_color, 3), z(grad_coord, 3), z(grad_mcoord, 3),
-                    z(grad_depth, 1), z(grad_mdepth, 1), z(grad_alpha, 1), z(grad_normal, 3), normal, sh,
+                    raster_settings.tanfovy, raster_settings.kernel_size, grad_color, grad_coord, grad_mcoord,
+                    grad_depth, grad_mdepth, grad_alpha, grad_normal, normal, sh,
                     raster_settings.sh_degree, raster_settings.campos, geomBuffer, num_rendered, binningBuffer, imgBuffer, alpha,
                     raster_settings.require_coord, raster_settings.require_depth, raster_settings.debug)
+            ws = ctx.lease.item[3] if getattr(ctx, "lease", None) is not None else None
             if raster_settings.debug:
                 cpu_args = cpu_deep_copy_tuple(args)
                 try:
-                    out = rasterize_gaussians_backward(*args)
+                    out, block = _backward(*args, workspace=ws)
                 except Exception as ex:
                     torch.save(cpu_args, "snapshot_bw.dump")
                     print("\nAn error occured in backward. Writing snapshot_bw.dump for debugging.\n")
                     raise ex
             else:
-                out = rasterize_gaussians_backward(*args)
+                out, block = _backward(*args, workspace=ws)
             grad_means2D, grad_colors_precomp, grad_opacities, grad_means3D, grad_cov3Ds_precomp, grad_sh, grad_scales, grad_rotations = out
             if clamp_grads:     # DGRC/diff_gaussian_rasterization_rade_clamp/__init__.py:156-162
                 grad_means3D = torch.clamp(grad_means3D, -15, 15)
@@ -311,10 +376,11 @@ def _make_function(clamp_grads):
                 grad_scales = torch.clamp(grad_scales, -15, 15)
                 grad_rotations = torch.clamp(grad_rotations, -15, 15)
             if NAN_CHECKS:
-                # the reference does 7 separate `.any()` host syncs (__init__.py:156-162); one fused check here
-                bad = torch.stack([torch.isnan(g).any() for g in (grad_means3D, grad_means2D, grad_sh, grad_colors_precomp,
-                                                                 grad_opacities, grad_scales, grad_rotations)])
-                assert not bool(bad.any())
+                # the reference asserts on seven tensors with seven `.any()` host syncs (__init__.py:156-162); six of them are
+                # one dense block here (its first 17 floats per Gaussian; the cov3D gradient behind them is not checked there
+                # either), so: two reductions, one host sync
+                P = means3D.size(0)
+                assert not bool(torch.isnan(block[:17 * P]).any() | torch.isnan(grad_sh).any())
             # shapes autograd expects: the gradient of an absent (empty CPU) input is None
             def m(g, ref):
                 return g if (ref is not None and ref.numel() > 0) else None

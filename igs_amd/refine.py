@@ -409,7 +409,8 @@ class Refiner:
             if self.iteration > cfg.from_iter and self.iteration % cfg.interval == 0:
                 assert not did_adam
                 if self.densify_gen is None:
-                    self.densify_gen = torch.Generator(device=p.device).manual_seed(self.densify_seed)
+                    self.densify_gen = torch.Generator(device=p.device).manual_seed(self.densify_seed)      # same seed on every rank
+                _dn.reduce_state(self.densify_state, self.world_size)      # N > 1: sum / max of the per-rank statistics
                 pl = _dn.densify_and_prune(p, self.densify_state, cfg, self.densify_gen)
                 self.densify_log.append((self.iteration, pl["n_clone"], pl["n_split"], pl["n_pruned"], p.P))
                 rebuilt = True
@@ -479,6 +480,20 @@ class Refiner:
         self.adam_fn()
         return pkg
 
+    def _exchange_step(self, cam, gt, explicit_view):
+        """N > 1 (or an injected optimiser): the same fused launches, ending in the flat gradient instead of the update; then the
+        exchange over RCCL / xGMI and the identical Adam step on every rank."""
+        p = self.params
+        picks = getattr(self, "last_picks", None) if explicit_view is None else None
+        if 1 < self.world_size <= 64 and self.fused and self.exchange == "colors" and picks is not None:      # (the library takes at most 64 views)
+            return self._colour_exchange_step(cam, gt, picks)
+        pkg = self._fused_step(cam, gt, grads_only=True) if self.fused else self._native_step(cam, gt)
+        if self.world_size > 1:
+            import torch.distributed as dist
+            dist.all_reduce(p.grad, op=dist.ReduceOp.SUM)      # one flat 59*P-float buffer over RCCL / xGMI
+        self.adam_fn()
+        return pkg
+
     def step(self, view=None):
         p = self.params
         explicit_view = view
@@ -486,14 +501,22 @@ class Refiner:
             view = self._next_view()
         cam, gt = self.cams[view], self.gt[view]
         native_ok = self.native and self.render_fn is render and (self.fused or self.lambda_depth_normal == 0.0)
-        if native_ok and self.densify is not None and self.world_size == 1 and self.adam_fn == p.adam_step:
+        if self.densify is not None and not (native_ok and self.adam_fn == p.adam_step):
+            raise NotImplementedError("densify-and-prune is implemented for the native path with the library's optimiser only "
+                                      "(native=True, no injected render_fn / adam_fn)")
+        if self.densify is not None:
             # the reference updates the statistics after every backward and, on a densification iteration, rebuilds the
-            # Gaussians BEFORE optimizer.step() -- which then finds no gradients and does nothing (infer_batch.py:308-324)
+            # Gaussians BEFORE optimizer.step() -- which then finds no gradients and does nothing (infer_batch.py:308-324).
+            # N > 1: every rank adds the statistics of its own view; they are reduced over ranks right before the decision
+            # (densify.reduce_state), which every rank then takes identically.
             if self._densify_due():
                 pkg = self._fused_step(cam, gt, grads_only=True) if self.fused else self._native_step(cam, gt)    # gradients only, no Adam
                 self._densify_hooks(pkg, did_adam=False)
             else:
-                pkg = self._fused_step(cam, gt) if self.fused else self._native_then_adam(cam, gt)
+                if self.world_size == 1:
+                    pkg = self._fused_step(cam, gt) if self.fused else self._native_then_adam(cam, gt)
+                else:
+                    pkg = self._exchange_step(cam, gt, explicit_view)
                 self._densify_hooks(pkg, did_adam=True) if self.iteration < self.densify.until_iter else None
             self.iteration += 1
             return pkg
@@ -501,16 +524,7 @@ class Refiner:
         if (native_ok and self.fused and self.world_size == 1 and self.adam_fn == p.adam_step):
             return self._fused_step(cam, gt)
         if native_ok:
-            # N > 1 (or an injected optimiser): the same fused launches, ending in the flat gradient instead of the update
-            picks = getattr(self, "last_picks", None) if explicit_view is None else None
-            if 1 < self.world_size <= 64 and self.fused and self.exchange == "colors" and picks is not None:      # (the library takes at most 64 views)
-                return self._colour_exchange_step(cam, gt, picks)
-            pkg = self._fused_step(cam, gt, grads_only=True) if self.fused else self._native_step(cam, gt)
-            if self.world_size > 1:
-                import torch.distributed as dist
-                dist.all_reduce(p.grad, op=dist.ReduceOp.SUM)      # one flat 59*P-float buffer over RCCL / xGMI
-            self.adam_fn()
-            return pkg
+            return self._exchange_step(cam, gt, explicit_view)
         p.zero_grad()
         act = p.activated()
         pkg = self.render_fn(act, cam, self.bg, clamp=True) if (getattr(self, "clamp", False) and self.render_fn is render) else self.render_fn(act, cam, self.bg)

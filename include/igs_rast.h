@@ -17,7 +17,8 @@
  *   - the three scratch buffers are opaque byte buffers grown through callbacks; they must stay alive and
  *     unmodified until the matching backward call, and P, R (= the value forward returned), W, H must be the same;
  *   - `stream` is a hipStream_t (pass the framework's current stream; NULL = default stream).  All work is
- *     enqueued on it.  forward performs ONE host wait (for the 12-byte frame status {num_rendered, slab overflow, prefilter
+ *     enqueued on it.  The host wait is bounded: IGS_RAST_WAIT_TIMEOUT_S seconds (default 10) without the status, a stream
+ *     error, or a drained stream without it return IGS_RAST_E_HIP.  forward performs ONE host wait (for the 12-byte frame status {num_rendered, slab overflow, prefilter
  *     flag} that the blend kernel posts into pinned host memory; the reference reads its count back at
  *     rasterizer_impl.cu:354); backward performs none;
  *   - threading: the library keeps a little state PER HOST THREAD (the pinned status slot, the per-tile slab size that worked
@@ -44,7 +45,7 @@
 extern "C" {
 #endif
 
-#define IGS_RAST_VERSION 1
+#define IGS_RAST_VERSION 2
 
 #define IGS_RAST_E_INVALID   (-1)   /* bad argument (NULL required pointer, negative size, ...) */
 #define IGS_RAST_E_HIP       (-2)   /* a HIP runtime call or kernel launch failed */
@@ -188,6 +189,10 @@ int igs_rast_debug_dump(void* stream, int P, int R, int width, int height,
  * few microseconds of stream time, so marking every frame slows a 0.35 ms refine step by about 10 %, every 8th by about 1 %.
  * In igs_refine_step the geom_bwd stage includes the activation backward and the Adam update. */
 #define IGS_RAST_NSTAGES 10
+/* Which backward tile-blend instance the last igs_rast_backward / igs_refine_step on this thread launched: bit 0 coord, bit 1
+ * depth, bit 2 normal gradients present, bit 3 the |screen-space gradient| moment; -1 = none.  (The reference instantiates from
+ * require_coord / require_depth alone, backward.cu:1153-1160; here branches whose upstream gradients are all NULL are left out.) */
+int igs_rast_last_backward_instance(void);
 int igs_rast_profile_enable(int on);
 int igs_rast_profile_read(double* ms_sum, long long* count, double* r_sum, long long* calls, int reset);
 
@@ -253,6 +258,7 @@ typedef struct igs_refine_step_args {
                                                  zero) -- what the ranks of a multi-GPU step gather instead of all-reducing dL/dSH */
 } igs_refine_step_args;
 int igs_refine_step(const igs_refine_step_args* args);
+size_t igs_refine_step_args_size(void);       /* sizeof(igs_refine_step_args) of the loaded library: bindings check it before the first call */
 
 /* Multi-GPU refine step (extension; views are sharded over the ranks): dL/dSH of the step = sum over its views of
  * basis(direction_v) x dL/dcolour_v (backward.cu:21-140, the W(k, b) rows of the SH backward).  Every rank all-gathers the

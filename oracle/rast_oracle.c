@@ -65,7 +65,7 @@ typedef struct { real x, y, z; } f3;
 
 /* test-only switch: bit 0 drops the d(coef)/d(cov2D) terms of backward.cu:367-375,398-400 (whose "opacity"
  * operand is really dL_dconic.w in the reference) so the remaining chain can be checked against autograd */
-static int g_flags = 0;
+static _Thread_local int g_flags = 0;      /* per thread: the tests evaluate several views concurrently */
 void gsor_set_flags(int f) { g_flags = f; }
 /* per-Gaussian sums of the blend backward: double by default (rounded once at the end, see the header); with flag 2 the running
  * sum is rounded to float after every add, i.e. the reference's float atomicAdd (backward.cu:878-1013) in ONE of its possible
@@ -558,6 +558,9 @@ typedef struct {
     uint32_t* ranges;      /* [T][2] */
     uint32_t* n_contrib;   /* [2*H*W] */
     real *accum_coord, *accum_depth, *normal_length;
+    /* test-only (flag 8): the per-Gaussian sums of the last blend backward on this state, kept so that further evaluations of the
+     * per-Gaussian backward on the SAME upstream gradients (the jitter samples of flag 4) skip the per-pixel loop */
+    double* acc_cache; int acc_cache_flags;
 } gsor_state;
 
 static void* xcalloc(size_t n, size_t sz) { void* p = calloc(n ? n : 1, sz); if (!p) { fprintf(stderr, "oracle: out of memory\n"); abort(); } return p; }
@@ -569,6 +572,7 @@ void gsor_free(gsor_state* s)
     free(s->view_points); free(s->cov3D); free(s->conic_opacity); free(s->rgb); free(s->clamped);
     free(s->tiles_touched); free(s->point_offsets); free(s->radii); free(s->keys); free(s->point_list);
     free(s->ranges); free(s->n_contrib); free(s->accum_coord); free(s->accum_depth); free(s->normal_length);
+    free(s->acc_cache);
     free(s);
 }
 
@@ -1207,11 +1211,16 @@ void gsor_backward(const gsor_state* s, const real* bg, const real* means3D, con
 {
     const int P = s->P;
     gacc_t A;
-    A.mean2D = xcalloc((size_t)P*3, 8); A.conic = xcalloc((size_t)P*4, 8); A.opacity = xcalloc(P, 8);
-    A.colors = xcalloc((size_t)P*3, 8); A.view_points = xcalloc((size_t)P*3, 8); A.ts = xcalloc(P, 8);
-    A.camera_planes = xcalloc((size_t)P*6, 8); A.ray_planes = xcalloc((size_t)P*2, 8); A.normals = xcalloc((size_t)P*3, 8);
+    /* one block of 26 P doubles: mean2D 3 | conic 4 | opacity 1 | colors 3 | view_points 3 | ts 1 | camera_planes 6 | ray_planes 2 | normals 3 */
+    gsor_state* ms = (gsor_state*)s;
+    const int reuse = (g_flags & 8) && ms->acc_cache && ms->acc_cache_flags == (g_flags & 2);
+    double* blk = reuse ? ms->acc_cache : xcalloc((size_t)P*26, 8);
+    A.mean2D = blk; A.conic = A.mean2D + (size_t)P*3; A.opacity = A.conic + (size_t)P*4; A.colors = A.opacity + (size_t)P;
+    A.view_points = A.colors + (size_t)P*3; A.ts = A.view_points + (size_t)P*3; A.camera_planes = A.ts + (size_t)P;
+    A.ray_planes = A.camera_planes + (size_t)P*6; A.normals = A.ray_planes + (size_t)P*2;
     int COORD = s->require_coord, DEPTH = s->require_depth, NORMAL = (s->require_coord || s->require_depth);
     const real* color_ptr = colors_precomp ? colors_precomp : s->rgb;
+    if (!reuse)
     for (int ty = 0; ty < s->gy; ty++) for (int tx = 0; tx < s->gx; tx++) {
         uint32_t r0 = s->ranges[2*(ty*s->gx + tx)], r1 = s->ranges[2*(ty*s->gx + tx) + 1];
         if (r1 <= r0) continue;
@@ -1230,8 +1239,8 @@ void gsor_backward(const gsor_state* s, const real* bg, const real* means3D, con
     for (size_t i = 0; i < (size_t)P; i++) { dL_dopacity[i] = (real)(A.opacity[i] * sum_jitter(i, 6)); f_ts[i] = (real)(A.ts[i] * sum_jitter(i, 7)); }
     for (size_t i = 0; i < (size_t)P*6; i++) f_cp[i] = (real)(A.camera_planes[i] * sum_jitter(i, 8));
     for (size_t i = 0; i < (size_t)P*2; i++) f_rp[i] = (real)(A.ray_planes[i] * sum_jitter(i, 9));
-    free(A.mean2D); free(A.conic); free(A.opacity); free(A.colors); free(A.view_points); free(A.ts);
-    free(A.camera_planes); free(A.ray_planes); free(A.normals);
+    if (g_flags & 8) { if (!reuse) { free(ms->acc_cache); ms->acc_cache = blk; ms->acc_cache_flags = g_flags & 2; } }
+    else if (!reuse) free(blk);
     if (dbg_view_points) memcpy(dbg_view_points, f_view_points, (size_t)P*3*sizeof(real));
     if (dbg_ts) memcpy(dbg_ts, f_ts, (size_t)P*sizeof(real));
     if (dbg_camera_planes) memcpy(dbg_camera_planes, f_cp, (size_t)P*6*sizeof(real));

@@ -16,3 +16,11 @@ def pytest_configure(config):
 def golden():
     import numpy as np
     return np.load(os.path.join(ROOT, "tests", "golden", "ref_helpers.npz"))
+
+
+@pytest.fixture(scope="session")
+def golden_torch_only():
+    """Outputs of the RaDe-GS python files that import with torch alone (loss_utils, general_utils, image_utils): made by
+    tests/golden/make_golden.py in the build container, data only."""
+    import numpy as np
+    return np.load(os.path.join(ROOT, "tests", "golden", "ref_torch_only.npz"))

@@ -7,6 +7,15 @@ computeColorFromSH, forward.cu:23-74, must reproduce) and igs/utils/graphics_uti
 (getProjectionMatrix, getWorld2View2, fov2focal, focal2fov: the matrix conventions of the callers).
 They are loaded by file path (the `igs` package itself cannot be imported: jaxtyping/omegaconf absent).
 Only inputs and outputs (data) are stored, never reference source.
+
+Round 2 adds tests/golden/ref_torch_only.npz from the RaDe-GS python files that import with torch alone
+(census: loss_utils, general_utils, image_utils, sh_utils, depth_utils import; graphics_utils -- home of
+depth_double_to_normal -- needs cv2, igs/utils/loss_utils.py needs icecream: both stay unpinned):
+  * submodules/RaDe-GS/utils/loss_utils.py  l1_loss, ssim (the same functions as igs/utils/loss_utils.py:17-63): values and the
+    autograd gradient of 0.8 L1 + 0.2 (1 - SSIM) w.r.t. the rendered image, on two image sizes;
+  * submodules/RaDe-GS/utils/general_utils.py  build_rotation, build_scaling_rotation + strip_symmetric (the 3-D covariance of
+    gaussian_model.py's build_covariance_from_scaling_rotation = what computeCov3D, forward.cu:270-304, must produce), inverse_sigmoid;
+  * submodules/RaDe-GS/utils/image_utils.py  psnr.
 """
 import importlib.util
 import math
@@ -26,7 +35,62 @@ def load(name):
     return m
 
 
+RADE = "/root/reference/submodules/RaDe-GS/utils"
+
+
+def load_rade(name):
+    spec = importlib.util.spec_from_file_location("rade_" + name, os.path.join(RADE, name + ".py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+def torch_only():
+    lu, gu, iu = load_rade("loss_utils"), load_rade("general_utils"), load_rade("image_utils")
+    out = {}
+    g = torch.Generator().manual_seed(4321)
+    for tag, (H, W) in (("a", (40, 52)), ("b", (67, 35))):
+        yy, xx = torch.meshgrid(torch.arange(H).float(), torch.arange(W).float(), indexing="ij")
+        gt = torch.stack([0.5 + 0.4 * torch.sin(xx / 5.0 + c) * torch.cos(yy / (7.0 + c)) for c in range(3)]) \
+            + 0.05 * torch.randn(3, H, W, generator=g)
+        gt = gt.clamp(0, 1)
+        img = (gt + 0.08 * torch.randn(3, H, W, generator=g)).clamp(0, 1)
+        x = img.clone().requires_grad_(True)
+        l1 = lu.l1_loss(x, gt)
+        s_avg = lu.ssim(x, gt)                                           # size_average=True
+        s_call = lu.ssim(x, gt.unsqueeze(0), size_average=False)         # the call shape of infer_batch.py:302
+        loss = 0.8 * l1 + 0.2 * (1.0 - s_call)
+        loss.sum().backward()
+        gx = torch.autograd.grad(lu.l1_loss(x, gt), x)[0]
+        gs = torch.autograd.grad(lu.ssim(x, gt), x)[0]
+        out["loss_%s_img" % tag], out["loss_%s_gt" % tag] = img.numpy(), gt.numpy()
+        out["loss_%s_l1" % tag], out["loss_%s_ssim" % tag] = l1.detach().numpy(), s_avg.detach().numpy()
+        out["loss_%s_ssim_call" % tag] = s_call.detach().numpy()
+        out["loss_%s_total" % tag], out["loss_%s_grad" % tag] = loss.detach().numpy(), x.grad.numpy()
+        out["loss_%s_grad_l1" % tag], out["loss_%s_grad_ssim" % tag] = gx.numpy(), gs.numpy()
+        out["psnr_%s" % tag] = iu.psnr(img.unsqueeze(0), gt.unsqueeze(0)).numpy()
+    N = 48
+    q = torch.randn(N, 4, generator=g)
+    s = torch.exp(torch.rand(N, 3, generator=g) * 3.0 - 3.5)
+    out["rot_q"], out["rot_scales"] = q.numpy(), s.numpy()
+    orig_zeros = torch.zeros
+    torch.zeros = lambda *a, **k: orig_zeros(*a, **{kk: vv for kk, vv in k.items() if kk != "device"})     # build_rotation says device='cuda'
+    try:
+        out["rot_R"] = gu.build_rotation(q).numpy()
+        L = gu.build_scaling_rotation(1.0 * s, q)
+        out["rot_cov6"] = gu.strip_symmetric(L @ L.transpose(1, 2)).numpy()
+        L2 = gu.build_scaling_rotation(1.7 * s, q)
+        out["rot_cov6_mod17"] = gu.strip_symmetric(L2 @ L2.transpose(1, 2)).numpy()
+    finally:
+        torch.zeros = orig_zeros
+    out["inv_sigmoid_x"] = np.array([0.01, 0.1, 0.5, 0.9, 0.995], dtype=np.float32)
+    out["inv_sigmoid_y"] = gu.inverse_sigmoid(torch.tensor(out["inv_sigmoid_x"])).numpy()
+    np.savez(os.path.join(HERE, "ref_torch_only.npz"), **out)
+    print("wrote ref_torch_only.npz:", {k: v.shape for k, v in out.items()})
+
+
 def main():
+    torch_only()
     sh_utils = load("sh_utils")
     gu = load("graphics_utils")
     g = torch.Generator().manual_seed(1234)

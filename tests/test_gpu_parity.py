@@ -2,10 +2,12 @@
 
 Bars (BASELINE.json north_star): rendered RGB/depth within 1e-4 abs, gradients within 1e-3 rel.  Index work (radii,
 tiles touched, sorted instance list, tile ranges, contributor counts) must be bit-exact.
-The gradient bar is applied to the bulk (>= 96 % of the elements within 1e-3 of the oracle, relative to
-|ref| + 1e-3 max|ref|): the reference recovers transmittance as T_final = 1 - sum(alpha*T) and divides it back
-(backward.cu:706,857), which amplifies last-ulp differences of expf by 1/T_final on a few Gaussians behind saturated
-pixels -- its own results move by the same amount between CUDA and x86 libm (tests/test_oracle_autograd.py).
+Gradients on the BASELINE configurations (cfg-1 10k @256x256; cfg-2/3 200k @1352x1014, all ten cameras) carry an EVERY-ELEMENT
+certificate (tests/certificate.py): each element within 1e-3 rel of a float64 evaluation, plus -- only where the float32 oracle
+itself is that far from float64, or moves that far under float-sum jitter -- an allowance of 5x that distance; the tests print how
+many elements needed it.  Why an allowance exists at all: the reference recovers transmittance as T_final = 1 - sum(alpha*T) and
+divides it back (backward.cu:706,857), which amplifies last-ulp differences of expf by 1/T_final behind saturated pixels.
+The smaller feature tests keep a bulk bar (`check_grads`: >= 96 % of the elements within 1e-3 of the float32 oracle).
 """
 import math
 
@@ -152,17 +154,21 @@ def test_gradients_match_oracle(dev, req):
 
 
 def test_cfg1_full_size_10k_256(dev):
-    """BASELINE.json configs[0]: 10k random Gaussians, 1 cam @256x256 -- images and gradients against the oracle."""
+    """BASELINE.json configs[0]: 10k random Gaussians, 1 cam @256x256 -- images against the oracle, and every gradient element
+    against float64 with the certificate of tests/certificate.py (dense scene, most pixels saturated: T_final ~ 1e-4)."""
+    import certificate as cert
     raw, cams, bg = cfg1_scene()
     cam, a = cams[0], activate(raw)
     out, ad, mats = hip_forward(a, cam, bg, dev)
+    grads = None
+    ob = None
     nr_o, oo, st = oracle_forward(a, cam, bg)
     assert out[0] == nr_o
     check_images(out, oo)
     grads = rand_grads(oo, 3)
-    # dense scene, most pixels saturated (T_final ~ 1e-4): the forward alpha agrees to 5e-6, and the reference's
-    # T_final = 1 - alpha turns that into percent-level differences for the splats behind such pixels
-    check_grads(hip_backward(out, ad, mats, cam, bg, dev, grads), oracle_backward(st, oo, a, cam, bg, grads), bulk=0.90, p99=2e-2)
+    gout = hip_backward(out, ad, mats, cam, bg, dev, grads)
+    ob = cert.oracle_all(a, cam, bg, grads, samples=24)
+    cert.certify(gout, ob, "cfg-1 10k @256x256", max_allowance_frac=0.25)
 
 
 @pytest.mark.parametrize("deg", [0, 1, 2])
@@ -895,33 +901,60 @@ def test_fused_step_on_a_ragged_image(dev):
         assert np.quantile(d, 0.98) < 2e-6 and d.max() <= 0.11, (loss, np.quantile(d, 0.98), d.max())
 
 
-def test_full_size_frame_matches_oracle(dev):
-    """BASELINE.json configs[1]/[2] at FULL size (200k Gaussians, 1352x1014, one view): the instance count, radii, the sorted
+def test_full_size_frames_match_oracle_on_all_ten_cameras(dev):
+    """BASELINE.json configs[1]/[2] at FULL size (200k Gaussians, 1352x1014), ALL TEN cameras: the instance count, radii, the sorted
     instance list, the tile ranges and the contributor counts are bit-exact against the CPU oracle, the seven images are within
-    1e-4, and the colour-loss gradients agree on the bulk (about 4 s of oracle time)."""
+    1e-4, and EVERY gradient element passes the float64 certificate (tests/certificate.py).  Even cameras: the upstream gradient
+    of a colour loss only (cfg-3's L1: the compact <colour-only> backward instance, the one bench.py times); odd cameras: random
+    upstream gradients on all seven outputs (the full <coord, depth, normal> instance).  The oracle work (float32 + float64 +
+    jitter samples, ~15 s per view on one core) runs on worker threads, one view each."""
+    import os
+    from concurrent.futures import ThreadPoolExecutor
+    import certificate as cert
     from igs_amd import rasterizer as R
     raw, cams, bg = sear_steak_like_scene()
-    cam, a = cams[3], activate(raw)
-    out, ad, mats = hip_forward(a, cam, bg, dev, debug=False)
-    nr_o, oo, st = oracle_forward(a, cam, bg)
-    it = st.intermediates()
+    a = activate(raw)
     P = a["means3D"].shape[0]
-    d = R.debug_dump(P, out[0], cam.width, cam.height, out[9], out[10], out[11])
-    assert out[0] == nr_o and nr_o > 400000
-    np.testing.assert_array_equal(out[8].cpu().numpy(), oo["radii"])
-    np.testing.assert_array_equal(d["point_list"].cpu().numpy().astype(np.uint32), it["point_list"])
-    np.testing.assert_array_equal(d["ranges"].cpu().numpy().astype(np.uint32), it["ranges"])
-    np.testing.assert_array_equal(d["n_contrib"].cpu().numpy().astype(np.uint32), it["n_contrib"])
-    check_images(out, oo)
-    rng = np.random.default_rng(1)
-    g = {k: None for k in KEYS}
-    g["color"] = (rng.standard_normal(tuple(out[1].shape)) / out[1].numel()).astype(np.float32)
-    zeros = {k: np.zeros(tuple(out[i].shape), np.float32) for k, i in zip(KEYS, (1, 2, 3, 6, 7, 4, 5))}
-    zeros["color"] = g["color"]
-    gout = hip_backward(out, ad, mats, cam, bg, dev, zeros)
-    gr = oracle_backward(st, oo, a, cam, bg, zeros)
-    # (worst single element out of ~12 million: behind saturated pixels 1/T_final amplifies last-ulp differences, DESIGN.md 2)
-    check_grads(gout, gr, worst=1.0)
+    hip = []
+    for v, cam in enumerate(cams):
+        out, ad, mats = hip_forward(a, cam, bg, dev, debug=False)
+        d = R.debug_dump(P, out[0], cam.width, cam.height, out[9], out[10], out[11])
+        rng = np.random.default_rng(100 + v)
+        if v % 2 == 0:
+            g = {k: None for k in KEYS}
+            g["color"] = (rng.standard_normal(tuple(out[1].shape)) / out[1].numel()).astype(np.float32)
+            gt = [None if g[k] is None else torch.from_numpy(g[k]).to(dev) for k in KEYS]
+            nr, color, coord, mcoord, alpha, normal, depth, mdepth, radii, gb, bb, ib = out
+            gout = R.rasterize_gaussians_backward(bg.to(dev), ad["means3D"], radii, E, ad["scales"], ad["rotations"], 1.0, E, mats[0], mats[1],
+                                                  cam.tanfovx, cam.tanfovy, 0.0, *gt, normal, ad["shs"], 3, mats[2], gb, nr, bb, ib, alpha,
+                                                  True, True, False)
+            assert R.last_backward_instance() == dict(coord=False, depth=False, normal=False, absgrad=True)
+        else:
+            g = {k: (rng.standard_normal(tuple(out[i].shape)) / out[1].numel()).astype(np.float32) for k, i in zip(KEYS, (1, 2, 3, 6, 7, 4, 5))}
+            gout = hip_backward(out, ad, mats, cam, bg, dev, g)
+            assert R.last_backward_instance() == dict(coord=True, depth=True, normal=True, absgrad=True)
+        hip.append(dict(nr=out[0], imgs=[None] + [t.cpu() for t in out[1:8]], radii=out[8].cpu().numpy(),
+                        lists={k: d[k].cpu().numpy().astype(np.uint32) for k in ("point_list", "ranges", "n_contrib")},
+                        gout=[t.cpu().numpy() for t in gout], grads=g))
+        del out, d, gout
+    torch.cuda.synchronize()
+    workers = max(1, min(len(cams), (os.cpu_count() or 2) - 1))
+    with ThreadPoolExecutor(workers) as ex:
+        obs = list(ex.map(lambda vc: cert.oracle_all(a, vc[1], bg, hip[vc[0]]["grads"], samples=12), enumerate(cams)))
+    used = tot = 0
+    for v, (h, ob) in enumerate(zip(hip, obs)):
+        it = ob["state"].intermediates()
+        assert h["nr"] == ob["nr"] and ob["nr"] > 400000, (v, h["nr"], ob["nr"])
+        np.testing.assert_array_equal(h["radii"], ob["out"]["radii"])
+        np.testing.assert_array_equal(h["lists"]["point_list"], it["point_list"])
+        np.testing.assert_array_equal(h["lists"]["ranges"], it["ranges"])
+        np.testing.assert_array_equal(h["lists"]["n_contrib"], it["n_contrib"])
+        check_images(h["imgs"], ob["out"])
+        st = cert.certify(h["gout"], ob, "cfg-2/3 camera %d (%s upstream gradients)" % (v, "colour-only" if v % 2 == 0 else "all seven"))
+        used += sum(x[1] for x in st.values()); tot += sum(x[0] for x in st.values())
+        ob["state"] = None
+    print("full size, ten cameras: %d of %d gradient elements (%.4f %%) needed the certificate's allowance" % (used, tot, 100.0 * used / tot))
+    assert used <= 0.02 * tot
 
 
 def test_drop_in_ssim_matches_the_reference_formula(dev):
@@ -1131,3 +1164,133 @@ def test_two_rank_colour_exchange_equals_flat_allreduce(dev):
                         "--master-port", str(port), os.path.join(root, "tools", "check_exchange.py"), "--backend", "gloo"],
                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300, env=env, cwd=root)
     assert r.returncode == 0 and "EXCHANGE_CHECK_OK" in r.stdout, r.stdout[-2000:]
+
+
+def test_two_rank_densification_keeps_replicas_identical(dev):
+    """N = 2 refine loop WITH densify-and-prune (gloo, both ranks on this GPU; tools/check_exchange.py --densify): every rank adds the
+    statistics of its own view, they are summed / maximised over ranks before each decision (gaussian_model.py:865-868,
+    infer_batch.py:308-321), the rebuilds happen on iterations 8, 16, 24 without an Adam step, and parameters and Adam moments stay
+    bit-identical on both ranks through all of it."""
+    import os, socket, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(root, "tools", "check_exchange.py"), "--backend", "gloo", "--densify"],
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300, env=env, cwd=root)
+    assert r.returncode == 0 and "DENSIFY_CHECK_OK" in r.stdout, r.stdout[-2000:]
+
+
+def test_drop_in_package_runs_only_the_backward_branches_the_loss_needs(dev):
+    """An unchanged IGS caller: `GaussianRasterizer` from the package, a loss that reads the colour image only (infer_batch.py:300-306).
+    autograd then hands None for the six other outputs (set_materialize_grads(False)); the C ABI reads NULL as zeros and launches
+    blend_bwd_kernel<false, false, false> -- same gradients as the all-outputs instance fed with explicit zeros; a depth / normal loss
+    selects exactly those branches; the scratch set of a finished graph is reused by the next render."""
+    import diff_gaussian_rasterization_rade as D
+    from igs_amd import rasterizer as R
+    raw, cams, bg = cfg1_scene(P=2500, size=112)
+    cam = cams[0].to(dev)
+
+    def run(loss_fn):
+        leaf = {k: v.to(dev).clone().requires_grad_(True) for k, v in raw.items()}
+        a = activate(leaf)
+        st = D.GaussianRasterizationSettings(image_height=cam.height, image_width=cam.width, tanfovx=cam.tanfovx, tanfovy=cam.tanfovy,
+                                             kernel_size=0.0, bg=bg.to(dev), scale_modifier=1.0, viewmatrix=cam.world_view_transform,
+                                             projmatrix=cam.full_proj_transform, sh_degree=3, campos=cam.camera_center,
+                                             prefiltered=False, require_depth=True, require_coord=True, debug=False)
+        m2d = torch.zeros_like(a["means3D"], requires_grad=True)
+        res = D.GaussianRasterizer(raster_settings=st)(means3D=a["means3D"], means2D=m2d, opacities=a["opacities"], shs=a["shs"],
+                                                       scales=a["scales"], rotations=a["rotations"])
+        loss_fn(res).backward()
+        inst = R.last_backward_instance()
+        return {k: v.grad.detach().clone() for k, v in leaf.items()}, m2d.grad.detach().clone(), inst
+
+    w = torch.randn((3, cam.height, cam.width), generator=torch.Generator().manual_seed(4)).to(dev)
+    g_col, m_col, inst = run(lambda r: (r[0] * w).sum())
+    assert inst == dict(coord=False, depth=False, normal=False, absgrad=True), inst
+    # the same loss with every other output multiplied by zero: all seven gradients present -> the full instance
+    g_all, m_all, inst_all = run(lambda r: (r[0] * w).sum() + 0.0 * (r[2].sum() + r[3].sum() + r[4].sum() + r[5].sum() + r[6].sum() + r[7].sum()))
+    assert inst_all == dict(coord=True, depth=True, normal=True, absgrad=True), inst_all
+    for k in g_col:
+        r = rel(g_col[k].cpu().numpy(), g_all[k].cpu().numpy())
+        assert np.quantile(r, 0.999) < 1e-3 and np.median(r) < 1e-5, (k, np.quantile(r, 0.999))
+    assert np.quantile(rel(m_col.cpu().numpy(), m_all.cpu().numpy()), 0.999) < 1e-3
+    # depth + normal loss (RaDe-GS regulariser shape): <depth, normal>, no coord; colour gradient absent (NULL dL_dpix)
+    _, _, inst_dn = run(lambda r: (r[4] * w[:1]).sum() + (r[7] * w).sum())
+    assert inst_dn == dict(coord=False, depth=True, normal=True, absgrad=True), inst_dn
+    # scratch reuse: after the graphs above died, a render leases a pooled set instead of allocating
+    n_free = sum(len(v) for v in R._POOL.free.values())
+    assert n_free >= 1
+    with torch.no_grad():
+        leaf = {k: v.to(dev) for k, v in raw.items()}
+        a = activate(leaf)
+        st = D.GaussianRasterizationSettings(image_height=cam.height, image_width=cam.width, tanfovx=cam.tanfovx, tanfovy=cam.tanfovy,
+                                             kernel_size=0.0, bg=bg.to(dev), scale_modifier=1.0, viewmatrix=cam.world_view_transform,
+                                             projmatrix=cam.full_proj_transform, sh_degree=3, campos=cam.camera_center,
+                                             prefiltered=False, require_depth=True, require_coord=True, debug=False)
+        img1 = D.GaussianRasterizer(raster_settings=st)(means3D=a["means3D"], means2D=a["means3D"], opacities=a["opacities"], shs=a["shs"],
+                                                        scales=a["scales"], rotations=a["rotations"])[0]
+        keep = img1.clone()
+        img2 = D.GaussianRasterizer(raster_settings=st)(means3D=a["means3D"] + 0.3, means2D=a["means3D"], opacities=a["opacities"],
+                                                        shs=a["shs"], scales=a["scales"], rotations=a["rotations"])[0]
+    assert torch.equal(img1, keep) and not torch.equal(img1, img2)          # outputs are never pooled
+    assert sum(len(v) for v in R._POOL.free.values()) == n_free
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_loss_kernels_match_reference_loss_utils_fixture(dev, golden_torch_only, tag):
+    """igs_ssim_l1_loss_fwd_bwd, igs_l1_loss_fwd_bwd and the drop-in `igs_amd.losses.ssim` against values and autograd gradients that
+    the REFERENCE's loss_utils.py produced (tests/golden/ref_torch_only.npz; RaDe-GS utils/loss_utils.py = igs/utils/loss_utils.py:17-63)."""
+    from igs_amd import _cabi
+    from igs_amd.losses import ssim as fused_ssim
+    from igs_amd.refine import L1Fused
+    g = golden_torch_only
+    img, gt = torch.from_numpy(g["loss_%s_img" % tag]).to(dev), torch.from_numpy(g["loss_%s_gt" % tag]).to(dev)
+    H, W = img.shape[-2:]
+    L = _cabi.lib()
+    scratch = torch.empty(L.igs_ssim_l1_scratch_bytes(W, H), dtype=torch.uint8, device=dev)
+    grad, sums = torch.empty_like(img), torch.empty(2048, device=dev)
+    rc = L.igs_ssim_l1_loss_fwd_bwd(torch.cuda.current_stream(dev).cuda_stream, W, H, img.data_ptr(), gt.data_ptr(), 0.2, 1.0,
+                                    scratch.data_ptr(), grad.data_ptr(), sums.data_ptr())
+    assert rc == 0
+    n = img.numel()
+    ssim_mean, l1_mean = float(sums[:1024].sum()) / n, float(sums[1024:].sum()) / n
+    np.testing.assert_allclose(ssim_mean, g["loss_%s_ssim" % tag], rtol=2e-5)
+    np.testing.assert_allclose(l1_mean, g["loss_%s_l1" % tag], rtol=2e-5)
+    np.testing.assert_allclose(0.8 * l1_mean + 0.2 * (1.0 - ssim_mean), g["loss_%s_total" % tag].item(), rtol=2e-5)
+    G = g["loss_%s_grad" % tag]
+    assert np.abs(grad.cpu().numpy() - G).max() <= 1e-4 * np.abs(G).max()
+    # the drop-in function with the reference's call shape, value and gradient of the SSIM part alone
+    x = img.clone().requires_grad_(True)
+    v = fused_ssim(x, gt.unsqueeze(0), size_average=False)
+    np.testing.assert_allclose(v.detach().cpu().numpy(), g["loss_%s_ssim_call" % tag], rtol=2e-5)
+    v.sum().backward()
+    Gs = g["loss_%s_grad_ssim" % tag]
+    assert np.abs(x.grad.cpu().numpy() - Gs).max() <= 1e-4 * np.abs(Gs).max()
+    # fused L1
+    gi = torch.empty_like(img)
+    s = L1Fused(dev)(img, gt, gi)
+    np.testing.assert_allclose(float(s.sum()) / n, g["loss_%s_l1" % tag], rtol=2e-5)
+    Gl = g["loss_%s_grad_l1" % tag]
+    assert np.abs(gi.cpu().numpy() - Gl).max() <= 1e-6 * np.abs(Gl).max() + 1e-12
+
+
+def test_cov3d_of_the_hip_forward_matches_reference_build_covariance(dev, golden_torch_only):
+    """The 3-D covariance the HIP preprocess kernel builds (rec words 24..29) against strip_symmetric(L L^T) from the reference's own
+    general_utils.py (fixture), for scale_modifier 1 and 1.7."""
+    from igs_amd import rasterizer as R
+    from igs_amd import camera
+    g = golden_torch_only
+    q, s = g["rot_q"], g["rot_scales"]
+    qn = torch.from_numpy(q / np.linalg.norm(q, axis=1, keepdims=True)).float()
+    P = q.shape[0]
+    means = torch.zeros(P, 3); means[:, 2] = 3.0
+    proj = camera.get_projection_matrix(0.01, 100.0, 1.0, 1.0).t().contiguous()
+    for mod, key in ((1.0, "rot_cov6"), (1.7, "rot_cov6_mod17")):
+        out = R.rasterize_gaussians(torch.zeros(3, device=dev), means.to(dev), E, torch.full((P, 1), 0.5, device=dev), torch.from_numpy(s).to(dev),
+                                    qn.to(dev), mod, E, torch.eye(4, device=dev), proj.to(dev), 0.5463, 0.5463, 0.0, 32, 32,
+                                    torch.zeros(P, 16, 3, device=dev), 3, torch.zeros(3, device=dev), False, True, True, False)
+        d = R.debug_dump(P, out[0], 32, 32, out[9], out[10], out[11])
+        cov = d["rec"][:, 24:30].cpu().numpy()
+        np.testing.assert_allclose(cov, g[key], rtol=2e-5, atol=1e-7 * float(np.abs(g[key]).max()))

@@ -20,7 +20,8 @@ def test_cabi_library_exports_every_declared_symbol():
     assert {"igs_rast_forward", "igs_rast_backward", "igs_rast_mark_visible", "igs_rast_backward_workspace_bytes"} <= names
     for n in sorted(names):
         assert hasattr(L, n), "libigs_rast.so does not export %s" % n
-    assert L.igs_rast_version() == 1
+    assert L.igs_rast_version() == _cabi.VERSION == 2
+    assert L.igs_refine_step_args_size() > 0
     assert L.igs_rast_backward_workspace_bytes(1000) >= 1000 * 25 * 4
     assert set(_cabi.EXPORTS) <= names | {"igs_rast_last_error", "igs_rast_version"}
 
@@ -188,6 +189,89 @@ def test_view_sharding_and_gradient_allreduce_gloo_world2():
     np.testing.assert_allclose(p.flat.numpy(), f0, rtol=1e-5, atol=1e-7)
     # without-replacement sampling: the first 3 steps (6 draws) cover all 6 views once
     assert sorted(v0[:3] + v1[:3]) == list(range(6))
+
+
+def _densify_rank_main(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sys.path.insert(0, ROOT)
+    from igs_amd import densify as dn
+    raw, stats, cfg = _densify_case()
+    P = raw["xyz"].shape[0]
+    st = dn.DensifyState(P, torch.device("cpu"))
+    for it in range(3):                                        # three steps; rank r sees view 2*it + r, its loss carries 1/world
+        g, radii = stats[2 * it + rank]
+        vis = radii > 0
+        st.grad_accum += torch.where(vis, g / world, torch.zeros_like(g))      # what igs_densify_stats adds (CPU restatement)
+        st.denom += vis.float()
+        st.max_radii = torch.maximum(st.max_radii, torch.where(vis, radii.float(), torch.zeros_like(g)))
+    dn.reduce_state(st, world)
+    pl = dn.plan(raw["xyz"], raw["rotation"], raw["opacity"], raw["scaling"], st, cfg, torch.Generator().manual_seed(5))
+    q.put((rank, st.grad_accum.numpy(), st.denom.numpy(), st.max_radii.numpy(),
+           {k: (v.numpy() if torch.is_tensor(v) else v) for k, v in pl.items()}))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _densify_case(P=400):
+    from igs_amd import densify as dn
+    from igs_amd.scenes import cfg1_scene
+    raw, _, _ = cfg1_scene(P=P, size=16)
+    gen = torch.Generator().manual_seed(21)
+    stats = []
+    for _ in range(6):                                          # per view: screen-space gradient norms and radii (0 = not visible)
+        g = torch.rand(P, generator=gen) * 4e-4
+        radii = torch.randint(0, 30, (P,), generator=gen) * (torch.rand(P, generator=gen) > 0.3)
+        stats.append((g, radii.int()))
+    cfg = dn.DensifyConfig(until_iter=100, from_iter=0, interval=3, grad_threshold=1.5e-4, min_opacity=0.05, max_num=P + 60,
+                           percent_dense=0.01, extent=5.0)
+    return raw, stats, cfg
+
+
+def test_densification_statistics_reduce_over_ranks_gloo_world2():
+    """N = 2 densification (gaussian_model.py:865-868, infer_batch.py:308-321): the per-rank accumulators are summed
+    (and the radii maximised) over ranks before the decision; both ranks then hold the statistics a single process would have
+    accumulated over the same six views at full loss weight, and derive the identical clone / split / prune plan (same RNG seed)."""
+    import torch.multiprocessing as mp
+    from igs_amd import densify as dn
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_densify_rank_main, args=(r, 2, port, q)) for r in range(2)]
+    for pr in procs:
+        pr.start()
+    res = sorted([q.get(timeout=120) for _ in procs], key=lambda t: t[0])
+    for pr in procs:
+        pr.join(timeout=60)
+        assert pr.exitcode == 0
+    (_, ga0, de0, mr0, pl0), (_, ga1, de1, mr1, pl1) = res
+    np.testing.assert_array_equal(ga0, ga1); np.testing.assert_array_equal(de0, de1); np.testing.assert_array_equal(mr0, mr1)
+    for k in pl0:
+        np.testing.assert_array_equal(pl0[k], pl1[k])          # identical plan on both ranks, split samples included
+    raw, stats, cfg = _densify_case()
+    P = raw["xyz"].shape[0]
+    st = dn.DensifyState(P, torch.device("cpu"))
+    for g, radii in stats:
+        vis = radii > 0
+        st.grad_accum += torch.where(vis, g, torch.zeros_like(g))
+        st.denom += vis.float()
+        st.max_radii = torch.maximum(st.max_radii, torch.where(vis, radii.float(), torch.zeros_like(g)))
+    np.testing.assert_allclose(ga0, st.grad_accum.numpy(), rtol=1e-6)
+    np.testing.assert_array_equal(de0, st.denom.numpy()); np.testing.assert_array_equal(mr0, st.max_radii.numpy())
+    assert pl0["n_clone"] + pl0["n_split"] > 0 and pl0["src"].shape[0] != P
+
+
+def test_densify_with_an_unsupported_driver_raises():
+    """Densification must not be skipped silently (round-1 finding): paths that cannot honour it raise."""
+    from igs_amd.refine import GaussianParams, Refiner
+    from igs_amd import densify as dn
+    raw, cams, gts = _make_scene()
+    p = GaussianParams(raw, torch.device("cpu"))
+    r = Refiner(p, cams, gts, None, render_fn=_fake_render, adam_fn=_torch_adam_on_flat(p), densify=dn.DensifyConfig())
+    with pytest.raises(NotImplementedError):
+        r.step(view=0)
 
 
 def test_depth_to_normal_on_an_analytic_plane():

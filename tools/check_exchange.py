@@ -15,6 +15,8 @@ def main():
     ap.add_argument("--backend", default="gloo")
     ap.add_argument("--loss", default="l1_ssim")
     ap.add_argument("--clamp", action="store_true")
+    ap.add_argument("--densify", action="store_true", help="instead: the refine loop with densify-and-prune on every rank (statistics reduced\n"
+                    "over ranks before each decision); replicas must stay bit-identical through the rebuilds")
     ap.add_argument("--time", action="store_true", help="also time both exchanges on the bench workload (200k Gaussians @1352x1014)")
     args = ap.parse_args()
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
@@ -32,6 +34,34 @@ def main():
     gt_raw = {k: v.to(dev) for k, v in perturbed_copy(raw, sigma=0.05).items()}
     with torch.no_grad():
         gts = [render(activate(gt_raw), c, bg)["images_pred"].clone() for c in cams]
+    if args.densify:
+        from igs_amd.densify import DensifyConfig
+        cfg = DensifyConfig(until_iter=30, from_iter=0, interval=8, grad_threshold=2e-5, min_opacity=0.005, max_num=33000,
+                            percent_dense=0.01, extent=15.0)
+        p = GaussianParams(raw, dev)
+        r = Refiner(p, cams, gts, bg, loss=args.loss, world_size=world, rank=rank, seed=3, densify=cfg, densify_seed=11)
+        r.start_frame()
+        counts = []
+        for _ in range(26):
+            r.step()
+            counts.append(p.P)
+        torch.cuda.synchronize()
+        n = torch.tensor([p.P, p.step_count], device=dev)
+        lo, hi = n.clone(), n.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN); dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        same = bool(torch.equal(lo, hi))
+        if same:
+            for t in (p.flat, p.exp_avg, p.exp_avg_sq):
+                a, b = t.clone(), t.clone()
+                dist.all_reduce(a, op=dist.ReduceOp.MIN); dist.all_reduce(b, op=dist.ReduceOp.MAX)
+                same = same and bool(torch.equal(a, b)) and bool(torch.isfinite(t).all())
+        ok = same and [e[0] for e in r.densify_log] == [8, 16, 24] and len(set(counts)) > 1 and p.step_count == 26 - 3
+        if rank == 0:
+            print("densify log (iteration, cloned, split, pruned, P):", r.densify_log, "replicas identical:", same, "steps:", p.step_count)
+            print("DENSIFY_CHECK_OK" if ok else "DENSIFY_CHECK_FAILED")
+        dist.barrier()
+        dist.destroy_process_group()
+        sys.exit(0 if ok else 1)
     results = {}
     for mode in ("gradients", "colors"):
         p = GaussianParams(raw, dev)
