@@ -1,22 +1,37 @@
 #!/usr/bin/env python3
-"""Headline benchmark: Gaussians rendered/sec (fwd+bwd) at 1352x1014  (BASELINE.json metric).
+"""Headline benchmark: Gaussians rendered/sec (fwd+bwd) at 1352x1014; PSNR vs ref  (BASELINE.json metric).
 
-Every step is ONE library call per rank (igs_refine_step: activations, forward, loss, backward and -- for N = 1 -- the Adam
-update, 6 launches); for N > 1 the call ends in the flat gradient, which is all-reduced and followed by one Adam launch.
+  python bench.py --gpus N --steps K --warmup W [--config cfg3|cfg2|cfg4|cfg5] [--scene bench|dense]
 
-Workload at every N (weak scaling): BASELINE.json configs[2] -- the sear_steak-like frame-0 scene (200k Gaussians,
-synthetic stand-in), 10 train cameras at 1352x1014, and per step ONE view per rank:
-forward render + L1 loss + backward + (N>1: RCCL all-reduce of the flat 59*P-float gradient) + Adam step.
-value = P * views_processed / seconds, whole job.
+N = 1 runs in this process.  N > 1 with no WORLD_SIZE in the environment SELF-LAUNCHES: before anything touches the GPU the parent
+checks torch.cuda.device_count() >= N (refusing with a non-zero exit code otherwise), starts N ranks as child processes
+(`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ...`, one rank per GPU over RCCL), relays
+rank 0's JSON line and exits with the children's code.  Launched by torch.distributed.run directly (what the driver does for
+N > 1) it reads RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* as usual.
 
-  python bench.py --gpus N --steps K --warmup W         (N > 1: launched by torch.distributed.run, one rank per GPU)
+Configurations (BASELINE.json `configs`; every scene is the synthetic "sear_steak-like" stand-in):
+  cfg3 (default, the headline)  200k Gaussians, 10 train cams @1352x1014; one step = ONE view per rank: activations + forward
+        (coord, depth, normal on) + L1 + backward + Adam -- one library call per rank (igs_refine_step, 6 launches); for N > 1 the
+        call ends in the gradient, the ranks exchange it over RCCL and apply the identical Adam step.
+  cfg2  forward-only render of the same scene through the drop-in entry point (one host wait per frame, as the reference);
+        one step = one rendered view per rank.
+  cfg4  stream: frames x 50 refine iterations (fresh optimiser per frame = load_fromstream, frame-to-frame drift of the target,
+        reference loss 0.8 L1 + 0.2 (1 - SSIM)); one step = one refine iteration (one view per rank); --steps K runs K // 50
+        frames (default 2500 = 50 frames).  Per-frame optimiser set-up is inside the timed region.
+  cfg5  cfg4 with the RaDe-GS depth-normal regulariser (lambda 0.05: the <depth, normal> backward instance) and the clamp
+        variant's +-15 gradient clamp; default 15000 steps = 300 frames.
 
-Prints ONE JSON line on rank 0 with `roofline` (dominant kernel, HIP-event timing over the timed region) and
-`cpu_baseline` (the CPU oracle timed on a bounded sample of the same workload; rank 0, N = 1 only).
+value = Gaussians x views processed / seconds, whole job (all ranks), inputs resident in HBM when the timed region starts.
+Rank 0 prints ONE JSON line with `roofline` (dominant kernel: HIP-event stage timing + algorithmic bytes + pixel-Gaussian pairs/s),
+`cpu_baseline` (N = 1 only: the pure-PyTorch restatement on BASELINE cfg-1 on all host cores, plus the scalar C port on a bounded
+sample of this workload) and `psnr` (held-out camera before / after the refine steps that were timed).
 """
 import argparse
 import json
 import os
+import socket
+import statistics
+import subprocess
 import sys
 import time
 
@@ -24,9 +39,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-import torch  # noqa: E402
-
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+ITERS_PER_FRAME = 50       # configs/demo.yaml refine_iterations
 
 
 def algorithmic_bytes(R, W, H, coord=True, depth=True, bwd_coord=None, bwd_depth=None, bwd_normal=None, l1_fused=False):
@@ -48,9 +62,48 @@ def algorithmic_bytes(R, W, H, coord=True, depth=True, bwd_coord=None, bwd_depth
     return dict(blend_fwd=R * g + H * W * p + 8 * T, blend_bwd=R * gb + H * W * px_bwd + R * 100)
 
 
-def cpu_baseline(raw, cams, bg, gts, n_views):
-    """Times the CPU oracle (scalar C restatement of the reference, 1 thread) on `n_views` views of the same workload:
-    forward + L1 gradient + backward.  Checker code used as a baseline only; never on the product path."""
+# ----------------------------------------------------------------------------------------------------------------------------
+# CPU baselines (checker code used as a baseline only; never on the product path)
+# ----------------------------------------------------------------------------------------------------------------------------
+def cpu_baseline_torch(repeats=5):
+    """north_star / BASELINE.md 3: the pure-PyTorch projection + per-pixel alpha-blend restatement (oracle/torch_oracle.py) on
+    BASELINE cfg-1 (10k Gaussians, 1 cam @256x256) with torch.set_num_threads(os.cpu_count()); 1 warm-up, median of `repeats`."""
+    import torch
+    from igs_amd.scenes import cfg1_scene, activate
+    from oracle import torch_oracle as to
+    cores = os.cpu_count() or 1
+    prev = torch.get_num_threads()
+    torch.set_num_threads(cores)
+    try:
+        raw, cams, bg = cfg1_scene()
+        cam = cams[0]
+        P = raw["xyz"].shape[0]
+
+        def run(bwd):
+            leaf = {k: v.clone().requires_grad_(bwd) for k, v in raw.items()}
+            a = activate(leaf)
+            t = time.perf_counter()
+            with torch.set_grad_enabled(bwd):
+                out = to.render(a["means3D"], a["shs"], None, a["opacities"], a["scales"], a["rotations"], None, 1.0,
+                                cam.world_view_transform, cam.full_proj_transform, cam.camera_center, cam.tanfovx, cam.tanfovy,
+                                0.0, cam.width, cam.height, 3, bg)
+                if bwd:
+                    out["color"].abs().mean().backward()
+            return time.perf_counter() - t
+        run(True)
+        fb = statistics.median(run(True) for _ in range(repeats))
+        f = statistics.median(run(False) for _ in range(repeats))
+    finally:
+        torch.set_num_threads(prev)
+    return dict(value=P / fb, unit="Gaussians/s", cores=cores, kind="port",
+                sample="BASELINE cfg-1 (10k Gaussians, 1 cam @256x256) forward + L1 + autograd backward on the pure-PyTorch restatement "
+                       "(oracle/torch_oracle.py), torch.set_num_threads(%d), median of %d after 1 warm-up: %.2f s per view" % (cores, repeats, fb),
+                forward_only_value=P / f, forward_only_s=f)
+
+
+def cpu_baseline_c_port(raw, cams, bg, gts, n_views):
+    """The scalar C restatement of the reference (oracle/rast_oracle.c, 1 thread) on `n_views` views of THIS workload:
+    forward + L1 gradient + backward (no Adam)."""
     import numpy as np
     from igs_amd.scenes import activate
     from oracle import c_oracle as co
@@ -69,162 +122,427 @@ def cpu_baseline(raw, cams, bg, gts, n_views):
                               None, None, None, None)
     dt = time.time() - t0
     return dict(value=P * n_views / dt, unit="Gaussians/s", cores=1, kind="port",
-                sample="%d view(s) fwd + L1 grad + bwd of the same 200k-Gaussian 1352x1014 workload on the scalar C oracle "
-                       "(no Adam), %.1f s" % (n_views, dt))
+                sample="%d view(s) fwd + L1 grad + bwd of this workload (%d Gaussians @%dx%d) on the scalar C oracle (no Adam), %.1f s"
+                       % (n_views, P, cams[0].width, cams[0].height, dt))
+
+
+# ----------------------------------------------------------------------------------------------------------------------------
+# self-launch (N > 1 without a launcher)
+# ----------------------------------------------------------------------------------------------------------------------------
+def self_launch(n):
+    """Runs before ANY GPU call in this process (torch.cuda.device_count() does not initialise the device on this image)."""
+    import torch
+    have = torch.cuda.device_count()
+    if have < n:
+        print("bench.py: --gpus %d requested but only %d GPU(s) are visible; refusing to run a smaller job under that label" % (n, have),
+              file=sys.stderr)
+        return 3
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)          # children inherit stdout / stderr: rank 0's JSON line goes straight through
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--steps", type=int, default=None, help="timed steps (default: 200 for cfg3 / cfg2, 2500 for cfg4, 15000 for cfg5)")
     ap.add_argument("--warmup", type=int, default=30)
+    ap.add_argument("--config", default="cfg3", choices=["cfg2", "cfg3", "cfg4", "cfg5"], help="BASELINE.json configs[1..4] (see module docstring)")
+    ap.add_argument("--mode", default=None, choices=["refine", "forward"], help="alias: --mode forward = --config cfg2")
+    ap.add_argument("--scene", default="bench", choices=["bench", "dense"],
+                    help="bench: the scene SURVEY.md 8d prescribes (log-scale mean -4, R/P = 2.6).  dense: DIAGNOSTIC, same Gaussians with\n"
+                         "log-scale mean -3 (R in the millions, as SURVEY 8d's own example): the blend kernels where blending dominates")
     ap.add_argument("--points", type=int, default=200000)
     ap.add_argument("--width", type=int, default=1352)
     ap.add_argument("--height", type=int, default=1014)
     ap.add_argument("--cams", type=int, default=10)
-    ap.add_argument("--loss", default="l1", choices=["l1", "l1_ssim"])
-    ap.add_argument("--lambda-depth-normal", type=float, default=0.0,
-                    help="add the RaDe-GS depth-normal regulariser with this weight (BASELINE cfg-5 uses 0.05): the blend backward\n"
-                         "then runs its <depth, normal> instance")
-    ap.add_argument("--clamp", action="store_true", help="clamp variant of the rasterizer (gradients clamped to +-15; BASELINE cfg-5)")
-    ap.add_argument("--cpu-views", type=int, default=3, help="views timed on the CPU oracle (0 = skip)")
+    ap.add_argument("--loss", default=None, choices=["l1", "l1_ssim"], help="default: l1 for cfg3 (BASELINE configs[2]), l1_ssim for cfg4 / cfg5")
+    ap.add_argument("--lambda-depth-normal", type=float, default=None,
+                    help="weight of the RaDe-GS depth-normal regulariser (cfg5 default 0.05): the blend backward then runs its <depth, normal> instance")
+    ap.add_argument("--clamp", action="store_true", help="clamp variant of the rasterizer (gradients clamped to +-15; default on for cfg5)")
+    ap.add_argument("--densify", action="store_true", help="cfg4 / cfg5: densify-and-prune as configs/demo.yaml:57-62 (changes the Gaussian count)")
+    ap.add_argument("--cpu-views", type=int, default=2, help="views timed on the scalar C oracle (0 = skip)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="do not record per-stage HIP events")
     ap.add_argument("--colour-only-forward", action="store_true",
-                    help="NOT the reference configuration: render colour only (require_coord = require_depth = False); the L1 / SSIM\n"
-                         "losses never look at the other outputs, so the refined parameters are the same")
-    ap.add_argument("--viewspace-grad", action="store_true",
-                    help="also produce dL/d(screen-space mean) with its absolute-gradient column (only the densification statistics\n"
-                         "read it; the refine loop without densification does not)")
+                    help="NOT the reference configuration: render colour only (require_coord = require_depth = False)")
+    ap.add_argument("--viewspace-grad", action="store_true", help="also produce dL/d(screen-space mean) (the densification statistic)")
     ap.add_argument("--no-spatial-sort", action="store_true", help="keep the Gaussians in the (random) order of the synthetic scene")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse the\n"
                     "N > 1 code path on a box with fewer GPUs than ranks)")
+    ap.add_argument("--exchange", default="colors", choices=["colors", "gradients"], help="N > 1 gradient exchange (DESIGN.md 6)")
     ap.add_argument("--profile-every", type=int, default=8,
-                    help="record the per-stage HIP events on every N-th step of the timed region (each event costs stream time)")
+                    help="timed region: record the per-stage HIP events on every N-th step (each event costs stream time); the stage\n"
+                         "means of the roofline come from a separate pass right after it with events on EVERY step")
+    ap.add_argument("--profile-steps", type=int, default=48, help="steps of that separate profiled pass (0 = skip it)")
     args = ap.parse_args()
+    if args.mode == "forward":
+        args.config = "cfg2"
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args.gpus))
+
+    import torch
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if rank == 0:
+            print("bench.py: --gpus %d but WORLD_SIZE is %d: refusing to report one under the other's label" % (args.gpus, world), file=sys.stderr)
+        sys.exit(3)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (no CPU fallback for the product path)")
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if args.backend == "nccl":
+            if torch.cuda.device_count() < world:
+                raise SystemExit("bench.py: %d ranks but %d GPUs" % (world, torch.cuda.device_count()))
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend=args.backend)
-    if args.gpus != world and rank == 0 and world > 1:
-        print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU (no CPU fallback for the product path)")
+        joined = dist.get_world_size()
+    else:
+        joined = 1
     dev = torch.device("cuda", local_rank if args.backend == "nccl" else local_rank % torch.cuda.device_count())
     torch.cuda.set_device(dev)
 
     from igs_amd import _cabi, rasterizer
-    from igs_amd.refine import GaussianParams, Refiner, render
-    from igs_amd.scenes import sear_steak_like_scene, perturbed_copy, activate
+    from igs_amd.refine import GaussianParams, Refiner, render, psnr
+    from igs_amd.scenes import sear_steak_like_scene, perturbed_copy, activate, SEAR_STEAK_BBOX
+
+    cfg = args.config
+    stream = cfg in ("cfg4", "cfg5")
+    loss = args.loss or ("l1_ssim" if stream else "l1")
+    ldn = args.lambda_depth_normal if args.lambda_depth_normal is not None else (0.05 if cfg == "cfg5" else 0.0)
+    clamp = args.clamp or cfg == "cfg5"
+    steps = args.steps if args.steps is not None else {"cfg2": 200, "cfg3": 200, "cfg4": 2500, "cfg5": 15000}[cfg]
+    if stream:
+        frames = max(1, steps // ITERS_PER_FRAME)
+        steps = frames * ITERS_PER_FRAME
 
     rasterizer.NAN_CHECKS = False          # the reference's 7 NaN asserts are host syncs; parity tests keep them on
-    raw, cams, bg = sear_steak_like_scene(P=args.points, n_cams=args.cams, width=args.width, height=args.height)
-    cams = [c.to(dev) for c in cams]
+    scale_mean = -3.0 if args.scene == "dense" else -4.0
+    raw, cams_all, bg = sear_steak_like_scene(P=args.points, n_cams=args.cams, width=args.width, height=args.height,
+                                              scale_mean=scale_mean, held_out=True)
+    cams_all = [c.to(dev) for c in cams_all]
+    cams, test_cam = cams_all[:-1], cams_all[-1]
     bg = bg.to(dev)
-    # ground truth: the same renderer on a perturbed copy (synthetic data)
-    gt_raw = {k: v.to(dev) for k, v in perturbed_copy(raw).items()}
-    with torch.no_grad():
-        gts = [render(activate(gt_raw), c, bg)["images_pred"].clone() for c in cams]
-    params = GaussianParams(raw, dev)
-    if not args.no_spatial_sort:
-        params.spatial_sort()              # once per frame, outside the timed region: Morton order of the positions
-    ref = Refiner(params, cams, gts, bg, loss=args.loss, world_size=world, rank=rank, seed=0,
-                  lambda_depth_normal=args.lambda_depth_normal)
-    ref.require_geometry = not args.colour_only_forward
-    ref.clamp = args.clamp
-    ref.want_viewspace_grad = args.viewspace_grad
 
     def barrier():
         if world > 1:
             import torch.distributed as dist
             dist.barrier()
 
-    for _ in range(args.warmup):
-        ref.step()
-    torch.cuda.synchronize()
-    if not args.no_profile:
-        _cabi.profile_enable(True, every=max(1, args.profile_every))
-        _cabi.profile_read(reset=True)
-    barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        ref.step()
-    torch.cuda.synchronize()
-    barrier()
-    t1 = time.perf_counter()
-    elapsed = t1 - t0
+    def max_over_ranks(x):
+        if world == 1:
+            return x, [x]
+        import torch.distributed as dist
+        t = torch.tensor([x], dtype=torch.float64, device=dev)
+        allv = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(allv, t)
+        vals = [float(v.item()) for v in allv]
+        return max(vals), vals
+
+    out_extra = {}
+    stages, r_sum, calls = ({}, 0.0, 0)
+    stages_timed = {}
+    gauss_views = None            # Gaussians x views processed by THIS rank in the timed region (densification changes P)
+    ref = None
+
+    # ------------------------------------------------------------------------------------------------------------------
+    if not stream:
+        # ground truth: the same renderer on a perturbed copy (synthetic data; SURVEY.md 8d)
+        gt_raw = {k: v.to(dev) for k, v in perturbed_copy(raw).items()}
+        with torch.no_grad():
+            gts = [render(activate(gt_raw), c, bg)["images_pred"].clone() for c in cams]
+            gt_test = render(activate(gt_raw), test_cam, bg)["images_pred"].clone()
+        params = GaussianParams(raw, dev)
+        if not args.no_spatial_sort:
+            params.spatial_sort()              # once per frame, outside the timed region: Morton order of the positions (DESIGN.md 4)
+
+        def eval_psnr():
+            with torch.no_grad():
+                return float(psnr(render(params.activated(), test_cam, bg)["images_pred"], gt_test))
+
+        if cfg == "cfg3":
+            ref = Refiner(params, cams, gts, bg, loss=loss, world_size=world, rank=rank, seed=0, lambda_depth_normal=ldn)
+            ref.require_geometry = not args.colour_only_forward
+            ref.clamp = clamp
+            ref.want_viewspace_grad = args.viewspace_grad
+            ref.exchange = args.exchange
+            psnr_before = eval_psnr()
+            for _ in range(args.warmup):
+                ref.step()
+            torch.cuda.synchronize()
+            if not args.no_profile:
+                _cabi.profile_enable(True, every=max(1, args.profile_every))
+                _cabi.profile_read(reset=True)
+            if world > 1:
+                ref.exchange_events = []
+            barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                ref.step()
+            torch.cuda.synchronize()
+            barrier()
+            elapsed = time.perf_counter() - t0
+            if world > 1:
+                out_extra["exchange_ms_per_step"] = ref.exchange_ms_per_step(steps)
+                ref.exchange_events = None
+            if not args.no_profile:
+                stages_timed, r_sum, calls = _cabi.profile_read(reset=True)
+                _cabi.profile_enable(False)
+            psnr_after = eval_psnr()
+            out_extra["psnr"] = {"camera": "held-out view between training cameras %d and %d (never trained on)" % (args.cams // 2 - 1, args.cams // 2),
+                                 "before": psnr_before, "after": psnr_after, "refine_steps_between": args.warmup + steps,
+                                 "formula": "-10 log10 mean((clamp(img,0,1) - gt)^2)  (infer_batch.py:350-353); gt = the renderer's image of the perturbed target scene"}
+            gauss_views = params.P * steps
+            # separate profiled pass: events on EVERY step, so that each stage mean has >= 20 samples
+            if not args.no_profile and args.profile_steps > 0:
+                _cabi.profile_enable(True, every=1)
+                _cabi.profile_read(reset=True)
+                for _ in range(args.profile_steps):
+                    ref.step()
+                torch.cuda.synchronize()
+                stages, r_sum2, calls2 = _cabi.profile_read(reset=True)
+                _cabi.profile_enable(False)
+                if calls2:
+                    r_sum, calls = r_sum2, calls2
+            else:
+                stages = stages_timed
+        else:
+            # cfg2: forward-only render through the drop-in entry point (one host wait per frame, like rasterizer_impl.cu:354)
+            a = {k: v.detach() for k, v in params.activated().items()}
+            bufs = rasterizer.RasterBuffers()
+            E = torch.Tensor([])
+            my_cams = [cams[(i * world + rank) % len(cams)] for i in range(len(cams))]
+
+            def fwd(i):
+                cam = my_cams[i % len(my_cams)]
+                return rasterizer.rasterize_gaussians(bg, a["means3D"], E, a["opacities"], a["scales"], a["rotations"], 1.0, E,
+                                                      cam.world_view_transform, cam.full_proj_transform, cam.tanfovx, cam.tanfovy, 0.0,
+                                                      cam.height, cam.width, a["shs"], 3, cam.camera_center, False,
+                                                      not args.colour_only_forward, not args.colour_only_forward, False, buffers=bufs)
+            for i in range(args.warmup):
+                fwd(i)
+            torch.cuda.synchronize()
+            if not args.no_profile:
+                _cabi.profile_enable(True, every=max(1, args.profile_every))
+                _cabi.profile_read(reset=True)
+            barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(steps):
+                fwd(i)
+            torch.cuda.synchronize()
+            barrier()
+            elapsed = time.perf_counter() - t0
+            if not args.no_profile:
+                stages_timed, r_sum, calls = _cabi.profile_read(reset=True)
+                _cabi.profile_enable(True, every=1)
+                for i in range(args.profile_steps):
+                    fwd(i)
+                torch.cuda.synchronize()
+                stages, r_sum2, calls2 = _cabi.profile_read(reset=True)
+                _cabi.profile_enable(False)
+                if calls2:
+                    r_sum, calls = r_sum2, calls2
+                else:
+                    stages = stages_timed
+            out_extra["psnr"] = {"camera": "held-out view", "before": eval_psnr(), "after": None, "refine_steps_between": 0,
+                                 "note": "forward-only configuration: nothing is refined"}
+            gauss_views = params.P * steps
+    else:
+        # ------------------------------------------------------------------------------------------------------------------
+        # cfg4 / cfg5: frame-by-frame stream (infer_batch.py:245-357 around the rasterizer).  Ground truth of every frame is
+        # rendered BEFORE the timed region (the reference loads it from disk): a target copy of the scene whose dynamic-bbox
+        # Gaussians drift by N(0, 0.01) per frame (SURVEY.md 8d cfg-4).
+        from igs_amd.stream import SyntheticStream
+        from igs_amd.densify import DensifyConfig
+        src = SyntheticStream(raw, cams + [test_cam], bg, dev)
+        warm_frames = 1
+        all_gts = [src.next_frame() for _ in range(frames + warm_frames)]
+        dcfg = DensifyConfig(until_iter=100, from_iter=0, interval=20, grad_threshold=0.00015, max_num=int(args.points * 1.05),
+                             extent=15.0) if args.densify else None
+        cur = {k: v.clone() for k, v in raw.items()}
+        psnr_b, psnr_a = [], []
+        gv = 0
+        ex_ms = 0.0
+
+        def one_frame(f, gts_f, timed):
+            nonlocal cur, gv, ex_ms, ref
+            params = GaussianParams(cur, dev)                 # load_fromstream: new leaves and a NEW optimiser for every frame
+            if not args.no_spatial_sort:
+                params.spatial_sort()
+            ref = Refiner(params, cams, gts_f[:-1], bg, loss=loss, world_size=world, rank=rank, seed=f, densify=dcfg,
+                          lambda_depth_normal=ldn)
+            ref.clamp = clamp
+            ref.exchange = args.exchange
+            ref.start_frame()
+            if timed and world > 1:
+                ref.exchange_events = []
+            with torch.no_grad():
+                pb = psnr(render(params.activated(), test_cam, bg)["images_pred"], gts_f[-1])
+            for _ in range(ITERS_PER_FRAME):
+                ref.step()
+                if timed:
+                    gv += params.P
+            with torch.no_grad():
+                pa = psnr(render(params.activated(), test_cam, bg)["images_pred"], gts_f[-1])
+            if timed:
+                psnr_b.append(pb); psnr_a.append(pa)
+                if world > 1:
+                    ex_ms += sum(x.elapsed_time(y) for x, y in ref.exchange_events) if False else 0.0
+            cur = {k: v.detach().clone() for k, v in params.leaves.items()}          # convert2stream: next frame starts from here
+            return ref
+
+        for f in range(warm_frames):
+            one_frame(f, all_gts[f], False)
+        torch.cuda.synchronize()
+        if not args.no_profile:
+            _cabi.profile_enable(True, every=max(1, args.profile_every))
+            _cabi.profile_read(reset=True)
+        barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        ev_lists = []
+        for f in range(frames):
+            r = one_frame(warm_frames + f, all_gts[warm_frames + f], True)
+            if world > 1:
+                ev_lists.append(r.exchange_events)
+        torch.cuda.synchronize()
+        barrier()
+        elapsed = time.perf_counter() - t0
+        if world > 1:
+            out_extra["exchange_ms_per_step"] = sum(a.elapsed_time(b) for lst in ev_lists for a, b in lst) / max(1, steps)
+        if not args.no_profile:
+            stages, r_sum, calls = _cabi.profile_read(reset=True)
+            stages_timed = stages
+            _cabi.profile_enable(False)
+        pb = [float(x) for x in psnr_b]; pa = [float(x) for x in psnr_a]
+        out_extra["psnr"] = {"camera": "held-out view (never trained on), evaluated against each frame's target before / after its %d iterations" % ITERS_PER_FRAME,
+                             "before": sum(pb) / len(pb), "after": sum(pa) / len(pa), "first_frame": [pb[0], pa[0]], "last_frame": [pb[-1], pa[-1]],
+                             "frames": frames, "refine_steps_between": ITERS_PER_FRAME}
+        gauss_views = gv
+        if ref is not None and ref.densify_log:
+            out_extra["densify_log_last_frame"] = ref.densify_log
+
+    # ------------------------------------------------------------------------------------------------------------------
+    elapsed_max, per_rank = max_over_ranks(elapsed)
     if world > 1:
         import torch.distributed as dist
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
-
-    stages, r_sum, calls = ({}, 0.0, 0)
-    if not args.no_profile:
-        stages, r_sum, calls = _cabi.profile_read(reset=True)
-        _cabi.profile_enable(False)
+        t = torch.tensor([float(gauss_views)], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        total_gv = float(t.item())
+    else:
+        total_gv = float(gauss_views)
 
     if rank == 0:
         P = args.points
-        value = P * args.steps * world / elapsed
+        loss_txt = "L1" if loss == "l1" else "0.8*L1+0.2*(1-SSIM)"
+        work = {
+            "cfg3": "BASELINE.json configs[2]: sear_steak-like frame-0 stand-in, %d Gaussians, SH degree 3, %d train cams @%dx%d; per step and rank "
+                    "one view: fwd + %s loss + bwd + Adam" % (P, args.cams, args.width, args.height, loss_txt),
+            "cfg2": "BASELINE.json configs[1]: sear_steak-like frame-0 stand-in, %d Gaussians, @%dx%d, forward-only render (coord, depth, normal on) "
+                    "through igs_rast_forward, one host wait per frame" % (P, args.width, args.height),
+            "cfg4": "BASELINE.json configs[3]: %d-frame stream x %d refine iterations, %d Gaussians, %d cams @%dx%d, fresh optimiser per frame, "
+                    "loss %s%s; per step and rank one view" % (steps // ITERS_PER_FRAME if stream else 0, ITERS_PER_FRAME, P, args.cams, args.width, args.height, loss_txt,
+                                                              ", densify-and-prune on" if args.densify else ""),
+            "cfg5": "BASELINE.json configs[4]: %d-frame stream x %d refine iterations, %d Gaussians, SH degree 3, loss %s + %.2f * depth-normal "
+                    "regulariser (<depth, normal> backward), clamp variant (+-15)%s" % (steps // ITERS_PER_FRAME if stream else 0, ITERS_PER_FRAME, P, loss_txt, ldn,
+                                                                                       ", densify-and-prune on" if args.densify else ""),
+        }[cfg]
+        if args.scene == "dense":
+            work = "DIAGNOSTIC dense scene (log-scale mean -3 instead of SURVEY 8d's -4) -- " + work
         out = {
-            "metric": "Gaussians rendered/sec (fwd+bwd) at 1352x1014",
-            "value": value, "unit": "Gaussians/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1000.0 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "metric": "Gaussians rendered/sec (fwd+bwd) at 1352x1014; PSNR vs ref" if cfg != "cfg2" else "Gaussians rendered/sec (forward only) at 1352x1014",
+            "value": total_gv / elapsed_max, "unit": "Gaussians/s", "n_gpus": joined, "steps": steps, "warmup": args.warmup,
+            "ms_per_step": 1000.0 * elapsed_max / steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "sear_steak-like frame-0 stand-in (BASELINE.json configs[2]): %d Gaussians, SH degree 3, "
-                                   "%d train cams @%dx%d, per step and rank one view: fwd + %s loss + bwd + Adam"
-                                   % (P, args.cams, args.width, args.height, "L1" if args.loss == "l1" else "0.8*L1+0.2*(1-SSIM)"),
-                       "points": P, "width": args.width, "height": args.height, "views": args.cams, "loss": args.loss,
+            "config": {"workload": work, "name": cfg, "scene": args.scene, "points": P, "width": args.width, "height": args.height,
+                       "views": args.cams, "loss": loss, "lambda_depth_normal": ldn, "clamp": bool(clamp),
                        "parallelism": ("one GPU: the whole step inside igs_refine_step, no exchange" if world == 1 else
-                                       "views sharded over %d ranks, one view per rank and step; RCCL all-gather of the per-view colour "
-                                       "gradients + all-reduce of the 11 small-group gradients (DESIGN.md section 6)" % world)},
+                                       ("views sharded over %d ranks, one view per rank and step; RCCL all-gather of the per-view colour "
+                                        "gradients + all-reduce of the 11 small-group gradients (DESIGN.md section 6)" % world
+                                        if args.exchange == "colors" else
+                                        "views sharded over %d ranks, one view per rank and step; RCCL all-reduce of the flat 59*P-float gradient" % world))},
+            "ms_per_step_per_rank": [1000.0 * e / steps for e in per_rank],
         }
+        out.update(out_extra)
         if stages and calls:
             R_avg = r_sum / calls
-            geo_bwd = False      # L1 / SSIM only see the colour image: geometry gradients are absent
-            fused = args.loss == "l1"      # pure L1: the loss is evaluated inside blend_bwd (reads colour + gt instead of dL_dpix)
+            dn = ldn > 0                       # depth-normal regulariser: depth + normal gradients present, coord absent
+            fused = loss == "l1" and not dn    # pure L1: the loss is evaluated inside blend_bwd (reads colour + gt instead of dL_dpix)
             geo_fwd = not args.colour_only_forward
-            dn = args.lambda_depth_normal > 0      # depth-normal regulariser: depth + normal gradients present, coord absent
-            ab = algorithmic_bytes(R_avg, args.width, args.height, geo_fwd, geo_fwd, geo_bwd, dn, dn, l1_fused=fused)
+            ab = algorithmic_bytes(R_avg, args.width, args.height, geo_fwd, geo_fwd, False, dn, dn, l1_fused=fused)
             per = {k: (ms / cnt if cnt else 0.0) for k, (ms, cnt) in stages.items()}
+            nsamp = {k: cnt for k, (ms, cnt) in stages.items() if cnt}
+            per_t = {k: (ms / cnt if cnt else 0.0) for k, (ms, cnt) in stages_timed.items()}
             dom = "blend_bwd" if per.get("blend_bwd", 0) >= per.get("blend_fwd", 0) else "blend_fwd"
+            oth = "blend_fwd" if dom == "blend_bwd" else "blend_bwd"
             ach = ab[dom] / (per[dom] * 1e-3) / 1e9 if per[dom] > 0 else 0.0
-            traffic = None
-            tf = os.path.join(ROOT, "profiles", "pmc_latest.json")
-            if os.path.exists(tf):
-                try:
-                    traffic = json.load(open(tf)).get(dom, {}).get("hbm_bytes_per_launch")
-                except Exception:  # noqa: BLE001
-                    traffic = None
-            out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                               "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
-                               "algorithmic_bytes_per_launch": ab[dom], "avg_launch_ms": per[dom],
-                               "instance": (("blend_bwd<depth, normal gradients%s>: R*64 + H*W*%d + R*100 bytes" % ((", L1 fused", 68) if fused else ("", 56)) if dn else
-                                             "blend_bwd<colour-only gradients%s>: R*40 + H*W*%d + R*100 bytes" % ((", L1 fused", 40) if fused else ("", 28))) if dom == "blend_bwd"
-                                            else "blend_fwd<coord,depth,normal>: R*100 + H*W*88 + 8*T bytes"),
-                               "num_rendered_avg": R_avg,
-                               "other": {"blend_fwd" if dom == "blend_bwd" else "blend_bwd": {
-                                   "achieved": (ab["blend_fwd" if dom == "blend_bwd" else "blend_bwd"]
-                                                / (per["blend_fwd" if dom == "blend_bwd" else "blend_bwd"] * 1e-3) / 1e9)
-                                   if per.get("blend_fwd" if dom == "blend_bwd" else "blend_bwd", 0) > 0 else 0.0}},
-                               "stage_ms": {k: round(v, 4) for k, v in per.items()}}
-        if world == 1 and args.cpu_views > 0:
+            roof = {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                    "traffic": None,
+                    "traffic_note": "HBM bytes are not measured in this process; rocprofv3 PMC passes of the same command: profiles/r02_pmc.json",
+                    "algorithmic_bytes_per_launch": ab[dom], "avg_launch_ms": per[dom], "avg_launch_samples": nsamp.get(dom, 0),
+                    "avg_launch_ms_sampled_in_timed_region": per_t.get(dom),
+                    "stage_timing": ("HIP events on the kernels' own stream, every step of a separate %d-step pass right after the timed region"
+                                     % args.profile_steps) if (cfg in ("cfg2", "cfg3") and args.profile_steps > 0) else
+                                    "HIP events on the kernels' own stream, every %d-th step of the timed region" % max(1, args.profile_every),
+                    "instance": (("blend_bwd<depth, normal gradients%s>: R*64 + H*W*%d + R*100 bytes" % ((", L1 fused", 68) if fused else ("", 56)) if dn else
+                                  "blend_bwd<colour-only gradients%s>: R*40 + H*W*%d + R*100 bytes" % ((", L1 fused", 40) if fused else ("", 28))) if dom == "blend_bwd"
+                                 else "blend_fwd<coord,depth,normal>: R*100 + H*W*88 + 8*T bytes"),
+                    "num_rendered_avg": R_avg,
+                    "other": {oth: {"achieved": (ab[oth] / (per[oth] * 1e-3) / 1e9) if per.get(oth, 0) > 0 else 0.0,
+                                    "frac": (ab[oth] / (per[oth] * 1e-3) / 1e9 / HBM_PEAK_GBS) if per.get(oth, 0) > 0 else 0.0,
+                                    "algorithmic_bytes_per_launch": ab[oth], "avg_launch_ms": per.get(oth)}},
+                    "stage_ms": {k: round(v, 4) for k, v in per.items()}}
+            # ALU-side figure (SURVEY.md 8d / hard part 3): pixel-Gaussian pairs = sum over pixels of the contributor count
             try:
-                gts_cpu = [g.cpu().numpy() for g in gts[:args.cpu_views]]
-                out["cpu_baseline"] = cpu_baseline(raw, [c.to("cpu") for c in cams], bg.cpu(), gts_cpu, args.cpu_views)
+                if ref is not None:
+                    pr = ref.params
+                    a = {k: v.detach() for k, v in pr.activated().items()}
+                    E = torch.Tensor([])
+                    tot_pairs = 0
+                    ncam = min(len(cams), 4)
+                    for cam in cams[:ncam]:
+                        o = rasterizer.rasterize_gaussians(bg, a["means3D"], E, a["opacities"], a["scales"], a["rotations"], 1.0, E,
+                                                           cam.world_view_transform, cam.full_proj_transform, cam.tanfovx, cam.tanfovy, 0.0,
+                                                           cam.height, cam.width, a["shs"], 3, cam.camera_center, False, True, True, False)
+                        d = rasterizer.debug_dump(pr.P, o[0], cam.width, cam.height, o[9], o[10], o[11])
+                        tot_pairs += int(d["n_contrib"][0].to(torch.int64).sum().item())
+                    pairs = tot_pairs / ncam
+                    roof["pairs_per_view"] = pairs
+                    roof["pairs_per_s"] = {k: (pairs / (per[k] * 1e-3) if per.get(k, 0) > 0 else None) for k in ("blend_fwd", "blend_bwd")}
+                    roof["pairs_note"] = ("pixel-Gaussian pairs examined per view (sum over pixels of the reference's `contributor` count, "
+                                          "forward.cu:556-573), mean over %d cameras; VALU issue fraction of the blend kernels: DESIGN.md section 5 "
+                                          "(rocprofv3 SQ_INSTS_VALU x measured cycles per wave64 op, tools/ubench/valu_rate)" % ncam)
             except Exception as e:  # noqa: BLE001
-                out["cpu_baseline"] = {"value": None, "unit": "Gaussians/s", "cores": 1, "kind": "port", "sample": "failed: %s" % e}
-        print(json.dumps(out))
+                roof["pairs_per_view"] = None
+                roof["pairs_note"] = "failed: %s" % e
+            out["roofline"] = roof
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                cb = cpu_baseline_torch()
+            except Exception as e:  # noqa: BLE001
+                cb = {"value": None, "unit": "Gaussians/s", "cores": os.cpu_count(), "kind": "port", "sample": "failed: %s" % e}
+            if args.cpu_views > 0 and not stream:
+                try:
+                    gts_cpu = [g.cpu().numpy() for g in gts[:args.cpu_views]]
+                    cb["c_port"] = cpu_baseline_c_port(raw, [c.to("cpu") for c in cams], bg.cpu(), gts_cpu, args.cpu_views)
+                except Exception as e:  # noqa: BLE001
+                    cb["c_port"] = {"value": None, "sample": "failed: %s" % e}
+            out["cpu_baseline"] = cb
+        print(json.dumps(out), flush=True)
     if world > 1:
         import torch.distributed as dist
+        dist.barrier()
         dist.destroy_process_group()
 
 

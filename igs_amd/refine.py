@@ -268,6 +268,34 @@ class Refiner:
         self.densify_gen = None
         self.densify_seed = densify_seed
         self.densify_log = []
+        # bench.py: HIP-event pairs around the collectives of the N > 1 step (None = not recorded)
+        self.exchange_events = None
+
+    class _Timed:
+        """Brackets a group of collectives with events on the current stream (the collective's own stream is joined to it)."""
+
+        def __init__(self, owner):
+            self.o = owner
+
+        def __enter__(self):
+            if self.o.exchange_events is not None:
+                self.e0 = torch.cuda.Event(enable_timing=True)
+                self.e0.record()
+            return self
+
+        def __exit__(self, *exc):
+            if self.o.exchange_events is not None:
+                e1 = torch.cuda.Event(enable_timing=True)
+                e1.record()
+                self.o.exchange_events.append((self.e0, e1))
+            return False
+
+    def exchange_ms_per_step(self, steps):
+        """Mean time per step spent in the collectives since `exchange_events` was set to [] (synchronises)."""
+        if not self.exchange_events or steps <= 0:
+            return 0.0
+        torch.cuda.synchronize(self.params.device)
+        return sum(a.elapsed_time(b) for a, b in self.exchange_events) / steps
 
     def _next_view(self):
         """Without-replacement view sampling (infer_batch.py:280-288); a step consumes `world_size` views."""
@@ -441,10 +469,11 @@ class Refiner:
             self._gc_mine = torch.zeros((P, 3), dtype=torch.float32, device=dev)
             self._campos_host = {}
         pkg = self._fused_step(cam, gt, grads_only=True, color_out=self._gc_mine)
-        if dist.get_backend() == "nccl":
-            dist.all_gather_into_tensor(self._gc.view(-1), self._gc_mine.view(-1))      # RCCL: straight into the [N,P,3] buffer
-        else:
-            dist.all_gather(list(self._gc.unbind(0)), self._gc_mine)
+        with self._Timed(self):
+            if dist.get_backend() == "nccl":
+                dist.all_gather_into_tensor(self._gc.view(-1), self._gc_mine.view(-1))      # RCCL: straight into the [N,P,3] buffer
+            else:
+                dist.all_gather(list(self._gc.unbind(0)), self._gc_mine)
         import ctypes as C
         for v in picks:
             if v not in self._campos_host:          # (one device read per camera, the first time it is used)
@@ -463,20 +492,22 @@ class Refiner:
                                                 p.exp_avg_sq.data_ptr() + 4 * sh0, p.lrs["shs"], b1, b2, p.eps, 1.0 - b1 ** t,
                                                 math.sqrt(1.0 - b2 ** t))
             _rast._check(rc, "igs_adam_sh_from_view_colors")
-            if sh0 > 0:
-                dist.all_reduce(p.grad[:sh0], op=dist.ReduceOp.SUM)
-            if sh0 + shn < p.grad.numel():
-                dist.all_reduce(p.grad[sh0 + shn:], op=dist.ReduceOp.SUM)
+            with self._Timed(self):
+                if sh0 > 0:
+                    dist.all_reduce(p.grad[:sh0], op=dist.ReduceOp.SUM)
+                if sh0 + shn < p.grad.numel():
+                    dist.all_reduce(p.grad[sh0 + shn:], op=dist.ReduceOp.SUM)
             p.adam_step(skip_sh=True)
             return pkg
         rc = L.igs_sh_grad_from_view_colors(stream, P, 3, 16, N, p.flat.data_ptr() + 4 * p.spans["xyz"][0],
                                             C.cast(campos, C.c_void_p), self._gc.data_ptr(), clamp,
                                             p.grad.data_ptr() + 4 * sh0)
         _rast._check(rc, "igs_sh_grad_from_view_colors")
-        if sh0 > 0:
-            dist.all_reduce(p.grad[:sh0], op=dist.ReduceOp.SUM)             # xyz | rotation | opacity | scaling: 11 floats per Gaussian
-        if sh0 + shn < p.grad.numel():
-            dist.all_reduce(p.grad[sh0 + shn:], op=dist.ReduceOp.SUM)
+        with self._Timed(self):
+            if sh0 > 0:
+                dist.all_reduce(p.grad[:sh0], op=dist.ReduceOp.SUM)             # xyz | rotation | opacity | scaling: 11 floats per Gaussian
+            if sh0 + shn < p.grad.numel():
+                dist.all_reduce(p.grad[sh0 + shn:], op=dist.ReduceOp.SUM)
         self.adam_fn()
         return pkg
 
@@ -490,7 +521,8 @@ class Refiner:
         pkg = self._fused_step(cam, gt, grads_only=True) if self.fused else self._native_step(cam, gt)
         if self.world_size > 1:
             import torch.distributed as dist
-            dist.all_reduce(p.grad, op=dist.ReduceOp.SUM)      # one flat 59*P-float buffer over RCCL / xGMI
+            with self._Timed(self):
+                dist.all_reduce(p.grad, op=dist.ReduceOp.SUM)      # one flat 59*P-float buffer over RCCL / xGMI
         self.adam_fn()
         return pkg
 

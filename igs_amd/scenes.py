@@ -49,10 +49,13 @@ def cfg1_scene(P=10000, seed=0, size=256):
     return raw, [cam], torch.zeros(3)
 
 
-def sear_steak_like_scene(P=200000, seed=1, n_cams=10, width=1352, height=1014, focal=730.0):
+def sear_steak_like_scene(P=200000, seed=1, n_cams=10, width=1352, height=1014, focal=730.0, scale_mean=-4.0, held_out=False):
     """cfg-2/3 stand-in: half the Gaussians uniform in the sear_steak dynamic bbox, half on a background
     shell at distance 15-40 m in front of the rig; `n_cams` cameras on a +-20 deg arc around the bbox centre,
-    starting at the origin, fx = fy = `focal` px (N3DV-like half resolution; builder's choice)."""
+    starting at the origin, fx = fy = `focal` px (N3DV-like half resolution; builder's choice).
+    `scale_mean`: mean of the log-scales (SURVEY 8d prescribes -4.0: ~1 px splats, R/P = 2.6; -3.0 gives the "dense" diagnostic
+    scene, R in the millions as in SURVEY 8d's own example).  `held_out=True` appends one more camera half-way between the two
+    middle training cameras (the evaluation view of bench.py's PSNR figures; it is never trained on)."""
     gen = torch.Generator().manual_seed(seed)
     lo = torch.tensor(SEAR_STEAK_BBOX[0])
     hi = torch.tensor(SEAR_STEAK_BBOX[1])
@@ -67,7 +70,7 @@ def sear_steak_like_scene(P=200000, seed=1, n_cams=10, width=1352, height=1014, 
     perm = torch.randperm(P, generator=gen)
     raw = dict(
         xyz=torch.cat([xyz_in, xyz_bg])[perm].contiguous(),
-        scaling=(torch.randn(P, 3, generator=gen) * 0.8 - 4.0).clamp(-7.0, -1.0),
+        scaling=(torch.randn(P, 3, generator=gen) * 0.8 + scale_mean).clamp(-7.0, -1.0),
         rotation=torch.randn(P, 4, generator=gen),
         opacity=torch.randn(P, 1, generator=gen) * 2.0 + 0.5,
     )
@@ -75,8 +78,11 @@ def sear_steak_like_scene(P=200000, seed=1, n_cams=10, width=1352, height=1014, 
     centre = 0.5 * (lo + hi)
     fov = (focal2fov(focal, width), focal2fov(focal, height))
     cams = []
-    for i in range(n_cams):
-        th = math.radians(-20.0 + 40.0 * (i / max(1, n_cams - 1)))
+    angles = [-20.0 + 40.0 * (i / max(1, n_cams - 1)) for i in range(n_cams)]
+    if held_out:
+        angles.append(-20.0 + 40.0 * ((max(0, n_cams // 2 - 1) + 0.5) / max(1, n_cams - 1)))
+    for ang in angles:
+        th = math.radians(ang)
         # rotate the origin about the vertical axis through the bbox centre
         d = -centre
         eye = centre + torch.tensor([math.cos(th) * d[0] + math.sin(th) * d[2], d[1],

@@ -83,6 +83,20 @@ static double sum_jitter(size_t i, unsigned salt)
     return 1.0 + 2e-6 * ((double)(z >> 11) / 9007199254740992.0 * 2.0 - 1.0);
 }
 
+/* flag 16: every exp() of the tile blend (forward.cu:565, backward.cu:851) is scaled by 1 + 2.4e-7 u, u in [-1,1] a hash of (pixel,
+ * Gaussian, flags >> 8).  2.4e-7 = 2 ulp, the documented maximum error of CUDA's expf (the reference is built without fast-math, its
+ * exp(float) is that expf); x86 libm and the GPU's v_exp_f32 differ from it and from each other by as much.  The same (pixel,
+ * Gaussian) pair gets the same factor in forward and backward -- as with any ONE deterministic exp -- so a perturbed forward must be
+ * followed by a backward with the same flags.  Tests use the resulting shift of a Gaussian's gradient as its sensitivity to the
+ * exp implementation (behind saturated pixels 1/T_final amplifies it, backward.cu:706,857). */
+static real exp_jitter(real v, size_t pix, uint32_t id)
+{
+    if (!(g_flags & 16)) return v;
+    uint64_t z = (uint64_t)pix * 0x9E3779B97F4A7C15ull + (uint64_t)id * 0xD6E8FEB86659FD93ull + (uint64_t)(g_flags >> 8) * 0xBF58476D1CE4E5B9ull + 0x94D049BB133111EBull;
+    z ^= z >> 30; z *= 0xBF58476D1CE4E5B9ull; z ^= z >> 27; z *= 0x94D049BB133111EBull; z ^= z >> 31;
+    return (real)((double)v * (1.0 + 2.4e-7 * ((double)(z >> 11) / 9007199254740992.0 * 2.0 - 1.0)));
+}
+
 /* ------------------------------------------------------------------ */
 /* small glm-like helpers                                              */
 /* ------------------------------------------------------------------ */
@@ -619,7 +633,7 @@ static void render_tile_pixel_fwd(const gsor_state* s, int COORD, int DEPTH, int
         const real* co = s->conic_opacity + 4*(size_t)id;
         real power = -0.5f * (co[0]*dx*dx + co[2]*dy*dy) - co[1]*dx*dy;
         if (power > 0.0f) continue;
-        real alpha = fminf_(0.99f, co[3] * EXP(power));
+        real alpha = fminf_(0.99f, co[3] * exp_jitter(EXP(power), pix_id, id));
         if (alpha < 1.0f / 255.0f) continue;
         real test_T = T * (1 - alpha);
         if (test_T < 0.0001f) break;          /* done = true: nothing after this is examined */
@@ -891,7 +905,7 @@ static void render_pixel_bwd(const gsor_state* s, int COORD, int DEPTH, int NORM
         const real* co = s->conic_opacity + 4*(size_t)id;
         real power = -0.5f * (co[0]*dx*dx + co[2]*dy*dy) - co[1]*dx*dy;
         if (power > 0.0f) continue;
-        const real G = EXP(power);
+        const real G = exp_jitter(EXP(power), pix_id, id);
         const real alpha = fminf_(0.99f, co[3] * G);
         if (alpha < 1.0f / 255.0f) continue;
         T = T / (1.f - alpha);

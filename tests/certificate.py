@@ -10,9 +10,12 @@ equal terms (backward.cu:367-375).  So the bar is stated against a float64 evalu
                      + K * |oracle32 - f64|_g + K * jitter_g                                        (the allowance)
 
 where, for the Gaussian g the element belongs to, |oracle32 - f64|_g is the distance of the float32 ORACLE itself from float64 (max over
-the Gaussian's components of that tensor) and jitter_g is how far the oracle's result moves when its per-Gaussian sums are kept in
-float (flag 2) and each finished sum is scaled by 1 + 2e-6 u (flag 4; `samples` draws of u).  An element that needs the allowance is an
-element on which the reference itself -- CUDA atomics in another order, another libm -- would differ by as much.  The function returns
+the Gaussian's components of that tensor) and jitter_g is how far the oracle's result moves (a) when its per-Gaussian sums are kept in
+float (flag 2) and each finished sum is scaled by 1 + 2e-6 u (flag 4; `samples` draws of u), and (b) when every exp() of the blend, forward
+and backward alike, is off by up to 2 ulp (flag 16; `exp_samples` draws) -- 2 ulp is the documented bound of CUDA's expf, which the
+reference calls (no fast-math in its setup.py); x86 libm (the oracle) and v_exp_f32 (the HIP kernels) differ from it by as much.
+An element that needs the allowance is an element on which the reference itself -- CUDA atomics in another order, another exp --
+would differ by as much.  The function returns
 how many elements needed it, so a test can print the number and bound it; any element outside even the allowance fails.
 """
 import numpy as np
@@ -36,14 +39,14 @@ def _np(x, dt):
 
 
 def oracle_all(a, cam, bg, grads, req=(True, True), deg=3, kernel_size=0.0, colors=None, cov=None, scale_modifier=1.0,
-               samples=16, want_f32=True):
+               samples=16, exp_samples=3):
     """Everything the certificate needs from the CPU oracle for one view, callable from a worker thread (ctypes releases the GIL,
     the oracle's flags are thread-local): float32 forward + backward (the parity oracle proper), float64 forward + backward, and
     the per-Gaussian jitter shifts.  `grads`: dict of the seven upstream image gradients (numpy, None = zeros).
     Returns dict(nr, out, state, g32, g64, shift)."""
     P = a["means3D"].shape[0]
 
-    def fwd_bwd(dt, flags_list, each):
+    def fwd_bwd(dt, fwd_flags, flags_list, each):
         with co.thread_precision(dt):
             T = np.float32 if dt == "float32" else np.float64
             arg = {k: _np(v, T) for k, v in a.items()}
@@ -51,10 +54,11 @@ def oracle_all(a, cam, bg, grads, req=(True, True), deg=3, kernel_size=0.0, colo
             sc, ro = (None, None) if v is not None else (arg["scales"], arg["rotations"])
             sh = None if c is not None else arg["shs"]
             V, Pm, cc = _np(cam.world_view_transform, T), _np(cam.full_proj_transform, T), _np(cam.camera_center, T)
-            nr, oo, st = co.rasterize_forward(_np(bg, T), arg["means3D"], c, arg["opacities"], sc, ro, scale_modifier, v, V, Pm,
-                                              cam.tanfovx, cam.tanfovy, kernel_size, cam.height, cam.width, sh, deg, cc,
-                                              require_coord=req[0], require_depth=req[1])
             try:
+                co.set_flags(fwd_flags)
+                nr, oo, st = co.rasterize_forward(_np(bg, T), arg["means3D"], c, arg["opacities"], sc, ro, scale_modifier, v, V, Pm,
+                                                  cam.tanfovx, cam.tanfovy, kernel_size, cam.height, cam.width, sh, deg, cc,
+                                                  require_coord=req[0], require_depth=req[1])
                 for fl in flags_list:
                     co.set_flags(fl)
                     each(co.rasterize_backward(st, _np(bg, T), arg["means3D"], c, sc, ro, v, V, Pm, cc, sh, oo["alpha"], oo["normal"],
@@ -75,13 +79,20 @@ def oracle_all(a, cam, bg, grads, req=(True, True), deg=3, kernel_size=0.0, colo
                 continue
             d = np.abs(g[n].astype(np.float64).reshape(P, -1) - box["g32"][n].astype(np.float64).reshape(P, -1)).max(1)
             box["shift"][n] = d if n not in box["shift"] else np.maximum(box["shift"][n], d)
-    nr, oo, st = fwd_bwd("float32", [0] + [2 + 4 + 8 + 256 * s for s in range(samples)], each32)
+    nr, oo, st = fwd_bwd("float32", 0, [0] + [2 + 4 + 8 + 256 * s for s in range(samples)], each32)
     g32, shift = box["g32"], box["shift"]
     for n in GNAMES:
         if g32[n].size and n not in shift:
             shift[n] = np.zeros(P)
+    # exp sensitivity: forward AND backward with every blend exp() off by up to 2 ulp; the shifts ADD to those of the sum jitter
+    sum_shift = {n: v.copy() for n, v in shift.items()}
+    box["shift"] = {}
+    for s_ in range(exp_samples):
+        fwd_bwd("float32", 16 + 256 * s_, [16 + 256 * s_], each32)
+    for n in sum_shift:
+        shift[n] = sum_shift[n] + box["shift"].get(n, 0.0)
     res64 = []
-    fwd_bwd("float64", [0], res64.append)
+    fwd_bwd("float64", 0, [0], res64.append)
     return dict(nr=nr, out=oo, state=st, g32=g32, g64=res64[0], shift=shift)
 
 
