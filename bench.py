@@ -43,6 +43,40 @@ HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 ITERS_PER_FRAME = 50       # configs/demo.yaml refine_iterations
 
 
+def usable_cores():
+    """Host cores this process may actually use: the smaller of os.cpu_count(), the affinity mask and the cgroup CPU quota (a GPU box
+    hands a one-GPU job a share of a many-core host; running one thread per HOST core on that share oversubscribes it badly)."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except Exception:  # noqa: BLE001
+        pass
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0])
+                per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if q > 0:
+                    n = min(n, max(1, q // per))
+            break
+        except Exception:  # noqa: BLE001
+            continue
+    return max(1, n)
+
+
+def log(msg):
+    """Progress on stderr (rank 0): a long run must show signs of life; the JSON line stays alone on stdout."""
+    if int(os.environ.get("RANK", "0")) == 0:
+        print("[bench %6.1fs] %s" % (time.perf_counter() - _T0, msg), file=sys.stderr, flush=True)
+
+
+_T0 = time.perf_counter()
+
+
 def algorithmic_bytes(R, W, H, coord=True, depth=True, bwd_coord=None, bwd_depth=None, bwd_normal=None, l1_fused=False):
     """per-launch algorithmic bytes of the two tile-blend kernels.
     forward : R*g + H*W*p + 8*T          g = 40 + 36[coord] + 12[depth] + 12[normal], p = 24 + 36[coord] + 12[depth] + 16[normal]
@@ -71,7 +105,7 @@ def cpu_baseline_torch(repeats=5):
     import torch
     from igs_amd.scenes import cfg1_scene, activate
     from oracle import torch_oracle as to
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     prev = torch.get_num_threads()
     torch.set_num_threads(cores)
     try:
@@ -97,7 +131,8 @@ def cpu_baseline_torch(repeats=5):
         torch.set_num_threads(prev)
     return dict(value=P / fb, unit="Gaussians/s", cores=cores, kind="port",
                 sample="BASELINE cfg-1 (10k Gaussians, 1 cam @256x256) forward + L1 + autograd backward on the pure-PyTorch restatement "
-                       "(oracle/torch_oracle.py), torch.set_num_threads(%d), median of %d after 1 warm-up: %.2f s per view" % (cores, repeats, fb),
+                       "(oracle/torch_oracle.py), torch.set_num_threads(%d) = the cores this job may use (os.cpu_count() = %d), median of %d "
+                       "after 1 warm-up: %.2f s per view" % (cores, os.cpu_count() or 1, repeats, fb),
                 forward_only_value=P / f, forward_only_s=f)
 
 
@@ -248,6 +283,7 @@ def main():
         vals = [float(v.item()) for v in allv]
         return max(vals), vals
 
+    log("config %s, scene %s, %d rank(s): scene built" % (cfg, args.scene, world))
     out_extra = {}
     stages, r_sum, calls = ({}, 0.0, 0)
     stages_timed = {}
@@ -292,6 +328,7 @@ def main():
             torch.cuda.synchronize()
             barrier()
             elapsed = time.perf_counter() - t0
+            log("timed region: %d steps, %.4f ms per step" % (steps, 1000.0 * elapsed / steps))
             if world > 1:
                 out_extra["exchange_ms_per_step"] = ref.exchange_ms_per_step(steps)
                 ref.exchange_events = None
@@ -343,6 +380,7 @@ def main():
             torch.cuda.synchronize()
             barrier()
             elapsed = time.perf_counter() - t0
+            log("timed region: %d forward renders, %.4f ms each" % (steps, 1000.0 * elapsed / steps))
             if not args.no_profile:
                 stages_timed, r_sum, calls = _cabi.profile_read(reset=True)
                 _cabi.profile_enable(True, every=1)
@@ -368,15 +406,15 @@ def main():
         src = SyntheticStream(raw, cams + [test_cam], bg, dev)
         warm_frames = 1
         all_gts = [src.next_frame() for _ in range(frames + warm_frames)]
+        log("ground truth of %d frames rendered" % len(all_gts))
         dcfg = DensifyConfig(until_iter=100, from_iter=0, interval=20, grad_threshold=0.00015, max_num=int(args.points * 1.05),
                              extent=15.0) if args.densify else None
         cur = {k: v.clone() for k, v in raw.items()}
         psnr_b, psnr_a = [], []
         gv = 0
-        ex_ms = 0.0
 
         def one_frame(f, gts_f, timed):
-            nonlocal cur, gv, ex_ms, ref
+            nonlocal cur, gv, ref
             params = GaussianParams(cur, dev)                 # load_fromstream: new leaves and a NEW optimiser for every frame
             if not args.no_spatial_sort:
                 params.spatial_sort()
@@ -397,8 +435,6 @@ def main():
                 pa = psnr(render(params.activated(), test_cam, bg)["images_pred"], gts_f[-1])
             if timed:
                 psnr_b.append(pb); psnr_a.append(pa)
-                if world > 1:
-                    ex_ms += sum(x.elapsed_time(y) for x, y in ref.exchange_events) if False else 0.0
             cur = {k: v.detach().clone() for k, v in params.leaves.items()}          # convert2stream: next frame starts from here
             return ref
 
@@ -419,6 +455,7 @@ def main():
         torch.cuda.synchronize()
         barrier()
         elapsed = time.perf_counter() - t0
+        log("timed region: %d frames x %d iterations, %.4f ms per step" % (frames, ITERS_PER_FRAME, 1000.0 * elapsed / steps))
         if world > 1:
             out_extra["exchange_ms_per_step"] = sum(a.elapsed_time(b) for lst in ev_lists for a, b in lst) / max(1, steps)
         if not args.no_profile:
@@ -528,8 +565,10 @@ def main():
                 roof["pairs_note"] = "failed: %s" % e
             out["roofline"] = roof
         if world == 1 and not args.no_cpu_baseline:
+            log("GPU part done; timing the CPU baselines (%d usable cores)" % usable_cores())
             try:
                 cb = cpu_baseline_torch()
+                log("torch CPU baseline done")
             except Exception as e:  # noqa: BLE001
                 cb = {"value": None, "unit": "Gaussians/s", "cores": os.cpu_count(), "kind": "port", "sample": "failed: %s" % e}
             if args.cpu_views > 0 and not stream:

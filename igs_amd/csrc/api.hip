@@ -449,11 +449,11 @@ extern "C" int igs_rast_forward_finish(void)
 extern "C" void igs_rast_set_slab_hint(unsigned slots_per_tile) { g_hint.slab = slots_per_tile > TILE_SORT_BIG ? TILE_SORT_BIG : slots_per_tile; }
 extern "C" unsigned igs_rast_get_slab_hint(void) { return g_hint.slab; }
 
-// which blend_bwd_kernel<COORD, DEPTH, NORMAL, ABS> the last backward on this thread launched: bit 0 coord, 1 depth, 2 normal,
-// 3 abs-gradient moment; -1 = none (R == 0 / no backward yet).  Tests use it to prove that absent upstream gradients select
-// the cheaper instance.
-static thread_local int g_last_bwd_instance = -1;
-extern "C" int igs_rast_last_backward_instance(void) { return g_last_bwd_instance; }
+// which blend_bwd_kernel<COORD, DEPTH, NORMAL, ABS> the last backward of this PROCESS launched (not per thread: PyTorch runs
+// autograd backward functions on its own worker thread): bit 0 coord, 1 depth, 2 normal, 3 abs-gradient moment; -1 = none
+// (R == 0 / no backward yet).  Tests use it to prove that absent upstream gradients select the cheaper instance.
+static int g_last_bwd_instance = -1;
+extern "C" int igs_rast_last_backward_instance(void) { return __atomic_load_n(&g_last_bwd_instance, __ATOMIC_RELAXED); }
 
 // l1_gt != NULL: L1 loss fused into the blend backward (dL_dpix ignored); fuse != NULL: activation backward + Adam fused into
 // the per-Gaussian backward (no gradient outputs except the optional dL_dmean2D).
@@ -512,12 +512,13 @@ static int backward_impl(
     ba.l1_gt = l1_gt; ba.l1_color = l1_color; ba.l1_scale = l1_scale; ba.l1_loss = loss_shards;
     ba.want_absgrad = (fuse && !dL_dmean2D) ? 0 : 1;
     bool gacc_compact = false;
-    g_last_bwd_instance = -1;
+    int inst_bits = -1;
     if (R > 0) {
-        HIP_TRY(launch_blend_bwd(s, ba, require_coord != 0, require_depth != 0, &gacc_compact, &g_last_bwd_instance), "blend_bwd launch");
+        HIP_TRY(launch_blend_bwd(s, ba, require_coord != 0, require_depth != 0, &gacc_compact, &inst_bits), "blend_bwd launch");
+        __atomic_store_n(&g_last_bwd_instance, inst_bits, __ATOMIC_RELAXED);
         DBG_SYNC("blend_bwd");
         prof_mark(s, ST_BLEND_BWD);
-    }
+    } else __atomic_store_n(&g_last_bwd_instance, -1, __ATOMIC_RELAXED);
     GeomBwdArgs ga;
     ga.P = P; ga.D = D; ga.M = shs ? M : 0; ga.W = width; ga.H = height;
     ga.means3D = means3D; ga.shs = shs; ga.scales = scales; ga.rotations = rotations; ga.cov3D_precomp = cov3D_precomp;

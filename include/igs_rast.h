@@ -189,7 +189,7 @@ int igs_rast_debug_dump(void* stream, int P, int R, int width, int height,
  * few microseconds of stream time, so marking every frame slows a 0.35 ms refine step by about 10 %, every 8th by about 1 %.
  * In igs_refine_step the geom_bwd stage includes the activation backward and the Adam update. */
 #define IGS_RAST_NSTAGES 10
-/* Which backward tile-blend instance the last igs_rast_backward / igs_refine_step on this thread launched: bit 0 coord, bit 1
+/* Which backward tile-blend instance the last igs_rast_backward / igs_refine_step of this process launched (any thread): bit 0 coord, bit 1
  * depth, bit 2 normal gradients present, bit 3 the |screen-space gradient| moment; -1 = none.  (The reference instantiates from
  * require_coord / require_depth alone, backward.cu:1153-1160; here branches whose upstream gradients are all NULL are left out.) */
 int igs_rast_last_backward_instance(void);
