@@ -21,6 +21,53 @@
 
 #define BCHUNK 128            // splats staged per round in the backward (LDS is shared with the reduction scratch)
 
+// Column writes of the transpose buffer: lane l stores its value of moment r at  base + r * stride + 4 l.  That is exactly the
+// address pattern of ds_write_addtid_b32 (address = M0 + offset + 4 * lane, no address VGPR), which moves 4 B per lane to the LDS
+// in 2 cycles instead of the 4 of ds_write_b32 / 3 per dword of ds_write2_b32 (MI355X_MICROARCH.md, LDS: a store's cost is the
+// transfer of its address and data registers) -- and this kernel is bound by the LDS pipe: 10 column writes per row
+// were 28 of its 68 LDS cycles.  M0 is set inside every asm statement (the compiler knows nothing of it otherwise); up to five
+// stores share one statement.
+template <int STRIDE_B, int R0, int N> struct ColWrite;
+template <int STRIDE_B, int R0> struct ColWrite<STRIDE_B, R0, 1> {
+    static __device__ __forceinline__ void run(unsigned m0, const float* v) {
+        asm volatile("s_mov_b32 m0, %1\n\tds_write_addtid_b32 %0 offset:%2" :: "v"(v[R0]), "s"(m0), "n"(R0 * STRIDE_B) : "memory");
+    }
+};
+template <int STRIDE_B, int R0> struct ColWrite<STRIDE_B, R0, 2> {
+    static __device__ __forceinline__ void run(unsigned m0, const float* v) {
+        asm volatile("s_mov_b32 m0, %2\n\tds_write_addtid_b32 %0 offset:%3\n\tds_write_addtid_b32 %1 offset:%4"
+                     :: "v"(v[R0]), "v"(v[R0 + 1]), "s"(m0), "n"(R0 * STRIDE_B), "n"((R0 + 1) * STRIDE_B) : "memory");
+    }
+};
+template <int STRIDE_B, int R0> struct ColWrite<STRIDE_B, R0, 3> {
+    static __device__ __forceinline__ void run(unsigned m0, const float* v) {
+        asm volatile("s_mov_b32 m0, %3\n\tds_write_addtid_b32 %0 offset:%4\n\tds_write_addtid_b32 %1 offset:%5\n\tds_write_addtid_b32 %2 offset:%6"
+                     :: "v"(v[R0]), "v"(v[R0 + 1]), "v"(v[R0 + 2]), "s"(m0), "n"(R0 * STRIDE_B), "n"((R0 + 1) * STRIDE_B), "n"((R0 + 2) * STRIDE_B) : "memory");
+    }
+};
+template <int STRIDE_B, int R0> struct ColWrite<STRIDE_B, R0, 4> {
+    static __device__ __forceinline__ void run(unsigned m0, const float* v) {
+        asm volatile("s_mov_b32 m0, %4\n\tds_write_addtid_b32 %0 offset:%5\n\tds_write_addtid_b32 %1 offset:%6\n\tds_write_addtid_b32 %2 offset:%7\n\t"
+                     "ds_write_addtid_b32 %3 offset:%8"
+                     :: "v"(v[R0]), "v"(v[R0 + 1]), "v"(v[R0 + 2]), "v"(v[R0 + 3]), "s"(m0), "n"(R0 * STRIDE_B), "n"((R0 + 1) * STRIDE_B),
+                        "n"((R0 + 2) * STRIDE_B), "n"((R0 + 3) * STRIDE_B) : "memory");
+    }
+};
+template <int STRIDE_B, int R0> struct ColWrite<STRIDE_B, R0, 5> {
+    static __device__ __forceinline__ void run(unsigned m0, const float* v) {
+        asm volatile("s_mov_b32 m0, %5\n\tds_write_addtid_b32 %0 offset:%6\n\tds_write_addtid_b32 %1 offset:%7\n\tds_write_addtid_b32 %2 offset:%8\n\t"
+                     "ds_write_addtid_b32 %3 offset:%9\n\tds_write_addtid_b32 %4 offset:%10"
+                     :: "v"(v[R0]), "v"(v[R0 + 1]), "v"(v[R0 + 2]), "v"(v[R0 + 3]), "v"(v[R0 + 4]), "s"(m0), "n"(R0 * STRIDE_B),
+                        "n"((R0 + 1) * STRIDE_B), "n"((R0 + 2) * STRIDE_B), "n"((R0 + 3) * STRIDE_B), "n"((R0 + 4) * STRIDE_B) : "memory");
+    }
+};
+template <int STRIDE_B, int R0, int N> struct ColWrite {          // N > 5: five now, the rest recursively
+    static __device__ __forceinline__ void run(unsigned m0, const float* v) {
+        ColWrite<STRIDE_B, R0, 5>::run(m0, v);
+        ColWrite<STRIDE_B, R0 + 5, N - 5>::run(m0, v);
+    }
+};
+
 // gacc slots (raw moments), see geom_bwd.hip for how they are combined:
 //  0..2  sum w*dL/dpix_ch            3..5  Sv = sum dLc_ch          6..8 Sx = sum dLc_ch*dx     9..11 Sy = sum dLc_ch*dy
 //  12    St = sum dLt   13 Stx   14 Sty   15..17 sum w*dL/dnormal_ch
@@ -36,11 +83,19 @@ blend_bwd_kernel(const BlendBwdArgs a)
     __shared__ uint64_t quad_bits[4][2];                // [quad][staging wave pair]: BCHUNK = 2 x 64 splats
     __shared__ int wave_max[4];
     constexpr int NROWS = 9 + (ABS ? 1 : 0) + (COORD ? 9 : 0) + (DEPTH ? 3 : 0) + (NORMAL ? 3 : 0);   // live moments of this instance
-    // floats per row of the per-wave transpose buffer: 16-byte aligned rows, row starts spread over all banks for the b128 reads
-    // (16 rows x 4 banks), and rows r, r+1 -- which the compiler pairs into one ds_write2_b32 -- 36 banks apart instead of 4
-    // ... for the colour-only instance; the instances with geometry (13..25 rows, 12 KB of staged records) are LDS-occupancy
-    // bound instead: <depth, normal> 38 KB -> 4 workgroups per CU with stride 100, 30 KB -> 5 with stride 68 (151 -> 140 us)
-    constexpr int RED_STRIDE = GEO ? 68 : 100;
+    // floats per row of the per-wave transpose buffer: 16-byte aligned rows for the b128 row reads.  Columns are written with
+    // ds_write_addtid_b32 (one dword per lane at consecutive addresses: conflict-free whatever the stride); the ROW reads -- 4
+    // lanes per row, each summing a 16-column segment with four ds_read_b128 -- are serviced in the fixed 16-lane groups of
+    // MI355X_MICROARCH.md's LDS table, and with the plain assignment "lane part p reads segment p" every group had a 2-way bank
+    // conflict on every read (stride 100: 8 extra LDS cycles per row = the 27 % SQ_LDS_BANK_CONFLICT of round 1, on a kernel that is
+    // bound by the LDS pipe).  Rotating the segments per row -- part p of row r reads segment (p + f[r]) mod 4, f found by search
+    // over the group table (tools/lds_swizzle_search.py) -- makes the 9- and 10-row instances conflict-free at stride 68, which also
+    // shrinks the buffer: 17 KB of LDS per workgroup, 8 waves per SIMD instead of 7.
+    constexpr int RED_STRIDE = 68;
+    constexpr uint32_t SEG_ROT = NROWS == 9 ? 0x1b46bu          // f = 3,2,2,1,0,1,3,2,1      (2 bits per row, row 0 lowest)
+                               : NROWS == 10 ? 0x4431eu       // f = 2,3,1,0,3,0,0,1,0,1
+                               : NROWS == 16 ? 0xa7dbb9c7u    // f = 3,1,0,3,1,2,3,2,3,2,1,3,3,1,2,2 (8 conflict cycles left of 32)
+                               : 0u;
     __shared__ __attribute__((aligned(16))) float red[4][NROWS * RED_STRIDE];
 
     uint32_t tile;
@@ -134,8 +189,11 @@ blend_bwd_kernel(const BlendBwdArgs a)
     const bool has_bg = (a.bg[0] != 0.f) || (a.bg[1] != 0.f) || (a.bg[2] != 0.f);      // wave-uniform
     const float halfW = 0.5f * a.W, halfH = 0.5f * a.H;
     float* myred = red[wid];
+    // LDS byte offset of this wave's transpose buffer (the low half of the flat address of a __shared__ object is its LDS offset)
+    const unsigned myred_m0 = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(size_t)myred);
     constexpr int LPR = NROWS <= 16 ? 4 : 2;             // lanes per row of the transpose buffer
     const int rrow = lane & (64 / LPR - 1), rpart = lane / (64 / LPR);
+    const int rseg = LPR == 4 ? ((rpart + (int)((SEG_ROT >> (2 * (rrow & 15))) & 3u)) & 3) : rpart;      // which column segment this lane sums
     // gacc slot of compact row `lane` (rows are emitted in slot order with the dead groups left out)
     // (the colour-only instance packs its 10 moments into slots 0..9 instead: one 64-byte atomic request per row, not two --
     //  float atomics execute at the memory side in 64-byte requests, ~20 G requests/s for the whole chip)
@@ -158,9 +216,9 @@ blend_bwd_kernel(const BlendBwdArgs a)
                     q1.z = a.colors_precomp[3 * (size_t)id]; q1.w = a.colors_precomp[3 * (size_t)id + 1];
                     q2.x = a.colors_precomp[3 * (size_t)id + 2];
                 }
+                if constexpr (!GEO) q2.y = __uint_as_float(id);      // the colour-only row never reads ts: the id rides in its slot
                 chunk[tid * NQ + 0] = q0; chunk[tid * NQ + 1] = q1; chunk[tid * NQ + 2] = q2;
-                if constexpr (GEO) { chunk[tid * NQ + 3] = src[3]; chunk[tid * NQ + 4] = src[4]; chunk[tid * NQ + 5] = src[5]; }
-                chunk_id[tid] = id;
+                if constexpr (GEO) { chunk[tid * NQ + 3] = src[3]; chunk[tid * NQ + 4] = src[4]; chunk[tid * NQ + 5] = src[5]; chunk_id[tid] = id; }
                 qmask = quad_reach_mask(q0, q1, tile_x0, tile_y0);
             }
         }
@@ -229,35 +287,42 @@ blend_bwd_kernel(const BlendBwdArgs a)
 
                 // ---- transpose-reduce over the 64 pixels of the wave: row r of `myred` = the 64 per-lane values of one LIVE
                 // moment (rows are compacted per template instance: 25 with every branch on, 10 for colour-only gradients)
-                float* col = myred + lane;
+                float mv[NROWS];
                 int r = 0;
-                col[(r++) * RED_STRIDE] = w * gp0; col[(r++) * RED_STRIDE] = w * gp1; col[(r++) * RED_STRIDE] = w * gp2;
+                mv[r++] = w * gp0; mv[r++] = w * gp1; mv[r++] = w * gp2;
                 if constexpr (COORD) {
-                    col[(r++) * RED_STRIDE] = dLc0; col[(r++) * RED_STRIDE] = dLc1; col[(r++) * RED_STRIDE] = dLc2;
-                    col[(r++) * RED_STRIDE] = dLc0 * dx; col[(r++) * RED_STRIDE] = dLc1 * dx; col[(r++) * RED_STRIDE] = dLc2 * dx;
-                    col[(r++) * RED_STRIDE] = dLc0 * dy; col[(r++) * RED_STRIDE] = dLc1 * dy; col[(r++) * RED_STRIDE] = dLc2 * dy;
+                    mv[r++] = dLc0; mv[r++] = dLc1; mv[r++] = dLc2;
+                    mv[r++] = dLc0 * dx; mv[r++] = dLc1 * dx; mv[r++] = dLc2 * dx;
+                    mv[r++] = dLc0 * dy; mv[r++] = dLc1 * dy; mv[r++] = dLc2 * dy;
                 }
-                if constexpr (DEPTH) { col[(r++) * RED_STRIDE] = dLt; col[(r++) * RED_STRIDE] = dLt * dx; col[(r++) * RED_STRIDE] = dLt * dy; }
-                if constexpr (NORMAL) { col[(r++) * RED_STRIDE] = w * gn0; col[(r++) * RED_STRIDE] = w * gn1; col[(r++) * RED_STRIDE] = w * gn2; }
-                col[(r++) * RED_STRIDE] = q; col[(r++) * RED_STRIDE] = qdx; col[(r++) * RED_STRIDE] = qdy;
-                col[(r++) * RED_STRIDE] = qdx * dx; col[(r++) * RED_STRIDE] = qdx * dy; col[(r++) * RED_STRIDE] = qdy * dy;
+                if constexpr (DEPTH) { mv[r++] = dLt; mv[r++] = dLt * dx; mv[r++] = dLt * dy; }
+                if constexpr (NORMAL) { mv[r++] = w * gn0; mv[r++] = w * gn1; mv[r++] = w * gn2; }
+                mv[r++] = q; mv[r++] = qdx; mv[r++] = qdy;
+                mv[r++] = qdx * dx; mv[r++] = qdx * dy; mv[r++] = qdy * dy;
                 if constexpr (ABS) {
                     const float gxa = q0.z * qdx + q0.w * qdy;      // -dL/d(delx) of the Gaussian term
                     const float gya = q1.x * qdy + q0.w * qdx;
-                    col[(r++) * RED_STRIDE] = fabsf(gxa * halfW) + fabsf(gya * halfH);
+                    mv[r++] = fabsf(gxa * halfW) + fabsf(gya * halfH);
                 }
+                ColWrite<RED_STRIDE * 4, 0, NROWS>::run(myred_m0, mv);
+                // every lane has written its column; the row sums below read what OTHER lanes wrote.  The wave runs in lockstep and
+                // LDS operations of one wave complete in issue order, so no hardware barrier is needed -- but the compiler must not
+                // move the reads above the writes: wave_barrier is a scheduling fence that emits no instruction
+                __builtin_amdgcn_wave_barrier();
                 // LPR lanes share a row (each sums 64/LPR columns), then LPR partials are combined across lanes
                 float part = 0.f;
                 if (rrow < NROWS) {
-                    const float4* row = (const float4*)(myred + rrow * RED_STRIDE + rpart * (64 / LPR));
+                    const float4* row = (const float4*)(myred + rrow * RED_STRIDE + rseg * (64 / LPR));
                     float4 acc4 = row[0];
 #pragma unroll
                     for (int k = 1; k < 16 / LPR; k++) { const float4 t4 = row[k]; acc4.x += t4.x; acc4.y += t4.y; acc4.z += t4.z; acc4.w += t4.w; }
                     part = (acc4.x + acc4.y) + (acc4.z + acc4.w);
                 }
+                __builtin_amdgcn_wave_barrier();      // ... and the next splat's column writes must stay behind these row reads
                 float tot = part + __shfl_xor(part, 32, 64);
                 if constexpr (LPR == 4) tot += __shfl_xor(tot, 16, 64);
-                if (lane < NROWS) atomicAdd(&a.gacc[(size_t)chunk_id[j] * GACC_F + slot_of_row], tot);
+                const uint32_t gid = GEO ? chunk_id[j] : __float_as_uint(q2.y);
+                if (lane < NROWS) atomicAdd(&a.gacc[(size_t)gid * GACC_F + slot_of_row], tot);
             }
         }
     }

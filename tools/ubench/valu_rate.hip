@@ -12,7 +12,7 @@
 #include <vector>
 #include <algorithm>
 
-enum { OP_FMA = 0, OP_EXP = 1, OP_RCP = 2, OP_MIX = 3, OP_LDSB128 = 4, OP_DPP = 5, OP_SWAP32 = 6, OP_SWAP16 = 7, OP_CNDMASK = 8, OP_BPERM = 9 };
+enum { OP_FMA = 0, OP_EXP = 1, OP_RCP = 2, OP_MIX = 3, OP_LDSB128 = 4, OP_DPP = 5, OP_SWAP32 = 6, OP_SWAP16 = 7, OP_CNDMASK = 8, OP_BPERM = 9, OP_PKFMA = 10, OP_PKADD = 11, OP_MUL = 12 };
 
 template <int OP>
 __global__ void __launch_bounds__(256) k(float* out, int iters, unsigned long long* cyc, float seed)
@@ -23,6 +23,8 @@ __global__ void __launch_bounds__(256) k(float* out, int iters, unsigned long lo
     float a0 = threadIdx.x * 1e-3f + seed, a1 = a0 + 1.f, a2 = a0 + 2.f, a3 = a0 + 3.f, a4 = a0 + 4.f, a5 = a0 + 5.f, a6 = a0 + 6.f, a7 = a0 + 7.f;
     const float b = 0.999f + seed * 1e-6f, c = 1e-3f;
     float4 q = make_float4(0, 0, 0, 0);
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    f2 p0 = {a0, a1}, p1 = {a2, a3}, p2 = {a4, a5}, p3 = {a6, a7}, pb = {b, b}, pc = {c, c};
     const unsigned long long t0 = __builtin_amdgcn_s_memtime();
     for (int i = 0; i < iters; i++) {
 #pragma unroll
@@ -63,6 +65,18 @@ __global__ void __launch_bounds__(256) k(float* out, int iters, unsigned long lo
                 a1 = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(addr, __builtin_bit_cast(int, a1)));
                 a2 = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(addr, __builtin_bit_cast(int, a2)));
                 a3 = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(addr, __builtin_bit_cast(int, a3)));
+            } else if (OP == OP_PKFMA) {    // packed fp32: two FMAs per lane and instruction on a 64-bit register pair
+                asm volatile("v_pk_fma_f32 %0, %0, %4, %5\n v_pk_fma_f32 %1, %1, %4, %5\n v_pk_fma_f32 %2, %2, %4, %5\n v_pk_fma_f32 %3, %3, %4, %5\n"
+                             "v_pk_fma_f32 %0, %0, %4, %5\n v_pk_fma_f32 %1, %1, %4, %5\n v_pk_fma_f32 %2, %2, %4, %5\n v_pk_fma_f32 %3, %3, %4, %5\n"
+                             : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3) : "v"(pb), "v"(pc));
+            } else if (OP == OP_PKADD) {
+                asm volatile("v_pk_add_f32 %0, %0, %4\n v_pk_add_f32 %1, %1, %4\n v_pk_add_f32 %2, %2, %4\n v_pk_add_f32 %3, %3, %4\n"
+                             "v_pk_add_f32 %0, %0, %4\n v_pk_add_f32 %1, %1, %4\n v_pk_add_f32 %2, %2, %4\n v_pk_add_f32 %3, %3, %4\n"
+                             : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3) : "v"(pc));
+            } else if (OP == OP_MUL) {
+                asm volatile("v_mul_f32 %0, %0, %8\n v_mul_f32 %1, %1, %8\n v_mul_f32 %2, %2, %8\n v_mul_f32 %3, %3, %8\n"
+                             "v_add_f32 %4, %4, %9\n v_add_f32 %5, %5, %9\n v_add_f32 %6, %6, %9\n v_add_f32 %7, %7, %9\n"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c));
             } else if (OP == OP_MIX) {      // the blend row's mix: 1 transcendental per ~30 plain ops -> here 1 exp + 7 fma
                 asm volatile("v_exp_f32 %0, %0\n v_fma_f32 %1, %1, %8, %9\n v_fma_f32 %2, %2, %8, %9\n v_fma_f32 %3, %3, %8, %9\n"
                              "v_fma_f32 %4, %4, %8, %9\n v_fma_f32 %5, %5, %8, %9\n v_fma_f32 %6, %6, %8, %9\n v_fma_f32 %7, %7, %8, %9\n"
@@ -76,7 +90,7 @@ __global__ void __launch_bounds__(256) k(float* out, int iters, unsigned long lo
         }
     }
     const unsigned long long t1 = __builtin_amdgcn_s_memtime();
-    const float s = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + q.x + q.y + q.z + q.w;
+    const float s = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + q.x + q.y + q.z + q.w + p0.x + p0.y + p1.x + p1.y + p2.x + p2.y + p3.x + p3.y;
     if (s == 12345.678f) out[0] = s;
     if ((threadIdx.x & 63) == 0) cyc[blockIdx.x * 4 + (threadIdx.x >> 6)] = t1 - t0;
 }
@@ -118,5 +132,8 @@ int main()
     run<OP_SWAP16>("v_permlane16_swap_b32", 64);
     run<OP_CNDMASK>("v_cndmask_b32", 64);
     run<OP_BPERM>("ds_bpermute_b32 (4 independent)", 32);
+    run<OP_MUL>("4 v_mul_f32 + 4 v_add_f32", 64);
+    run<OP_PKFMA>("v_pk_fma_f32 (2 FMAs per lane)", 64);
+    run<OP_PKADD>("v_pk_add_f32", 64);
     return 0;
 }
