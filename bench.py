@@ -164,11 +164,12 @@ def cpu_baseline_c_port(raw, cams, bg, gts, n_views):
 # ----------------------------------------------------------------------------------------------------------------------------
 # self-launch (N > 1 without a launcher)
 # ----------------------------------------------------------------------------------------------------------------------------
-def self_launch(n):
-    """Runs before ANY GPU call in this process (torch.cuda.device_count() does not initialise the device on this image)."""
+def self_launch(n, backend="nccl"):
+    """Runs before ANY GPU call in this process (torch.cuda.device_count() does not initialise the device on this image).
+    With --backend gloo (a rehearsal of the N > 1 code path on a box with fewer GPUs) the ranks share the visible GPU(s)."""
     import torch
     have = torch.cuda.device_count()
-    if have < n:
+    if have < n and backend == "nccl" or have < 1:
         print("bench.py: --gpus %d requested but only %d GPU(s) are visible; refusing to run a smaller job under that label" % (n, have),
               file=sys.stderr)
         return 3
@@ -219,7 +220,7 @@ def main():
         args.config = "cfg2"
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        sys.exit(self_launch(args.gpus))
+        sys.exit(self_launch(args.gpus, args.backend))
 
     import torch
     world = int(os.environ.get("WORLD_SIZE", "1"))

@@ -957,7 +957,7 @@ def test_full_size_frames_match_oracle_on_all_ten_cameras(dev):
         ob["state"] = None
     print("full size, ten cameras: %d of %d gradient elements (%.4f %%) needed the certificate's allowance; %d contributor counts (of %d) differ"
           % (used, tot, 100.0 * used / tot, flips_total, 10 * 2 * 1352 * 1014))
-    assert used <= 0.02 * tot
+    assert used <= 0.001 * tot          # measured: 0.027 % -- exactly where the float32 oracle itself leaves plain 1e-3
 
 
 def test_drop_in_ssim_matches_the_reference_formula(dev):
@@ -1297,3 +1297,27 @@ def test_cov3d_of_the_hip_forward_matches_reference_build_covariance(dev, golden
         d = R.debug_dump(P, out[0], 32, 32, out[9], out[10], out[11])
         cov = d["rec"][:, 24:30].cpu().numpy()
         np.testing.assert_allclose(cov, g[key], rtol=2e-5, atol=1e-7 * float(np.abs(g[key]).max()))
+
+
+def test_autograd_path_direct_adam_equals_flat_buffer_path(dev):
+    """Refiner(native=False): handing autograd's gradient tensors straight to the fused Adam (`direct_adam`, the reference's
+    zero_grad(set_to_none=True) semantics, infer_batch.py:324) leaves the same parameters as zero-filling and accumulating into the
+    flat gradient buffer."""
+    from igs_amd.refine import GaussianParams, Refiner, render
+    from igs_amd.scenes import perturbed_copy
+    raw, cams, bg = cfg1_scene(P=2000, size=96)
+    cams = [cams[0].to(dev)]
+    bg = bg.to(dev)
+    gt_raw = {k: v.to(dev) for k, v in perturbed_copy(raw, sigma=0.03).items()}
+    with torch.no_grad():
+        gts = [render(activate(gt_raw), cams[0], bg)["images_pred"].clone()]
+    for loss in ("l1", "l1_ssim"):
+        pa, pb = GaussianParams(raw, dev), GaussianParams(raw, dev)
+        ra, rb = Refiner(pa, cams, gts, bg, loss=loss, native=False), Refiner(pb, cams, gts, bg, loss=loss, native=False)
+        ra.direct_adam = True
+        for _ in range(3):
+            ra.step(view=0); rb.step(view=0)
+        assert pa.step_count == pb.step_count == 3
+        d = (pa.flat - pb.flat).abs().cpu().numpy()
+        # (|dp| <= lr per step; float-atomic order differs between two backward launches)
+        assert np.quantile(d, 0.98) < 5e-6 and d.max() <= 0.16, (loss, np.quantile(d, 0.98), d.max())

@@ -73,6 +73,20 @@ def test_algorithmic_bytes_formula():
     assert ab0["blend_fwd"] == 1000 * 40 + 256 * 256 * 24 + 8 * 256 and ab0["blend_bwd"] == 1000 * 40 + 256 * 256 * 28 + 1000 * 100
 
 
+def test_bench_refuses_to_mislabel_a_smaller_job():
+    """`python bench.py --gpus N` without a launcher self-launches N ranks -- or refuses (rc != 0) when fewer GPUs are visible; it never
+    runs one GPU under the label of N (round-1 finding).  Here no GPU is visible at all."""
+    import subprocess
+    if torch.cuda.is_available():
+        pytest.skip("needs a box without N GPUs")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=120)
+    assert r.returncode != 0 and "refusing" in r.stderr and r.stdout.strip() == ""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4"], env=dict(env, WORLD_SIZE="1", RANK="0"),
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=120)
+    assert r.returncode != 0 and "refusing" in r.stderr and r.stdout.strip() == ""
+
+
 def _fake_render(act, cam, bg):
     """Differentiable stand-in for the rasterizer (CPU): an 'image' that depends on every parameter group and the view."""
     w = cam["w"]

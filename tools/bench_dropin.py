@@ -33,7 +33,9 @@ def main():
         rasterizer.NAN_CHECKS = nan
         for loss in ("l1", "l1_ssim"):
             p = GaussianParams(raw, dev); p.spatial_sort()
-            out["%s/%s" % (name, loss)] = round(run(Refiner(p, cams, gts, bg, loss=loss, **kw)), 4)
+            r = Refiner(p, cams, gts, bg, loss=loss, **kw)
+            r.direct_adam = True         # autograd path: gradients straight from autograd into the fused Adam (set_to_none semantics, infer_batch.py:324)
+            out["%s/%s" % (name, loss)] = round(run(r), 4)
     print(json.dumps(out))
 
 if __name__ == "__main__":

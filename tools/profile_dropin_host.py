@@ -20,6 +20,7 @@ def main():
         gts = [render(activate(gt_raw), c, bg)["images_pred"].clone() for c in cams]
     p = GaussianParams(raw, dev); p.spatial_sort()
     ref = Refiner(p, cams, gts, bg, loss="l1", native=False)
+    ref.direct_adam = True
     for _ in range(30):
         ref.step()
     torch.cuda.synchronize()
