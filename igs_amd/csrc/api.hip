@@ -713,6 +713,24 @@ extern "C" int igs_rast_debug_dump(void* stream, int P, int R, int width, int he
     return 0;
 }
 
+// Test hook: fills the LDS of every CU with signalling garbage (NaN bit patterns), so that a kernel which reads LDS it never wrote
+// -- invisible on a fresh device, whose LDS reads as zeros -- shows up in small parity tests (round 2 found such a read only through
+// the PSNR of a long run: a missing wait state left one moment of each wave's first row unwritten).
+__global__ void __launch_bounds__(256) poison_lds_kernel(float* sink)
+{
+    extern __shared__ uint32_t lds_all[];
+    for (int i = threadIdx.x; i < 16000; i += 256) lds_all[i] = 0x7FC0BEEFu + (uint32_t)i;
+    __syncthreads();
+    if (lds_all[(threadIdx.x * 7) % 16000] == 1u && sink) sink[0] = 1.f;      // (keeps the stores alive)
+}
+extern "C" int igs_rast_debug_poison_lds(void* stream)
+{
+    // 64000 bytes per workgroup: two workgroups per CU cover most of the 160 KB; 2048 workgroups = 8 per CU, so every CU's LDS
+    // is swept several times whatever the placement
+    hipLaunchKernelGGL(poison_lds_kernel, dim3(2048), dim3(256), 64000, (hipStream_t)stream, (float*)nullptr);
+    return hipGetLastError() == hipSuccess ? 0 : IGS_RAST_E_HIP;
+}
+
 extern "C" int igs_sh_grad_from_view_colors(void* stream, int P, int D, int M, int n_views, const float* means3D, const float* campos,
                                             const float* color_grads, float clamp_grads, float* dL_dsh)
 {

@@ -193,6 +193,9 @@ int igs_rast_debug_dump(void* stream, int P, int R, int width, int height,
  * depth, bit 2 normal gradients present, bit 3 the |screen-space gradient| moment; -1 = none.  (The reference instantiates from
  * require_coord / require_depth alone, backward.cu:1153-1160; here branches whose upstream gradients are all NULL are left out.) */
 int igs_rast_last_backward_instance(void);
+/* Test hook: overwrites the LDS of every CU with NaN bit patterns (a kernel that reads LDS it never wrote then fails small parity
+ * tests instead of passing on a fresh device's zeros). */
+int igs_rast_debug_poison_lds(void* stream);
 int igs_rast_profile_enable(int on);
 int igs_rast_profile_read(double* ms_sum, long long* count, double* r_sum, long long* calls, int reset);
 

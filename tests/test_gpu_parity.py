@@ -37,8 +37,15 @@ def dev():
     return torch.device("cuda:0")
 
 
+def poison_lds(dev):
+    """NaN patterns into every CU's LDS before a kernel under test: reads of LDS the kernel never wrote become visible."""
+    from igs_amd import _cabi
+    assert _cabi.lib().igs_rast_debug_poison_lds(torch.cuda.current_stream(dev).cuda_stream) == 0
+
+
 def hip_forward(a, cam, bg, dev, req=(True, True), deg=3, colors=None, cov=None, debug=True, kernel_size=0.0, prefiltered=False, scale_modifier=1.0):
     from igs_amd import rasterizer as R
+    poison_lds(dev)
     ad = {k: v.to(dev) for k, v in a.items()}
     V, Pm, cc = cam.world_view_transform.to(dev), cam.full_proj_transform.to(dev), cam.camera_center.to(dev)
     out = R.rasterize_gaussians(bg.to(dev), ad["means3D"], E if colors is None else colors.to(dev), ad["opacities"],
@@ -52,6 +59,7 @@ def hip_backward(out, ad, mats, cam, bg, dev, grads, req=(True, True), deg=3, co
     from igs_amd import rasterizer as R
     nr, color, coord, mcoord, alpha, normal, depth, mdepth, radii, gb, bb, ib = out
     V, Pm, cc = mats
+    poison_lds(dev)
     gt = {k: torch.from_numpy(v).to(dev) for k, v in grads.items()}
     return R.rasterize_gaussians_backward(bg.to(dev), ad["means3D"], radii, E if colors is None else colors.to(dev),
                                           E if cov is not None else ad["scales"], E if cov is not None else ad["rotations"], scale_modifier,
