@@ -1,25 +1,28 @@
 // blend_fwd.hip -- tile-wise front-to-back alpha compositing for gfx950 (wave64).
 // Replaces FORWARD::render / renderCUDA (DGR/cuda_rasterizer/forward.cu:428-742).
 //
-// One 256-thread workgroup per 16x16 tile; each of its 4 waves owns an 8x8 pixel quad (lane = pixel).
-// Splats are staged 256 at a time into LDS as packed 96-byte records gathered as whole 128-byte lines from the
-// per-Gaussian record array.  While staging, the thread that holds a splat also decides which of the four quads
-// it can reach at all (bounding box of the alpha >= 1/255 ellipse against the quad's pixel-centre rectangle,
-// conservative); a ballot turns that into one 256-bit "to do" set per quad, so each wave walks only its own
-// splats with scalar bit-scans (s_ff1) and reads them back as wave-uniform (broadcast) ds_read_b128, the next
-// record being fetched while the current one is blended.
-// Tiles are handed to workgroups through an XCD-aware remap so that the tiles sharing an L2 are neighbours.
+// ONE WAVE PER 8x8 PIXEL QUAD, one single-wave workgroup per quad (lane = pixel); the four quads of a 16x16 tile are four
+// independent workgroups.  Round 1 ran a tile as one 256-thread workgroup whose four waves staged 256 splats together between
+// two barriers: the quads of a tile have different amounts of work (a splat reaches 1.02 quads on average on the bench scene, so a
+// quad's share of the tile's list is a binomial draw), three waves waited at every barrier for the slowest, and a finished wave's
+// slot stayed empty until the whole workgroup retired -- 77 % of the wave slots were occupied on average (rocprofv3, round 2).
+// Here a wave stages the tile's list for itself, 64 splats at a time: lane l gathers splat base + l as one 128-byte line of the
+// per-Gaussian record array, drops the 96 bytes the blend needs into LDS, and decides whether the alpha >= 1/255 ellipse of that
+// splat can reach THIS quad at all (bounding box, then the exact minimum of the conic form over the quad's pixel rectangle); a
+// ballot makes that the wave's 64-bit to-do set, walked with scalar bit scans and broadcast ds_read_b128.  No workgroup barrier,
+// no cross-wave state; the price is that the four quads each read the tile's records (from their XCD's L2: the quads of a tile are
+// consecutive blocks of one XCD group).
 #include "blend_common.h"
 
+#define QCHUNK 64            // splats staged per round = one per lane
+
 template <bool COORD, bool DEPTH, bool NORMAL>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(64)
 blend_fwd_kernel(const BlendFwdArgs a)
 {
     constexpr bool GEO = COORD || DEPTH || NORMAL;
     constexpr int NQ = GEO ? 6 : 3;                     // float4 per staged record
-    __shared__ float4 chunk[CHUNK * NQ];
-    __shared__ uint64_t quad_bits[4][4];                // [quad][staging wave]
-    __shared__ int wave_done[4];
+    __shared__ float4 chunk[QCHUNK * NQ];
 
     if (blockIdx.x == 0 && threadIdx.x == 0 && a.host_dst) {
         a.host_dst[0] = a.stats_src[0]; a.host_dst[1] = a.stats_src[1]; a.host_dst[2] = a.flag_src[0];
@@ -27,19 +30,19 @@ blend_fwd_kernel(const BlendFwdArgs a)
         __hip_atomic_store(&a.host_dst[3], a.host_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);      // the host polls this word
         __threadfence_system();
     }
-    uint32_t tile;
-    if (!tile_for_block(blockIdx.x, a.gx, a.gy, tile)) return;
+    uint32_t tile, quad;
+    if (!quad_for_block(blockIdx.x, a.gx, a.gy, tile, quad)) return;
     const uint32_t tx = tile % a.gx, ty = tile / a.gx;
-    const uint32_t tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const uint32_t px = tx * TILE + (wid & 1) * 8 + (lane & 7);
-    const uint32_t py = ty * TILE + (wid >> 1) * 8 + (lane >> 3);
+    const uint32_t lane = threadIdx.x;
+    const uint32_t qx = tx * TILE + (quad & 1) * 8, qy = ty * TILE + (quad >> 1) * 8;
+    const uint32_t px = qx + (lane & 7);
+    const uint32_t py = qy + (lane >> 3);
     const bool inside = px < (uint32_t)a.W && py < (uint32_t)a.H;
     const float pixfx = (float)px, pixfy = (float)py;
-    const float tile_x0 = (float)(tx * TILE), tile_y0 = (float)(ty * TILE);
+    const float quad_x0 = (float)qx, quad_y0 = (float)qy;
 
     const uint2 range = ((const uint2*)a.ranges)[tile];
     const int n = (int)(range.y - range.x);      // (a tile that overflowed its slab has an empty range; the frame is then redone)
-    const int rounds = (n + CHUNK - 1) / CHUNK;
 
     bool done = !inside;
     float T = 1.0f;
@@ -47,83 +50,68 @@ blend_fwd_kernel(const BlendFwdArgs a)
     float C0 = 0, C1 = 0, C2 = 0, weight = 0;
     float Co0 = 0, Co1 = 0, Co2 = 0, mC0 = 0, mC1 = 0, mC2 = 0, Depth = 0, mDepth = 0, N0 = 0, N1 = 0, N2 = 0;
 
-    if (tid < 4) wave_done[tid] = 0;
-    for (int i = 0; i < rounds; i++) {
-        __syncthreads();                                           // previous chunk consumed, wave_done published
-        if (wave_done[0] & wave_done[1] & wave_done[2] & wave_done[3]) break;
-        const int progress = i * CHUNK + (int)tid;
-        uint32_t qmask = 0;
-        if (progress < n) {
-            const uint32_t id = a.point_list[range.x + progress];
+    for (int base = 0; base < n; base += QCHUNK) {
+        if (__ballot(!done) == 0ull) break;                        // every pixel of the quad has saturated
+        // ---- stage: lane l takes splat base + l.  (LDS operations of one wave complete in issue order: the reads of the previous
+        //      round are behind us, and this round's reads are issued after these writes -- no barrier.)
+        const int pos = base + (int)lane;
+        bool reach = false;
+        if (pos < n) {
+            const uint32_t id = a.point_list[range.x + pos];
             const float4* src = (const float4*)(a.rec + (size_t)id * REC_F);
             float4 q0 = src[0], q1 = src[1], q2 = src[2];
             if (a.colors_precomp) {                                // feature_ptr = colors_precomp (rasterizer_impl.cu:394)
                 q1.z = a.colors_precomp[3 * (size_t)id]; q1.w = a.colors_precomp[3 * (size_t)id + 1];
                 q2.x = a.colors_precomp[3 * (size_t)id + 2];
             }
-            chunk[tid * NQ + 0] = q0; chunk[tid * NQ + 1] = q1; chunk[tid * NQ + 2] = q2;
-            if constexpr (GEO) { chunk[tid * NQ + 3] = src[3]; chunk[tid * NQ + 4] = src[4]; chunk[tid * NQ + 5] = src[5]; }
-            qmask = quad_reach_mask(q0, q1, tile_x0, tile_y0);
+            chunk[lane * NQ + 0] = q0; chunk[lane * NQ + 1] = q1; chunk[lane * NQ + 2] = q2;
+            if constexpr (GEO) { chunk[lane * NQ + 3] = src[3]; chunk[lane * NQ + 4] = src[4]; chunk[lane * NQ + 5] = src[5]; }
+            reach = quad_reach_one(q0, q1, quad_x0, quad_y0);
         }
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const uint64_t b = __ballot((qmask >> q) & 1u);
-            if (lane == 0) quad_bits[q][wid] = b;
-        }
-        __syncthreads();
-        if (__ballot(!done) != 0ull) {
-            bool wave_finished = false;
-            for (int sw = 0; sw < 4 && !wave_finished; sw++) {
-                uint64_t bits = uniform64(quad_bits[wid][sw]);     // wave-uniform
-                while (bits != 0ull) {
-                    const int j = sw * 64 + __builtin_ctzll(bits);
-                    bits &= bits - 1;
-                    const float4* r = &chunk[j * NQ];
-                    const float4 q0 = r[0], q1 = r[1], q2 = r[2];
-                    const float dx = q0.x - pixfx, dy = q0.y - pixfy;
-                    const float power = gauss_power(q0.z, q0.w, q1.x, dx, dy);
-                    const float alpha = fminf(0.99f, q1.y * __expf(power));
-                    const float test_T = T * (1.0f - alpha);
-                    // negated comparisons keep the reference's behaviour for NaN (forward.cu:556-573: `if (x > 0) continue`)
-                    const bool pass = !done && !(power > 0.0f) && !(alpha < 1.0f / 255.0f);
-                    const bool contrib = pass && !(test_T < 0.0001f);
-                    done = done || (pass && test_T < 0.0001f);
-                    // straight-line accumulate: after the per-quad culling nearly every splat that gets here contributes
-                    const uint32_t contributor = (uint32_t)(i * CHUNK + j + 1);
-                    const float aT = contrib ? alpha * T : 0.0f;
-                    C0 += q1.z * aT; C1 += q1.w * aT; C2 += q2.x * aT;
-                    const bool before_median = contrib && T > 0.5f;
-                    if constexpr (GEO) {
-                        const float4 q3 = r[3];                            // view_point, n.x
-                        const float4 q5 = r[5];                            // cp4, cp5, n.y, n.z
-                        if constexpr (COORD) {
-                            const float4 q4 = r[4];                        // cp0..3
-                            const float c0 = q3.x + q4.x * dx + q4.y * dy;
-                            const float c1 = q3.y + q4.z * dx + q4.w * dy;
-                            const float c2 = q3.z + q5.x * dx + q5.y * dy;
-                            Co0 += c0 * aT; Co1 += c1 * aT; Co2 += c2 * aT;
-                        }
-                        if constexpr (DEPTH) {
-                            const float t = q2.y + (q2.z * dx + q2.w * dy);
-                            Depth += t * aT;
-                        }
-                        if constexpr (NORMAL) { N0 += q3.w * aT; N1 += q5.z * aT; N2 += q5.w * aT; }
-                        // only the index of the median splat is tracked here; its coordinate and depth are re-evaluated once
-                        // per pixel after the loop (forward.cu:640-652 stores them inside the loop)
-                        max_contributor = before_median ? contributor : max_contributor;
-                    }
-                    weight += aT;
-                    T = contrib ? test_T : T;
-                    last_contributor = contrib ? contributor : last_contributor;
+        uint64_t bits = __ballot(reach);                           // wave-uniform to-do set of this round
+        __builtin_amdgcn_wave_barrier();                           // (scheduling fence only: keeps the row reads behind the staging writes)
+        while (bits != 0ull) {
+            const int j = __builtin_ctzll(bits);
+            bits &= bits - 1;
+            const float4* r = &chunk[j * NQ];
+            const float4 q0 = r[0], q1 = r[1], q2 = r[2];
+            const float dx = q0.x - pixfx, dy = q0.y - pixfy;
+            const float power = gauss_power(q0.z, q0.w, q1.x, dx, dy);
+            const float alpha = fminf(0.99f, q1.y * __expf(power));
+            const float test_T = T * (1.0f - alpha);
+            // negated comparisons keep the reference's behaviour for NaN (forward.cu:556-573: `if (x > 0) continue`)
+            const bool pass = !done && !(power > 0.0f) && !(alpha < 1.0f / 255.0f);
+            const bool contrib = pass && !(test_T < 0.0001f);
+            done = done || (pass && test_T < 0.0001f);
+            // straight-line accumulate: after the per-quad culling nearly every splat that gets here contributes
+            const uint32_t contributor = (uint32_t)(base + j + 1);
+            const float aT = contrib ? alpha * T : 0.0f;
+            C0 += q1.z * aT; C1 += q1.w * aT; C2 += q2.x * aT;
+            const bool before_median = contrib && T > 0.5f;
+            if constexpr (GEO) {
+                const float4 q3 = r[3];                            // view_point, n.x
+                const float4 q5 = r[5];                            // cp4, cp5, n.y, n.z
+                if constexpr (COORD) {
+                    const float4 q4 = r[4];                        // cp0..3
+                    const float c0 = q3.x + q4.x * dx + q4.y * dy;
+                    const float c1 = q3.y + q4.z * dx + q4.w * dy;
+                    const float c2 = q3.z + q5.x * dx + q5.y * dy;
+                    Co0 += c0 * aT; Co1 += c1 * aT; Co2 += c2 * aT;
                 }
-                // "has every pixel of the quad saturated?" is asked once per 64 staged splats, not per row: the ballot of the
-                // `done` mask costs two VALU ops and a branch in the middle of the row (measured: 71.5 -> 65 us); at most the
-                // rest of one 64-splat word is blended into lanes that no longer take anything
-                if (__ballot(!done) == 0ull) wave_finished = true;
+                if constexpr (DEPTH) {
+                    const float t = q2.y + (q2.z * dx + q2.w * dy);
+                    Depth += t * aT;
+                }
+                if constexpr (NORMAL) { N0 += q3.w * aT; N1 += q5.z * aT; N2 += q5.w * aT; }
+                // only the index of the median splat is tracked here; its coordinate and depth are re-evaluated once
+                // per pixel after the loop (forward.cu:640-652 stores them inside the loop)
+                max_contributor = before_median ? contributor : max_contributor;
             }
+            weight += aT;
+            T = contrib ? test_T : T;
+            last_contributor = contrib ? contributor : last_contributor;
         }
-        const bool all_done = __ballot(!done) == 0ull;            // (the ballot must be taken by the whole wave)
-        if (lane == 0) wave_done[wid] = all_done ? 1 : 0;
+        __builtin_amdgcn_wave_barrier();                           // the next round's staging writes stay behind these reads
     }
 
     if (inside) {
@@ -191,7 +179,7 @@ blend_fwd_kernel(const BlendFwdArgs a)
 
 hipError_t launch_blend_fwd(hipStream_t s, const BlendFwdArgs& a, bool coord, bool depth)
 {
-    const dim3 grid(tile_grid_blocks(a.gx, a.gy)), block(256);
+    const dim3 grid(quad_grid_blocks(a.gx, a.gy)), block(64);
     // dispatch of forward.cu:732-739: NORMAL is on whenever COORD or DEPTH is
     if (coord && depth) hipLaunchKernelGGL((blend_fwd_kernel<true, true, true>), grid, block, 0, s, a);
     else if (coord) hipLaunchKernelGGL((blend_fwd_kernel<true, false, true>), grid, block, 0, s, a);

@@ -293,6 +293,17 @@ __device__ __forceinline__ bool tile_for_block(uint32_t b, uint32_t gx, uint32_t
     return row < gy;
 }
 static inline uint32_t tile_grid_blocks(uint32_t gx, uint32_t gy) { return 8u * ((gy + 7u) / 8u) * gx; }
+// The same for single-wave workgroups, one per 8x8 QUAD: the four quads of a tile are the blocks b, b + 8, b + 16, b + 24 of one
+// XCD group (they gather the same Gaussian records: one L2), dispatched back to back.
+__device__ __forceinline__ bool quad_for_block(uint32_t b, uint32_t gx, uint32_t gy, uint32_t& tile, uint32_t& quad) {
+    const uint32_t xcd = b & 7u, k = b >> 3;
+    quad = k & 3u;
+    const uint32_t kk = k >> 2;
+    const uint32_t row = xcd + 8u * (kk / gx), col = kk % gx;
+    tile = row * gx + col;
+    return row < gy;
+}
+static inline uint32_t quad_grid_blocks(uint32_t gx, uint32_t gy) { return 4u * 8u * ((gy + 7u) / 8u) * gx; }
 
 // XCD-aware bijective remap (contiguous bands; kept for comparison): blocks b, b+8, .. share an XCD (round-robin dispatch), give each XCD a contiguous band of tiles
 __device__ __forceinline__ uint32_t xcd_remap(uint32_t b, uint32_t n) {
