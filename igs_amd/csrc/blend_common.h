@@ -64,42 +64,6 @@ __device__ __forceinline__ uint32_t quad_reach_mask(float4 q0, float4 q1, float 
     return m;
 }
 
-// The same two tests for ONE 8x8 quad whose first pixel centre is (qx0, qy0): used by the wave-per-quad kernels, where every wave
-// stages the tile's list for itself and keeps only the splats that can reach its own pixels.
-__device__ __forceinline__ bool quad_reach_one(float4 q0, float4 q1, float qx0, float qy0)
-{
-    const float o = q1.y;
-    if (o < (1.0f / 255.0f)) return false;                    // alpha <= o < 1/255 for every pixel
-    const float cx = q0.z, cy = q0.w, cz = q1.x;
-    const float det = cx * cz - cy * cy;
-    if (!(det > 0.f) || !(cx > 0.f) || !(cz > 0.f) || !(det < 3.0e38f)) return true;
-    const float two_tau = 2.0f * __logf(255.0f * o) * 1.002f + 1e-3f;
-    if (!(two_tau < 3.0e38f)) return true;
-    const float inv = 1.0f / det;
-    const float ex = sqrtf(two_tau * cz * inv) * 1.001f + 0.02f;
-    const float ey = sqrtf(two_tau * cx * inv) * 1.001f + 0.02f;
-    if (!(ex < 3.0e38f) || !(ey < 3.0e38f)) return true;
-    const float lx = q0.x - ex - qx0, hx = q0.x + ex - qx0;          // reach interval in quad-local pixel coordinates
-    const float ly = q0.y - ey - qy0, hy = q0.y + ey - qy0;
-    if (!((hx >= 0.f) && (lx <= 7.f) && (hy >= 0.f) && (ly <= 7.f))) return false;
-    // exact minimum of the quadratic form over the quad's pixel-centre rectangle (inflated by 0.02 px), relative to the splat centre
-    const float xl = (qx0 - 0.02f) - q0.x, xh = xl + 7.04f;
-    const float yl = (qy0 - 0.02f) - q0.y, yh = yl + 7.04f;
-    const bool xin = (xl <= 0.f) && (xh >= 0.f), yin = (yl <= 0.f) && (yh >= 0.f);
-    if (xin && yin) return true;
-    const float nbc = -cy / cz, nba = -cy / cx;               // argmin of the form along a vertical / horizontal line
-    const float fx = xl > 0.f ? xl : xh;                      // x of the vertical edge facing the centre
-    const float dyv = fminf(fmaxf(nbc * fx, yl), yh);
-    const float qv = cx * fx * fx + 2.0f * cy * fx * dyv + cz * dyv * dyv;
-    const float fy = yl > 0.f ? yl : yh;                      // y of the horizontal edge facing the centre
-    const float dxh = fminf(fmaxf(nba * fy, xl), xh);
-    const float qh = cx * dxh * dxh + 2.0f * cy * dxh * fy + cz * fy * fy;
-    float qmin = 3.0e38f;
-    if (!xin) qmin = qv;
-    if (!yin) qmin = fminf(qmin, qh);
-    return !(qmin > two_tau);                                 // (a NaN keeps the quad)
-}
-
 // wave-uniform copy of a 64-bit value (readfirstlane returns a SIGNED int: widen through uint32_t, not int)
 __device__ __forceinline__ uint64_t uniform64(uint64_t v)
 {

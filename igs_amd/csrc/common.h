@@ -84,8 +84,9 @@ struct SlabLayout {
         total = o + 256;
     }
 };
+#define LOAD_BUCKETS 64                     // tiles are listed by load class (see tile_sort_kernel): heaviest classes are dispatched first
 struct ImgLayout {
-    size_t ranges, n_contrib, accum_coord, accum_depth, normal_length, tile_count, stats, counters, zero_end, total;
+    size_t ranges, n_contrib, accum_coord, accum_depth, normal_length, tile_count, stats, counters, bucket_fill, zero_end, bucket_list, total;
     __host__ ImgLayout(size_t HW, size_t T) {
         size_t o = 0;
         ranges = o;        o += align_up(T * 8, 256);
@@ -95,8 +96,10 @@ struct ImgLayout {
         normal_length = o; o += align_up(HW * 4, 256);
         tile_count = o;    o += align_up(T * 4, 256);      // slab binning: instances per tile (fill cursor)
         stats = o;         o += 256;                       // ... [0] R, [1] largest tile that overflowed its slab (0 = none)
-        counters = o;      o += (COUNTER_SHARDS + 1) * COUNTER_SHARD_STRIDE * 4;   // ... instance-count shards; these three are zeroed by one fill
+        counters = o;      o += (COUNTER_SHARDS + 1) * COUNTER_SHARD_STRIDE * 4;   // ... instance-count shards
+        bucket_fill = o;   o += LOAD_BUCKETS * 4;          // ... tiles per load class; these four are zeroed by one fill
         zero_end = o;
+        bucket_list = o;   o += align_up((size_t)LOAD_BUCKETS * T * 4, 256);       // [class][position] tile ids
         total = o + 256;
     }
 };
@@ -119,7 +122,8 @@ hipError_t launch_preprocess_fwd(hipStream_t s, const FwdParams& p, float* rec, 
                                  uint32_t* tile_count, uint64_t* pairs, uint32_t slab);
 void sort_geometry(uint32_t n, uint32_t* nb, uint32_t* per);
 hipError_t launch_tile_sort(hipStream_t s, uint32_t T, const uint32_t* tile_count, const uint64_t* pairs, uint32_t* point_list,
-                            uint32_t* ranges, uint32_t slab, uint32_t* stats, const uint32_t* counters);
+                            uint32_t* ranges, uint32_t slab, uint32_t* stats, const uint32_t* counters, uint32_t* bucket_fill,
+                            uint32_t* bucket_list);
 hipError_t launch_compact_lists(hipStream_t s, uint32_t T, const uint32_t* ranges_in, const uint32_t* list_in, uint32_t* ranges_out,
                                 uint32_t* list_out, uint32_t out_capacity);
 hipError_t launch_mark_visible(hipStream_t s, int P, const float* means3D, const float* view, uint8_t* present);
@@ -144,6 +148,7 @@ struct BlendFwdArgs {
     uint32_t* n_contrib; float *accum_coord, *accum_depth, *normal_length;
     // slab binning: workgroup 0 forwards {R, overflow, prefilter flag} to host-visible memory (no copy kernels on the stream)
     const uint32_t* stats_src; const uint32_t* flag_src; uint32_t* host_dst; uint32_t host_seq;      // host_dst[3] = host_seq, written last
+    const uint32_t* bucket_fill = nullptr; const uint32_t* bucket_list = nullptr;      // load-ordered tile lists (NULL: plain XCD-aware order)
 };
 hipError_t launch_blend_fwd(hipStream_t s, const BlendFwdArgs& a, bool coord, bool depth);
 
@@ -159,6 +164,7 @@ struct BlendBwdArgs {
     // 0: nobody reads dL_dmean2D.z (the absolute screen-space gradient sum the densification statistics use): the colour-only
     // instance then drops that moment (its |.| terms, one LDS row, one atomic lane per row)
     int want_absgrad = 1;
+    const uint32_t* bucket_fill = nullptr; const uint32_t* bucket_list = nullptr;      // load-ordered tile lists (NULL: plain XCD-aware order)
 };
 hipError_t launch_blend_bwd(hipStream_t s, const BlendBwdArgs& a, bool coord, bool depth, bool* compact_layout, int* instance_bits = nullptr);
 
@@ -293,17 +299,41 @@ __device__ __forceinline__ bool tile_for_block(uint32_t b, uint32_t gx, uint32_t
     return row < gy;
 }
 static inline uint32_t tile_grid_blocks(uint32_t gx, uint32_t gy) { return 8u * ((gy + 7u) / 8u) * gx; }
-// The same for single-wave workgroups, one per 8x8 QUAD: the four quads of a tile are the blocks b, b + 8, b + 16, b + 24 of one
-// XCD group (they gather the same Gaussian records: one L2), dispatched back to back.
-__device__ __forceinline__ bool quad_for_block(uint32_t b, uint32_t gx, uint32_t gy, uint32_t& tile, uint32_t& quad) {
-    const uint32_t xcd = b & 7u, k = b >> 3;
-    quad = k & 3u;
-    const uint32_t kk = k >> 2;
-    const uint32_t row = xcd + 8u * (kk / gx), col = kk % gx;
-    tile = row * gx + col;
-    return row < gy;
+
+// Longest-first dispatch.  A tile's blend time is proportional to its instance count, which ranges from 0 to several times the
+// mean; workgroups are dispatched in block order, and with ~2.7 generations of resident workgroups a heavy tile that starts late
+// runs on alone while the rest of the chip idles (round 2, rocprofv3: ~20 % of the wave slots empty over both blend kernels).  The
+// tile sort -- the first kernel that sees the final counts -- therefore files every tile under a load class, and block b of a blend
+// kernel takes the b-th tile in descending class order: 64 class sizes, one wave prefix sum, two dependent loads.
+__device__ __forceinline__ uint32_t load_class(uint32_t n) {            // 0 = empty ... 63 = heaviest; ~13 % of load per class
+    if (n == 0u) return 0u;
+    const uint32_t c = 1u + (uint32_t)(5.5f * __log2f((float)n));
+    return c > (uint32_t)(LOAD_BUCKETS - 1) ? (uint32_t)(LOAD_BUCKETS - 1) : c;
 }
-static inline uint32_t quad_grid_blocks(uint32_t gx, uint32_t gy) { return 4u * 8u * ((gy + 7u) / 8u) * gx; }
+// Block -> tile.  wave-uniform; every lane of the calling wave must be active.  With valid load-class lists (their sizes add up to the
+// number of tiles: the slab-binning forward zeroes the sizes and the tile sort files every tile; the global-sort path only zeroes
+// them) block b takes the b-th tile in descending class order; otherwise the plain XCD-aware order.  Returns false for blocks that
+// have no tile.
+__device__ __forceinline__ bool tile_select(uint32_t b, uint32_t gx, uint32_t gy, const uint32_t* __restrict__ bucket_fill,
+                                            const uint32_t* __restrict__ bucket_list, uint32_t& tile) {
+    if (bucket_fill && bucket_list) {
+        const uint32_t T = gx * gy;
+        const uint32_t lane = threadIdx.x & 63u;
+        const uint32_t c = bucket_fill[LOAD_BUCKETS - 1 - lane];        // lane 0 = heaviest class
+        uint32_t incl = c;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) { const uint32_t v = (uint32_t)__shfl_up((int)incl, off, 64); if (lane >= (uint32_t)off) incl += v; }
+        const uint32_t total = (uint32_t)__shfl((int)incl, 63, 64);
+        if (total == T) {
+            if (b >= T) return false;
+            const int l = __builtin_ctzll(__ballot(incl > b));
+            const uint32_t before = (uint32_t)__shfl((int)(incl - c), l, 64);
+            tile = bucket_list[(size_t)(LOAD_BUCKETS - 1 - l) * T + (b - before)];
+            return tile < T;
+        }
+    }
+    return tile_for_block(b, gx, gy, tile);
+}
 
 // XCD-aware bijective remap (contiguous bands; kept for comparison): blocks b, b+8, .. share an XCD (round-robin dispatch), give each XCD a contiguous band of tiles
 __device__ __forceinline__ uint32_t xcd_remap(uint32_t b, uint32_t n) {

@@ -101,7 +101,7 @@ blend_bwd_kernel(const BlendBwdArgs a)
     __shared__ __attribute__((aligned(16))) float red[4][NROWS * RED_STRIDE];
 
     uint32_t tile;
-    if (!tile_select(blockIdx.x, a.gx, a.gy, a.bucket_fill, a.bucket_list, tile)) return;      // heaviest tiles first (common.h)
+    if (!tile_for_block(blockIdx.x, a.gx, a.gy, tile)) return;
     const uint32_t tx = tile % a.gx, ty = tile / a.gx;
     const uint32_t tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const uint32_t px = tx * TILE + (wid & 1) * 8 + (lane & 7);
@@ -321,15 +321,8 @@ blend_bwd_kernel(const BlendBwdArgs a)
                     part = (acc4.x + acc4.y) + (acc4.z + acc4.w);
                 }
                 __builtin_amdgcn_wave_barrier();      // ... and the next splat's column writes must stay behind these row reads
-                // the LPR partials of a row sit 64 / LPR lanes apart: v_permlane32_swap / v_permlane16_swap (gfx950) fold them in the
-                // vector ALU -- no trip through the LDS crossbar (ds_bpermute: 6 LDS cycles each on the kernel's busiest unit, and a
-                // round trip of latency in the middle of the row's dependency chain)
-                const auto s32 = __builtin_amdgcn_permlane32_swap(__float_as_uint(part), __float_as_uint(part), false, false);
-                float tot = __uint_as_float(s32[0]) + __uint_as_float(s32[1]);
-                if constexpr (LPR == 4) {
-                    const auto s16 = __builtin_amdgcn_permlane16_swap(__float_as_uint(tot), __float_as_uint(tot), false, false);
-                    tot = __uint_as_float(s16[0]) + __uint_as_float(s16[1]);
-                }
+                float tot = part + __shfl_xor(part, 32, 64);
+                if constexpr (LPR == 4) tot += __shfl_xor(tot, 16, 64);
                 const uint32_t gid = GEO ? chunk_id[j] : __float_as_uint(q2.y);
                 if (lane < NROWS) atomicAdd(&a.gacc[(size_t)gid * GACC_F + slot_of_row], tot);
             }

@@ -2,7 +2,7 @@
 // Replaces FORWARD::render / renderCUDA (DGR/cuda_rasterizer/forward.cu:428-742).
 //
 // One 256-thread workgroup per 16x16 tile; each of its 4 waves owns an 8x8 pixel quad (lane = pixel).
-// Splats are staged 192 at a time into LDS as packed 96-byte records gathered as whole 128-byte lines from the
+// Splats are staged 256 at a time into LDS as packed 96-byte records gathered as whole 128-byte lines from the
 // per-Gaussian record array.  While staging, the thread that holds a splat also decides which of the four quads
 // it can reach at all (bounding box of the alpha >= 1/255 ellipse against the quad's pixel-centre rectangle,
 // conservative); a ballot turns that into one 256-bit "to do" set per quad, so each wave walks only its own
@@ -11,21 +11,14 @@
 // Tiles are handed to workgroups through an XCD-aware remap so that the tiles sharing an L2 are neighbours.
 #include "blend_common.h"
 
-// 192 splats staged per round by the first three waves: 18 KB of LDS per workgroup instead of 24.5 (256 splats), so that eight
-// workgroups fit a CU; together with the 64-VGPR budget below (8 waves per SIMD instead of 6; two dwords spill outside the row
-// loop) the fuller machine hides more of a row's dependency chain: 64.4 -> 61.0 us on the bench scene (same-box A/B, round 2)
-#undef CHUNK
-#define CHUNK 192
-#define NSW (CHUNK / 64)     // staging waves
-
 template <bool COORD, bool DEPTH, bool NORMAL>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8)))
+__global__ void __launch_bounds__(256)
 blend_fwd_kernel(const BlendFwdArgs a)
 {
     constexpr bool GEO = COORD || DEPTH || NORMAL;
     constexpr int NQ = GEO ? 6 : 3;                     // float4 per staged record
     __shared__ float4 chunk[CHUNK * NQ];
-    __shared__ uint64_t quad_bits[4][NSW];              // [quad][staging wave]
+    __shared__ uint64_t quad_bits[4][4];                // [quad][staging wave]
     __shared__ int wave_done[4];
 
     if (blockIdx.x == 0 && threadIdx.x == 0 && a.host_dst) {
@@ -35,7 +28,7 @@ blend_fwd_kernel(const BlendFwdArgs a)
         __threadfence_system();
     }
     uint32_t tile;
-    if (!tile_select(blockIdx.x, a.gx, a.gy, a.bucket_fill, a.bucket_list, tile)) return;      // heaviest tiles first (common.h)
+    if (!tile_for_block(blockIdx.x, a.gx, a.gy, tile)) return;
     const uint32_t tx = tile % a.gx, ty = tile / a.gx;
     const uint32_t tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const uint32_t px = tx * TILE + (wid & 1) * 8 + (lane & 7);
@@ -60,7 +53,7 @@ blend_fwd_kernel(const BlendFwdArgs a)
         if (wave_done[0] & wave_done[1] & wave_done[2] & wave_done[3]) break;
         const int progress = i * CHUNK + (int)tid;
         uint32_t qmask = 0;
-        if (tid < CHUNK && progress < n) {
+        if (progress < n) {
             const uint32_t id = a.point_list[range.x + progress];
             const float4* src = (const float4*)(a.rec + (size_t)id * REC_F);
             float4 q0 = src[0], q1 = src[1], q2 = src[2];
@@ -72,17 +65,15 @@ blend_fwd_kernel(const BlendFwdArgs a)
             if constexpr (GEO) { chunk[tid * NQ + 3] = src[3]; chunk[tid * NQ + 4] = src[4]; chunk[tid * NQ + 5] = src[5]; }
             qmask = quad_reach_mask(q0, q1, tile_x0, tile_y0);
         }
-        if (wid < NSW) {
 #pragma unroll
-            for (int q = 0; q < 4; q++) {
-                const uint64_t b = __ballot((qmask >> q) & 1u);
-                if (lane == 0) quad_bits[q][wid] = b;
-            }
+        for (int q = 0; q < 4; q++) {
+            const uint64_t b = __ballot((qmask >> q) & 1u);
+            if (lane == 0) quad_bits[q][wid] = b;
         }
         __syncthreads();
         if (__ballot(!done) != 0ull) {
             bool wave_finished = false;
-            for (int sw = 0; sw < NSW && !wave_finished; sw++) {
+            for (int sw = 0; sw < 4 && !wave_finished; sw++) {
                 uint64_t bits = uniform64(quad_bits[wid][sw]);     // wave-uniform
                 while (bits != 0ull) {
                     const int j = sw * 64 + __builtin_ctzll(bits);

@@ -1,0 +1,189 @@
+// blend_fwd.hip -- tile-wise front-to-back alpha compositing for gfx950 (wave64).
+// Replaces FORWARD::render / renderCUDA (DGR/cuda_rasterizer/forward.cu:428-742).
+//
+// ONE WAVE PER 8x8 PIXEL QUAD, one single-wave workgroup per quad (lane = pixel); the four quads of a 16x16 tile are four
+// independent workgroups.  Round 1 ran a tile as one 256-thread workgroup whose four waves staged 256 splats together between
+// two barriers: the quads of a tile have different amounts of work (a splat reaches 1.02 quads on average on the bench scene, so a
+// quad's share of the tile's list is a binomial draw), three waves waited at every barrier for the slowest, and a finished wave's
+// slot stayed empty until the whole workgroup retired -- 77 % of the wave slots were occupied on average (rocprofv3, round 2).
+// Here a wave stages the tile's list for itself, 64 splats at a time: lane l gathers splat base + l as one 128-byte line of the
+// per-Gaussian record array, drops the 96 bytes the blend needs into LDS, and decides whether the alpha >= 1/255 ellipse of that
+// splat can reach THIS quad at all (bounding box, then the exact minimum of the conic form over the quad's pixel rectangle); a
+// ballot makes that the wave's 64-bit to-do set, walked with scalar bit scans and broadcast ds_read_b128.  No workgroup barrier,
+// no cross-wave state; the price is that the four quads each read the tile's records (from their XCD's L2: the quads of a tile are
+// consecutive blocks of one XCD group).
+#include "blend_common.h"
+
+#define QCHUNK 64            // splats staged per round = one per lane
+
+template <bool COORD, bool DEPTH, bool NORMAL>
+__global__ void __launch_bounds__(64)
+blend_fwd_kernel(const BlendFwdArgs a)
+{
+    constexpr bool GEO = COORD || DEPTH || NORMAL;
+    constexpr int NQ = GEO ? 6 : 3;                     // float4 per staged record
+    __shared__ float4 chunk[QCHUNK * NQ];
+
+    if (blockIdx.x == 0 && threadIdx.x == 0 && a.host_dst) {
+        a.host_dst[0] = a.stats_src[0]; a.host_dst[1] = a.stats_src[1]; a.host_dst[2] = a.flag_src[0];
+        __threadfence_system();
+        __hip_atomic_store(&a.host_dst[3], a.host_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);      // the host polls this word
+        __threadfence_system();
+    }
+    uint32_t tile, quad;
+    if (!quad_for_block(blockIdx.x, a.gx, a.gy, tile, quad)) return;
+    const uint32_t tx = tile % a.gx, ty = tile / a.gx;
+    const uint32_t lane = threadIdx.x;
+    const uint32_t qx = tx * TILE + (quad & 1) * 8, qy = ty * TILE + (quad >> 1) * 8;
+    const uint32_t px = qx + (lane & 7);
+    const uint32_t py = qy + (lane >> 3);
+    const bool inside = px < (uint32_t)a.W && py < (uint32_t)a.H;
+    const float pixfx = (float)px, pixfy = (float)py;
+    const float quad_x0 = (float)qx, quad_y0 = (float)qy;
+
+    const uint2 range = ((const uint2*)a.ranges)[tile];
+    const int n = (int)(range.y - range.x);      // (a tile that overflowed its slab has an empty range; the frame is then redone)
+
+    bool done = !inside;
+    float T = 1.0f;
+    uint32_t last_contributor = 0, max_contributor = 0xFFFFFFFFu;
+    float C0 = 0, C1 = 0, C2 = 0, weight = 0;
+    float Co0 = 0, Co1 = 0, Co2 = 0, mC0 = 0, mC1 = 0, mC2 = 0, Depth = 0, mDepth = 0, N0 = 0, N1 = 0, N2 = 0;
+
+    for (int base = 0; base < n; base += QCHUNK) {
+        if (__ballot(!done) == 0ull) break;                        // every pixel of the quad has saturated
+        // ---- stage: lane l takes splat base + l.  (LDS operations of one wave complete in issue order: the reads of the previous
+        //      round are behind us, and this round's reads are issued after these writes -- no barrier.)
+        const int pos = base + (int)lane;
+        bool reach = false;
+        if (pos < n) {
+            const uint32_t id = a.point_list[range.x + pos];
+            const float4* src = (const float4*)(a.rec + (size_t)id * REC_F);
+            float4 q0 = src[0], q1 = src[1], q2 = src[2];
+            if (a.colors_precomp) {                                // feature_ptr = colors_precomp (rasterizer_impl.cu:394)
+                q1.z = a.colors_precomp[3 * (size_t)id]; q1.w = a.colors_precomp[3 * (size_t)id + 1];
+                q2.x = a.colors_precomp[3 * (size_t)id + 2];
+            }
+            chunk[lane * NQ + 0] = q0; chunk[lane * NQ + 1] = q1; chunk[lane * NQ + 2] = q2;
+            if constexpr (GEO) { chunk[lane * NQ + 3] = src[3]; chunk[lane * NQ + 4] = src[4]; chunk[lane * NQ + 5] = src[5]; }
+            reach = quad_reach_one(q0, q1, quad_x0, quad_y0);
+        }
+        uint64_t bits = __ballot(reach);                           // wave-uniform to-do set of this round
+        __builtin_amdgcn_wave_barrier();                           // (scheduling fence only: keeps the row reads behind the staging writes)
+        while (bits != 0ull) {
+            const int j = __builtin_ctzll(bits);
+            bits &= bits - 1;
+            const float4* r = &chunk[j * NQ];
+            const float4 q0 = r[0], q1 = r[1], q2 = r[2];
+            const float dx = q0.x - pixfx, dy = q0.y - pixfy;
+            const float power = gauss_power(q0.z, q0.w, q1.x, dx, dy);
+            const float alpha = fminf(0.99f, q1.y * __expf(power));
+            const float test_T = T * (1.0f - alpha);
+            // negated comparisons keep the reference's behaviour for NaN (forward.cu:556-573: `if (x > 0) continue`)
+            const bool pass = !done && !(power > 0.0f) && !(alpha < 1.0f / 255.0f);
+            const bool contrib = pass && !(test_T < 0.0001f);
+            done = done || (pass && test_T < 0.0001f);
+            // straight-line accumulate: after the per-quad culling nearly every splat that gets here contributes
+            const uint32_t contributor = (uint32_t)(base + j + 1);
+            const float aT = contrib ? alpha * T : 0.0f;
+            C0 += q1.z * aT; C1 += q1.w * aT; C2 += q2.x * aT;
+            const bool before_median = contrib && T > 0.5f;
+            if constexpr (GEO) {
+                const float4 q3 = r[3];                            // view_point, n.x
+                const float4 q5 = r[5];                            // cp4, cp5, n.y, n.z
+                if constexpr (COORD) {
+                    const float4 q4 = r[4];                        // cp0..3
+                    const float c0 = q3.x + q4.x * dx + q4.y * dy;
+                    const float c1 = q3.y + q4.z * dx + q4.w * dy;
+                    const float c2 = q3.z + q5.x * dx + q5.y * dy;
+                    Co0 += c0 * aT; Co1 += c1 * aT; Co2 += c2 * aT;
+                }
+                if constexpr (DEPTH) {
+                    const float t = q2.y + (q2.z * dx + q2.w * dy);
+                    Depth += t * aT;
+                }
+                if constexpr (NORMAL) { N0 += q3.w * aT; N1 += q5.z * aT; N2 += q5.w * aT; }
+                // only the index of the median splat is tracked here; its coordinate and depth are re-evaluated once
+                // per pixel after the loop (forward.cu:640-652 stores them inside the loop)
+                max_contributor = before_median ? contributor : max_contributor;
+            }
+            weight += aT;
+            T = contrib ? test_T : T;
+            last_contributor = contrib ? contributor : last_contributor;
+        }
+        __builtin_amdgcn_wave_barrier();                           // the next round's staging writes stay behind these reads
+    }
+
+    if (inside) {
+        const size_t HW = (size_t)a.H * a.W;
+        const size_t pix = (size_t)a.W * py + px;
+        if constexpr (GEO) {
+            if (max_contributor != 0xFFFFFFFFu) {
+                const uint32_t id = a.point_list[range.x + max_contributor - 1];
+                const float4* src = (const float4*)(a.rec + (size_t)id * REC_F);
+                const float4 q0 = src[0];
+                const float dx = q0.x - pixfx, dy = q0.y - pixfy;
+                if constexpr (COORD) {
+                    const float4 q3 = src[3], q4 = src[4], q5 = src[5];
+                    mC0 = q3.x + q4.x * dx + q4.y * dy;
+                    mC1 = q3.y + q4.z * dx + q4.w * dy;
+                    mC2 = q3.z + q5.x * dx + q5.y * dy;
+                }
+                if constexpr (DEPTH) {
+                    const float4 q2 = src[2];
+                    mDepth = q2.y + (q2.z * dx + q2.w * dy);
+                }
+            }
+        }
+        a.n_contrib[pix] = last_contributor;
+        a.n_contrib[pix + HW] = max_contributor;
+        a.out_color[pix] = C0 + T * a.bg[0];
+        a.out_color[HW + pix] = C1 + T * a.bg[1];
+        a.out_color[2 * HW + pix] = C2 + T * a.bg[2];
+        a.out_alpha[pix] = weight;
+        const float pnx = (pixfx - a.W / 2.f) / a.fx, pny = (pixfy - a.H / 2.f) / a.fy;
+        const float ln = sqrtf(pnx * pnx + pny * pny + 1);
+        if constexpr (COORD) {
+            a.out_coord[pix] = last_contributor ? Co0 / weight : 0.f;
+            a.out_coord[HW + pix] = last_contributor ? Co1 / weight : 0.f;
+            a.out_coord[2 * HW + pix] = last_contributor ? Co2 / weight : 0.f;
+            a.accum_coord[pix] = Co0; a.accum_coord[HW + pix] = Co1; a.accum_coord[2 * HW + pix] = Co2;
+            a.out_mcoord[pix] = mC0; a.out_mcoord[HW + pix] = mC1; a.out_mcoord[2 * HW + pix] = mC2;
+        } else {
+            a.out_coord[pix] = 0.f; a.out_coord[HW + pix] = 0.f; a.out_coord[2 * HW + pix] = 0.f;
+            a.out_mcoord[pix] = 0.f; a.out_mcoord[HW + pix] = 0.f; a.out_mcoord[2 * HW + pix] = 0.f;
+        }
+        if constexpr (DEPTH) {
+            const float depth_ln = Depth / ln;
+            a.accum_depth[pix] = depth_ln;
+            a.out_depth[pix] = last_contributor ? depth_ln / weight : 0.f;
+            a.out_mdepth[pix] = mDepth / ln;
+        } else {
+            a.out_depth[pix] = 0.f; a.out_mdepth[pix] = 0.f;
+        }
+        if constexpr (NORMAL) {
+            if (last_contributor) {
+                float len = sqrtf(N0 * N0 + N1 * N1 + N2 * N2);
+                a.normal_length[pix] = len;
+                len = fmaxf(len, 1.0E-12F);
+                a.out_normal[pix] = N0 / len; a.out_normal[HW + pix] = N1 / len; a.out_normal[2 * HW + pix] = N2 / len;
+            } else {
+                a.normal_length[pix] = 1.f;
+                a.out_normal[pix] = 0.f; a.out_normal[HW + pix] = 0.f; a.out_normal[2 * HW + pix] = 0.f;
+            }
+        } else {
+            a.out_normal[pix] = 0.f; a.out_normal[HW + pix] = 0.f; a.out_normal[2 * HW + pix] = 0.f;
+        }
+    }
+}
+
+hipError_t launch_blend_fwd(hipStream_t s, const BlendFwdArgs& a, bool coord, bool depth)
+{
+    const dim3 grid(quad_grid_blocks(a.gx, a.gy)), block(64);
+    // dispatch of forward.cu:732-739: NORMAL is on whenever COORD or DEPTH is
+    if (coord && depth) hipLaunchKernelGGL((blend_fwd_kernel<true, true, true>), grid, block, 0, s, a);
+    else if (coord) hipLaunchKernelGGL((blend_fwd_kernel<true, false, true>), grid, block, 0, s, a);
+    else if (depth) hipLaunchKernelGGL((blend_fwd_kernel<false, true, true>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((blend_fwd_kernel<false, false, false>), grid, block, 0, s, a);
+    return hipGetLastError();
+}

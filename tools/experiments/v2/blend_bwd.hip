@@ -1,7 +1,8 @@
 // blend_bwd.hip -- backward of the tile blend for gfx950 (wave64).
 // Replaces BACKWARD::render / renderCUDA (DGR/cuda_rasterizer/backward.cu:631-1016, dispatch 1101-1163).
 //
-// Same tiling as the forward (workgroup = tile, wave = 8x8 quad, lane = pixel), traversed back to front.
+// Same tiling as the forward (ONE single-wave workgroup per 8x8 quad, lane = pixel; no workgroup barrier, every wave stages the
+// tile's list for itself, 64 splats per round -- see blend_fwd.hip), traversed back to front from the quad's own deepest contributor.
 // What is different from the reference, by design:
 //  * The reference keeps one suffix recurrence per output channel (11 of them) and issues up to 25 global float
 //    atomics per (pixel, splat) pair.  Every recurrence is linear in the channel value, and the upstream gradient
@@ -19,7 +20,7 @@
 // T is recovered exactly like the reference does (T_final = 1 - out_alpha, T <- T / (1 - alpha), backward.cu:706,857).
 #include "blend_common.h"
 
-#define BCHUNK 128            // splats staged per round in the backward (LDS is shared with the reduction scratch)
+#define BCHUNK 64             // splats staged per round = one per lane
 
 // Column writes of the transpose buffer: lane l stores its value of moment r at  base + r * stride + 4 l.  That is exactly the
 // address pattern of ds_write_addtid_b32 (address = M0 + offset + 4 * lane, no address VGPR), which moves 4 B per lane to the LDS
@@ -75,15 +76,13 @@ template <int STRIDE_B, int R0, int N> struct ColWrite {          // N > 5: five
 //  12    St = sum dLt   13 Stx   14 Sty   15..17 sum w*dL/dnormal_ch
 //  18 Q0 = sum q  19 Qx  20 Qy  21 Qxx  22 Qxy  23 Qyy  (q = dL/dG * G)   24 Z = abs-sum for dL_dmean2D.z
 template <bool COORD, bool DEPTH, bool NORMAL, bool ABS = true>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(64)
 blend_bwd_kernel(const BlendBwdArgs a)
 {
     constexpr bool GEO = COORD || DEPTH || NORMAL;
     constexpr int NQ = GEO ? 6 : 3;
     __shared__ float4 chunk[BCHUNK * NQ];
     __shared__ uint32_t chunk_id[BCHUNK];
-    __shared__ uint64_t quad_bits[4][2];                // [quad][staging wave pair]: BCHUNK = 2 x 64 splats
-    __shared__ int wave_max[4];
     constexpr int NROWS = 9 + (ABS ? 1 : 0) + (COORD ? 9 : 0) + (DEPTH ? 3 : 0) + (NORMAL ? 3 : 0);   // live moments of this instance
     // floats per row of the per-wave transpose buffer: 16-byte aligned rows for the b128 row reads.  Columns are written with
     // ds_write_addtid_b32 (one dword per lane at consecutive addresses: conflict-free whatever the stride); the ROW reads -- 4
@@ -98,17 +97,18 @@ blend_bwd_kernel(const BlendBwdArgs a)
                                : NROWS == 10 ? 0x4431eu       // f = 2,3,1,0,3,0,0,1,0,1
                                : NROWS == 16 ? 0xa7dbb9c7u    // f = 3,1,0,3,1,2,3,2,3,2,1,3,3,1,2,2 (8 conflict cycles left of 32)
                                : 0u;
-    __shared__ __attribute__((aligned(16))) float red[4][NROWS * RED_STRIDE];
+    __shared__ __attribute__((aligned(16))) float red[NROWS * RED_STRIDE];
 
-    uint32_t tile;
-    if (!tile_select(blockIdx.x, a.gx, a.gy, a.bucket_fill, a.bucket_list, tile)) return;      // heaviest tiles first (common.h)
+    uint32_t tile, quad;
+    if (!quad_for_block(blockIdx.x, a.gx, a.gy, tile, quad)) return;
     const uint32_t tx = tile % a.gx, ty = tile / a.gx;
-    const uint32_t tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const uint32_t px = tx * TILE + (wid & 1) * 8 + (lane & 7);
-    const uint32_t py = ty * TILE + (wid >> 1) * 8 + (lane >> 3);
+    const uint32_t lane = threadIdx.x;
+    const uint32_t qx = tx * TILE + (quad & 1) * 8, qy = ty * TILE + (quad >> 1) * 8;
+    const uint32_t px = qx + (lane & 7);
+    const uint32_t py = qy + (lane >> 3);
     const bool inside = px < (uint32_t)a.W && py < (uint32_t)a.H;
     const float pixfx = (float)px, pixfy = (float)py;
-    const float tile_x0 = (float)(tx * TILE), tile_y0 = (float)(ty * TILE);
+    const float quad_x0 = (float)qx, quad_y0 = (float)qy;
     const size_t HW = (size_t)a.H * a.W;
     const size_t pix = (size_t)a.W * py + px;
 
@@ -133,7 +133,7 @@ blend_bwd_kernel(const BlendBwdArgs a)
         }
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
-        if (lane == 0 && acc != 0.f) atomicAdd(&a.l1_loss[16 * ((blockIdx.x * 4 + wid) & 63)], acc);
+        if (lane == 0 && acc != 0.f) atomicAdd(&a.l1_loss[16 * (blockIdx.x & 63)], acc);
     }
     float gc0 = 0, gc1 = 0, gc2 = 0, gm0 = 0, gm1 = 0, gm2 = 0, g_t = 0, g_mt = 0, gn0 = 0, gn1 = 0, gn2 = 0;
     if (last_contributor > 0) {
@@ -174,23 +174,20 @@ blend_bwd_kernel(const BlendBwdArgs a)
         }
     }
 
-    // nothing behind the deepest last_contributor of the tile is ever touched: start there
-    int my_wave_max;                               // ... and this wave's own deepest one (wave-uniform): rows behind it are skipped
+    // nothing behind the deepest last_contributor of THIS quad is ever touched by it: the wave walks elements [0, n) of the tile's
+    // list back to front
+    int n;
     {
         int m = last_contributor;
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) m = max(m, __shfl_xor(m, off, 64));
-        if (lane == 0) wave_max[wid] = m;
-        my_wave_max = __builtin_amdgcn_readfirstlane(m);
+        n = __builtin_amdgcn_readfirstlane(m);
     }
-    __syncthreads();
-    const int n = max(max(wave_max[0], wave_max[1]), max(wave_max[2], wave_max[3]));   // elements [0, n) of the range
-    const int rounds = (n + BCHUNK - 1) / BCHUNK;
 
     float T = T_final, S = 0.f, Dprev = 0.f, last_alpha = 0.f;
     const bool has_bg = (a.bg[0] != 0.f) || (a.bg[1] != 0.f) || (a.bg[2] != 0.f);      // wave-uniform
     const float halfW = 0.5f * a.W, halfH = 0.5f * a.H;
-    float* myred = red[wid];
+    float* myred = red;
     // LDS byte offset of this wave's transpose buffer (the low half of the flat address of a __shared__ object is its LDS offset)
     const unsigned myred_m0 = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(size_t)myred);
     constexpr int LPR = NROWS <= 16 ? 4 : 2;             // lanes per row of the transpose buffer
@@ -205,11 +202,12 @@ blend_bwd_kernel(const BlendBwdArgs a)
     if (!COMPACT && !DEPTH && slot_of_row >= 12) slot_of_row += 3;
     if (!COMPACT && !NORMAL && slot_of_row >= 15) slot_of_row += 3;
 
-    for (int i = 0; i < rounds; i++) {
-        __syncthreads();
-        uint32_t qmask = 0;
-        if (tid < BCHUNK) {
-            const int progress = i * BCHUNK + (int)tid;      // position counted from the back of [0, n)
+    for (int base = 0; base < n; base += BCHUNK) {
+        // ---- stage: lane l takes the splat at position base + l counted from the back of [0, n)  (LDS operations of one wave
+        //      complete in issue order: no barrier between the rounds or between these writes and the row reads below)
+        bool reach = false;
+        {
+            const int progress = base + (int)lane;
             if (progress < n) {
                 const uint32_t id = a.point_list[range.x + (uint32_t)(n - 1 - progress)];
                 const float4* src = (const float4*)(a.rec + (size_t)id * REC_F);
@@ -219,27 +217,18 @@ blend_bwd_kernel(const BlendBwdArgs a)
                     q2.x = a.colors_precomp[3 * (size_t)id + 2];
                 }
                 if constexpr (!GEO) q2.y = __uint_as_float(id);      // the colour-only row never reads ts: the id rides in its slot
-                chunk[tid * NQ + 0] = q0; chunk[tid * NQ + 1] = q1; chunk[tid * NQ + 2] = q2;
-                if constexpr (GEO) { chunk[tid * NQ + 3] = src[3]; chunk[tid * NQ + 4] = src[4]; chunk[tid * NQ + 5] = src[5]; chunk_id[tid] = id; }
-                qmask = quad_reach_mask(q0, q1, tile_x0, tile_y0);
+                chunk[lane * NQ + 0] = q0; chunk[lane * NQ + 1] = q1; chunk[lane * NQ + 2] = q2;
+                if constexpr (GEO) { chunk[lane * NQ + 3] = src[3]; chunk[lane * NQ + 4] = src[4]; chunk[lane * NQ + 5] = src[5]; chunk_id[lane] = id; }
+                reach = quad_reach_one(q0, q1, quad_x0, quad_y0);
             }
         }
-        if (wid < 2) {
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-                const uint64_t b = __ballot((qmask >> q) & 1u);
-                if (lane == 0) quad_bits[q][wid] = b;
-            }
-        }
-        __syncthreads();
-        for (int sw = 0; sw < 2; sw++) {
-            uint64_t bits = quad_bits[wid][sw];
-            bits = uniform64(bits);
+        uint64_t bits = __ballot(reach);                 // wave-uniform to-do set of this round
+        __builtin_amdgcn_wave_barrier();
+        {
             while (bits != 0ull) {
-                const int j = sw * 64 + __builtin_ctzll(bits);
+                const int j = __builtin_ctzll(bits);
                 bits &= bits - 1;
-                const int eidx = n - 1 - (i * BCHUNK + j);      // 0-based position in the tile's list = the reference's `contributor`
-                if (eidx >= my_wave_max) continue;              // (scalar test) behind every pixel of this quad: another quad's tail
+                const int eidx = n - 1 - (base + j);            // 0-based position in the tile's list = the reference's `contributor`
                 const float4 q0 = chunk[j * NQ + 0];
                 const float4 q1 = chunk[j * NQ + 1];
                 const float dx = q0.x - pixfx, dy = q0.y - pixfy;
@@ -321,25 +310,19 @@ blend_bwd_kernel(const BlendBwdArgs a)
                     part = (acc4.x + acc4.y) + (acc4.z + acc4.w);
                 }
                 __builtin_amdgcn_wave_barrier();      // ... and the next splat's column writes must stay behind these row reads
-                // the LPR partials of a row sit 64 / LPR lanes apart: v_permlane32_swap / v_permlane16_swap (gfx950) fold them in the
-                // vector ALU -- no trip through the LDS crossbar (ds_bpermute: 6 LDS cycles each on the kernel's busiest unit, and a
-                // round trip of latency in the middle of the row's dependency chain)
-                const auto s32 = __builtin_amdgcn_permlane32_swap(__float_as_uint(part), __float_as_uint(part), false, false);
-                float tot = __uint_as_float(s32[0]) + __uint_as_float(s32[1]);
-                if constexpr (LPR == 4) {
-                    const auto s16 = __builtin_amdgcn_permlane16_swap(__float_as_uint(tot), __float_as_uint(tot), false, false);
-                    tot = __uint_as_float(s16[0]) + __uint_as_float(s16[1]);
-                }
+                float tot = part + __shfl_xor(part, 32, 64);
+                if constexpr (LPR == 4) tot += __shfl_xor(tot, 16, 64);
                 const uint32_t gid = GEO ? chunk_id[j] : __float_as_uint(q2.y);
                 if (lane < NROWS) atomicAdd(&a.gacc[(size_t)gid * GACC_F + slot_of_row], tot);
             }
         }
+        __builtin_amdgcn_wave_barrier();                 // the next round's staging writes stay behind this round's reads
     }
 }
 
 hipError_t launch_blend_bwd(hipStream_t s, const BlendBwdArgs& a, bool coord, bool depth, bool* compact_layout, int* instance_bits)
 {
-    const dim3 grid(tile_grid_blocks(a.gx, a.gy)), block(256);
+    const dim3 grid(quad_grid_blocks(a.gx, a.gy)), block(64);
     // The reference instantiates (COORD, DEPTH, NORMAL) from require_coord / require_depth alone (backward.cu:1153-1160).
     // A branch whose upstream gradients are all absent (NULL = zero: the output did not take part in the loss, which is
     // the case for IGS's refine loop, whose loss only sees the colour image) contributes exact zeros everywhere, so the

@@ -2,7 +2,7 @@
 // Replaces FORWARD::render / renderCUDA (DGR/cuda_rasterizer/forward.cu:428-742).
 //
 // One 256-thread workgroup per 16x16 tile; each of its 4 waves owns an 8x8 pixel quad (lane = pixel).
-// Splats are staged 192 at a time into LDS as packed 96-byte records gathered as whole 128-byte lines from the
+// Splats are staged 256 at a time into LDS as packed 96-byte records gathered as whole 128-byte lines from the
 // per-Gaussian record array.  While staging, the thread that holds a splat also decides which of the four quads
 // it can reach at all (bounding box of the alpha >= 1/255 ellipse against the quad's pixel-centre rectangle,
 // conservative); a ballot turns that into one 256-bit "to do" set per quad, so each wave walks only its own
@@ -10,12 +10,8 @@
 // record being fetched while the current one is blended.
 // Tiles are handed to workgroups through an XCD-aware remap so that the tiles sharing an L2 are neighbours.
 #include "blend_common.h"
-
-// 192 splats staged per round by the first three waves: 18 KB of LDS per workgroup instead of 24.5 (256 splats), so that eight
-// workgroups fit a CU; together with the 64-VGPR budget below (8 waves per SIMD instead of 6; two dwords spill outside the row
-// loop) the fuller machine hides more of a row's dependency chain: 64.4 -> 61.0 us on the bench scene (same-box A/B, round 2)
 #undef CHUNK
-#define CHUNK 192
+#define CHUNK 192            // 18 KB of staged records per workgroup: 8 workgroups per CU
 #define NSW (CHUNK / 64)     // staging waves
 
 template <bool COORD, bool DEPTH, bool NORMAL>
@@ -35,7 +31,7 @@ blend_fwd_kernel(const BlendFwdArgs a)
         __threadfence_system();
     }
     uint32_t tile;
-    if (!tile_select(blockIdx.x, a.gx, a.gy, a.bucket_fill, a.bucket_list, tile)) return;      // heaviest tiles first (common.h)
+    if (!tile_for_block(blockIdx.x, a.gx, a.gy, tile)) return;
     const uint32_t tx = tile % a.gx, ty = tile / a.gx;
     const uint32_t tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const uint32_t px = tx * TILE + (wid & 1) * 8 + (lane & 7);
