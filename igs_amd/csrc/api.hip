@@ -348,7 +348,10 @@ static int forward_impl(
     ba.accum_coord = (float*)(ibase + IL.accum_coord); ba.accum_depth = (float*)(ibase + IL.accum_depth);
     ba.normal_length = (float*)(ibase + IL.normal_length);
     ba.stats_src = slab_stats; ba.flag_src = counters + 1; ba.host_dst = slab_pending ? g_slot.pinned_dev : nullptr;
-    ba.bucket_fill = order_fill; ba.bucket_list = order_list;
+    // (the forward keeps the plain XCD-aware order: dispatching its heaviest tiles first separates the compute-heavy tiles from the
+    //  store-heavy near-empty ones -- every tile writes 15 floats per pixel -- and the stores no longer hide under the blending:
+    //  62 -> 83 us on the bench scene, same-box A/B; the backward, which writes almost nothing per tile, takes the ordered lists)
+    (void)order_fill; (void)order_list;
     if (slab_pending) { g_host_seq = g_host_seq + 1 ? g_host_seq + 1 : 1; g_slot.pinned[3] = 0; }
     ba.host_seq = g_host_seq;
     g_status_stream = s;
