@@ -228,7 +228,6 @@ static int forward_impl(
     bool slab_pending = false;            // slab path: the host has not looked at R yet
     uint32_t slab_size = 0;                // slab size of this call
     const uint32_t* slab_stats = nullptr;
-    const uint32_t *order_fill = nullptr, *order_list = nullptr;      // load-ordered tile lists (slab path only)
 
     if (!force_radix) {
         // ---------------- slab binning (default): nothing below needs the host to know R ----------------
@@ -254,15 +253,13 @@ static int forward_impl(
         point_list = (uint32_t*)(bbase + KL.point_list);
         uint64_t* pairs = (uint64_t*)(bbase + KL.pairs);
         counters = (uint32_t*)(ibase + IL.counters);
-        HIP_TRY(hipMemsetAsync(tile_count, 0, IL.zero_end - IL.tile_count, s), "memset tile counters");   // tile_count + stats + counters + load classes
+        HIP_TRY(hipMemsetAsync(tile_count, 0, IL.zero_end - IL.tile_count, s), "memset tile counters");   // tile_count + stats + counters
         prof_mark(s, ST_GAP);
         HIP_TRY(launch_preprocess_fwd(s, fp, rec, tiles, nullptr, nullptr, radii, counters, nullptr, 0, tile_count, pairs, slab_size),
                 "preprocess_fwd launch");
         DBG_SYNC("preprocess_fwd");
         prof_mark(s, ST_PREPROCESS);
-        HIP_TRY(launch_tile_sort(s, (uint32_t)Tn, tile_count, pairs, point_list, ranges, slab_size, stats, counters,
-                                 (uint32_t*)(ibase + IL.bucket_fill), (uint32_t*)(ibase + IL.bucket_list)), "tile_sort launch");
-        order_fill = (const uint32_t*)(ibase + IL.bucket_fill); order_list = (const uint32_t*)(ibase + IL.bucket_list);
+        HIP_TRY(launch_tile_sort(s, (uint32_t)Tn, tile_count, pairs, point_list, ranges, slab_size, stats, counters), "tile_sort launch");
         DBG_SYNC("tile_sort");
         prof_mark(s, ST_TILE_SORT);
         slab_stats = stats;
@@ -271,8 +268,7 @@ static int forward_impl(
     } else {
         // ---------------- global radix binning (fallback for tiles denser than TILE_SORT_BIG) ----------------
         HIP_TRY(hipMemsetAsync(counters, 0, counter_bytes, s), "memset counters");
-        HIP_TRY(hipMemsetAsync(ibase + IL.bucket_fill, 0, LOAD_BUCKETS * 4, s), "memset load classes");      // = no load-ordered lists
-        order_fill = (const uint32_t*)(ibase + IL.bucket_fill); order_list = (const uint32_t*)(ibase + IL.bucket_list);
+
         uint32_t dnb = 0, dper = 0;
         sort_geometry((uint32_t)P, &dnb, &dper);
         HIP_TRY(hipMemsetAsync(ghist, 0, (size_t)256 * SORT_MAX_BLOCKS * 4, s), "memset depth-sort histogram 0");
@@ -348,10 +344,7 @@ static int forward_impl(
     ba.accum_coord = (float*)(ibase + IL.accum_coord); ba.accum_depth = (float*)(ibase + IL.accum_depth);
     ba.normal_length = (float*)(ibase + IL.normal_length);
     ba.stats_src = slab_stats; ba.flag_src = counters + 1; ba.host_dst = slab_pending ? g_slot.pinned_dev : nullptr;
-    // (the forward keeps the plain XCD-aware order: dispatching its heaviest tiles first separates the compute-heavy tiles from the
-    //  store-heavy near-empty ones -- every tile writes 15 floats per pixel -- and the stores no longer hide under the blending:
-    //  62 -> 83 us on the bench scene, same-box A/B; the backward, which writes almost nothing per tile, takes the ordered lists)
-    (void)order_fill; (void)order_list;
+    ba.tile_order = (uint32_t*)(ibase + IL.tile_order);          // built on the side for the backward (both binning paths)
     if (slab_pending) { g_host_seq = g_host_seq + 1 ? g_host_seq + 1 : 1; g_slot.pinned[3] = 0; }
     ba.host_seq = g_host_seq;
     g_status_stream = s;
@@ -520,8 +513,7 @@ static int backward_impl(
     ba.gacc = gacc;
     ba.l1_gt = l1_gt; ba.l1_color = l1_color; ba.l1_scale = l1_scale; ba.l1_loss = loss_shards;
     ba.want_absgrad = (fuse && !dL_dmean2D) ? 0 : 1;
-    // load-ordered tile lists of the forward (slab binning only: the global-sort path leaves them empty, total 0 != T)
-    ba.bucket_fill = (const uint32_t*)(ibase + IL.bucket_fill); ba.bucket_list = (const uint32_t*)(ibase + IL.bucket_list);
+    ba.tile_order = (const uint32_t*)(ibase + IL.tile_order);    // the forward's blend kernel ordered the tiles heaviest-first
     bool gacc_compact = false;
     int inst_bits = -1;
     if (R > 0) {

@@ -101,7 +101,11 @@ blend_bwd_kernel(const BlendBwdArgs a)
     __shared__ __attribute__((aligned(16))) float red[4][NROWS * RED_STRIDE];
 
     uint32_t tile;
-    if (!tile_select(blockIdx.x, a.gx, a.gy, a.bucket_fill, a.bucket_list, tile)) return;      // heaviest tiles first (common.h)
+    if (a.tile_order) {                                  // heaviest tiles first (common.h: build_tile_order)
+        if (blockIdx.x >= (uint32_t)(a.gx * a.gy)) return;
+        tile = a.tile_order[blockIdx.x];
+        if (tile >= (uint32_t)(a.gx * a.gy)) return;      // (a corrupt image buffer must not turn into an out-of-bounds access)
+    } else if (!tile_for_block(blockIdx.x, a.gx, a.gy, tile)) return;
     const uint32_t tx = tile % a.gx, ty = tile / a.gx;
     const uint32_t tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const uint32_t px = tx * TILE + (wid & 1) * 8 + (lane & 7);

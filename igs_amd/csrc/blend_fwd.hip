@@ -27,6 +27,7 @@ blend_fwd_kernel(const BlendFwdArgs a)
     __shared__ float4 chunk[CHUNK * NQ];
     __shared__ uint64_t quad_bits[4][NSW];              // [quad][staging wave]
     __shared__ int wave_done[4];
+    __shared__ uint32_t order_hist[2 * LOAD_CLASSES];
 
     if (blockIdx.x == 0 && threadIdx.x == 0 && a.host_dst) {
         a.host_dst[0] = a.stats_src[0]; a.host_dst[1] = a.stats_src[1]; a.host_dst[2] = a.flag_src[0];
@@ -34,8 +35,10 @@ blend_fwd_kernel(const BlendFwdArgs a)
         __hip_atomic_store(&a.host_dst[3], a.host_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);      // the host polls this word
         __threadfence_system();
     }
+    // workgroup 0, on the side: the tile order of the backward blend (common.h: build_tile_order), before it turns to its own tile
+    if (blockIdx.x == 0 && a.tile_order) build_tile_order(a.ranges, (uint32_t)(a.gx * a.gy), a.tile_order, order_hist);
     uint32_t tile;
-    if (!tile_select(blockIdx.x, a.gx, a.gy, a.bucket_fill, a.bucket_list, tile)) return;      // heaviest tiles first (common.h)
+    if (!tile_for_block(blockIdx.x, a.gx, a.gy, tile)) return;
     const uint32_t tx = tile % a.gx, ty = tile / a.gx;
     const uint32_t tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const uint32_t px = tx * TILE + (wid & 1) * 8 + (lane & 7);

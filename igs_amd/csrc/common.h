@@ -84,9 +84,9 @@ struct SlabLayout {
         total = o + 256;
     }
 };
-#define LOAD_BUCKETS 64                     // tiles are listed by load class (see tile_sort_kernel): heaviest classes are dispatched first
+#define LOAD_CLASSES 64                     // tiles are ordered by load class for the backward blend: heaviest classes are dispatched first
 struct ImgLayout {
-    size_t ranges, n_contrib, accum_coord, accum_depth, normal_length, tile_count, stats, counters, bucket_fill, zero_end, bucket_list, total;
+    size_t ranges, n_contrib, accum_coord, accum_depth, normal_length, tile_count, stats, counters, zero_end, tile_order, total;
     __host__ ImgLayout(size_t HW, size_t T) {
         size_t o = 0;
         ranges = o;        o += align_up(T * 8, 256);
@@ -96,10 +96,9 @@ struct ImgLayout {
         normal_length = o; o += align_up(HW * 4, 256);
         tile_count = o;    o += align_up(T * 4, 256);      // slab binning: instances per tile (fill cursor)
         stats = o;         o += 256;                       // ... [0] R, [1] largest tile that overflowed its slab (0 = none)
-        counters = o;      o += (COUNTER_SHARDS + 1) * COUNTER_SHARD_STRIDE * 4;   // ... instance-count shards
-        bucket_fill = o;   o += LOAD_BUCKETS * 4;          // ... tiles per load class; these four are zeroed by one fill
+        counters = o;      o += (COUNTER_SHARDS + 1) * COUNTER_SHARD_STRIDE * 4;   // ... instance-count shards; these three are zeroed by one fill
         zero_end = o;
-        bucket_list = o;   o += align_up((size_t)LOAD_BUCKETS * T * 4, 256);       // [class][position] tile ids
+        tile_order = o;    o += align_up(T * 4, 256);      // tile ids, heaviest load class first (written by blend_fwd's workgroup 0)
         total = o + 256;
     }
 };
@@ -122,8 +121,7 @@ hipError_t launch_preprocess_fwd(hipStream_t s, const FwdParams& p, float* rec, 
                                  uint32_t* tile_count, uint64_t* pairs, uint32_t slab);
 void sort_geometry(uint32_t n, uint32_t* nb, uint32_t* per);
 hipError_t launch_tile_sort(hipStream_t s, uint32_t T, const uint32_t* tile_count, const uint64_t* pairs, uint32_t* point_list,
-                            uint32_t* ranges, uint32_t slab, uint32_t* stats, const uint32_t* counters, uint32_t* bucket_fill,
-                            uint32_t* bucket_list);
+                            uint32_t* ranges, uint32_t slab, uint32_t* stats, const uint32_t* counters);
 hipError_t launch_compact_lists(hipStream_t s, uint32_t T, const uint32_t* ranges_in, const uint32_t* list_in, uint32_t* ranges_out,
                                 uint32_t* list_out, uint32_t out_capacity);
 hipError_t launch_mark_visible(hipStream_t s, int P, const float* means3D, const float* view, uint8_t* present);
@@ -148,7 +146,7 @@ struct BlendFwdArgs {
     uint32_t* n_contrib; float *accum_coord, *accum_depth, *normal_length;
     // slab binning: workgroup 0 forwards {R, overflow, prefilter flag} to host-visible memory (no copy kernels on the stream)
     const uint32_t* stats_src; const uint32_t* flag_src; uint32_t* host_dst; uint32_t host_seq;      // host_dst[3] = host_seq, written last
-    const uint32_t* bucket_fill = nullptr; const uint32_t* bucket_list = nullptr;      // load-ordered tile lists (NULL: plain XCD-aware order)
+    uint32_t* tile_order = nullptr;            // [T] out: tile ids by descending load class, built by workgroup 0 on the side (for the backward)
 };
 hipError_t launch_blend_fwd(hipStream_t s, const BlendFwdArgs& a, bool coord, bool depth);
 
@@ -164,7 +162,7 @@ struct BlendBwdArgs {
     // 0: nobody reads dL_dmean2D.z (the absolute screen-space gradient sum the densification statistics use): the colour-only
     // instance then drops that moment (its |.| terms, one LDS row, one atomic lane per row)
     int want_absgrad = 1;
-    const uint32_t* bucket_fill = nullptr; const uint32_t* bucket_list = nullptr;      // load-ordered tile lists (NULL: plain XCD-aware order)
+    const uint32_t* tile_order = nullptr;      // [T] tile ids, heaviest first (the forward's blend kernel wrote them); NULL: plain XCD-aware order
 };
 hipError_t launch_blend_bwd(hipStream_t s, const BlendBwdArgs& a, bool coord, bool depth, bool* compact_layout, int* instance_bits = nullptr);
 
@@ -300,41 +298,37 @@ __device__ __forceinline__ bool tile_for_block(uint32_t b, uint32_t gx, uint32_t
 }
 static inline uint32_t tile_grid_blocks(uint32_t gx, uint32_t gy) { return 8u * ((gy + 7u) / 8u) * gx; }
 
-// Longest-first dispatch.  A tile's blend time is proportional to its instance count, which ranges from 0 to several times the
-// mean; workgroups are dispatched in block order, and with ~2.7 generations of resident workgroups a heavy tile that starts late
-// runs on alone while the rest of the chip idles (round 2, rocprofv3: ~20 % of the wave slots empty over both blend kernels).  The
-// tile sort -- the first kernel that sees the final counts -- therefore files every tile under a load class, and block b of the
-// BACKWARD blend kernel takes the b-th tile in descending class order: 64 class sizes, one wave prefix sum, two dependent loads.
-// Measured (same-box A/B, round 2): backward 214.6 -> 194.5 us on the dense diagnostic scene (mean 430 instances per tile), no change
-// on the bench scene (mean 95: its idle slots come from the unequal quads INSIDE a workgroup, not from a tail).
+// Longest-first dispatch of the BACKWARD blend.  A tile's blend time is proportional to its instance count, which ranges from 0 to
+// several times the mean; workgroups are dispatched in block order, and with ~2.7 generations of resident workgroups a heavy tile
+// that starts late runs on alone while the rest of the chip idles.  Workgroup 0 of the forward blend kernel -- which has the final
+// ranges in front of it and 60 us of kernel around it -- orders the tiles by load class (counting sort in LDS, build_tile_order) and
+// block b of the backward takes order[b].  Measured (same-box A/B, round 2): backward 214.6 -> 194.5 us on the dense diagnostic
+// scene (mean 430 instances per tile), no change on the bench scene (mean 95: its idle slots come from the unequal quads INSIDE a
+// workgroup, not from a tail).  The forward itself keeps the plain order: heaviest-first separates its compute-heavy tiles from the
+// store-heavy near-empty ones (every tile writes 15 floats per pixel) and the stores no longer hide under the blending: 62 -> 83 us.
+// (First version: the tile sort filed the tiles with one returning global atomic each -- 5440 atomics on a handful of words
+// serialise at ~12 ns each: tile_sort 17 -> 58 us.)
 __device__ __forceinline__ uint32_t load_class(uint32_t n) {            // 0 = empty ... 63 = heaviest; ~13 % of load per class
     if (n == 0u) return 0u;
     const uint32_t c = 1u + (uint32_t)(5.5f * __log2f((float)n));
-    return c > (uint32_t)(LOAD_BUCKETS - 1) ? (uint32_t)(LOAD_BUCKETS - 1) : c;
+    return c > (uint32_t)(LOAD_CLASSES - 1) ? (uint32_t)(LOAD_CLASSES - 1) : c;
 }
-// Block -> tile.  wave-uniform; every lane of the calling wave must be active.  With valid load-class lists (their sizes add up to the
-// number of tiles: the slab-binning forward zeroes the sizes and the tile sort files every tile; the global-sort path only zeroes
-// them) block b takes the b-th tile in descending class order; otherwise the plain XCD-aware order.  Returns false for blocks that
-// have no tile.
-__device__ __forceinline__ bool tile_select(uint32_t b, uint32_t gx, uint32_t gy, const uint32_t* __restrict__ bucket_fill,
-                                            const uint32_t* __restrict__ bucket_list, uint32_t& tile) {
-    if (bucket_fill && bucket_list) {
-        const uint32_t T = gx * gy;
-        const uint32_t lane = threadIdx.x & 63u;
-        const uint32_t c = bucket_fill[LOAD_BUCKETS - 1 - lane];        // lane 0 = heaviest class
+// called by ALL 256 threads of one workgroup; `hist` = 2 * LOAD_CLASSES words of LDS
+__device__ __forceinline__ void build_tile_order(const uint32_t* __restrict__ ranges, uint32_t T, uint32_t* __restrict__ order, uint32_t* hist) {
+    const uint32_t tid = threadIdx.x;
+    if (tid < 2 * LOAD_CLASSES) hist[tid] = 0u;
+    __syncthreads();
+    for (uint32_t t = tid; t < T; t += 256) atomicAdd(&hist[load_class(ranges[2 * t + 1] - ranges[2 * t])], 1u);
+    __syncthreads();
+    if (tid < 64) {                                                      // start of every class in descending order (one wave)
+        const uint32_t c = hist[LOAD_CLASSES - 1 - tid];
         uint32_t incl = c;
 #pragma unroll
-        for (int off = 1; off < 64; off <<= 1) { const uint32_t v = (uint32_t)__shfl_up((int)incl, off, 64); if (lane >= (uint32_t)off) incl += v; }
-        const uint32_t total = (uint32_t)__shfl((int)incl, 63, 64);
-        if (total == T) {
-            if (b >= T) return false;
-            const int l = __builtin_ctzll(__ballot(incl > b));
-            const uint32_t before = (uint32_t)__shfl((int)(incl - c), l, 64);
-            tile = bucket_list[(size_t)(LOAD_BUCKETS - 1 - l) * T + (b - before)];
-            return tile < T;
-        }
+        for (int off = 1; off < 64; off <<= 1) { const uint32_t v = (uint32_t)__shfl_up((int)incl, off, 64); if (tid >= (uint32_t)off) incl += v; }
+        hist[LOAD_CLASSES + (LOAD_CLASSES - 1 - tid)] = incl - c;
     }
-    return tile_for_block(b, gx, gy, tile);
+    __syncthreads();
+    for (uint32_t t = tid; t < T; t += 256) order[atomicAdd(&hist[LOAD_CLASSES + load_class(ranges[2 * t + 1] - ranges[2 * t])], 1u)] = t;
 }
 
 // XCD-aware bijective remap (contiguous bands; kept for comparison): blocks b, b+8, .. share an XCD (round-robin dispatch), give each XCD a contiguous band of tiles

@@ -374,7 +374,7 @@ __device__ __forceinline__ void wave_sort_tile(const uint64_t* __restrict__ src,
 __global__ void __launch_bounds__(256)
 tile_sort_kernel(uint32_t T, const uint32_t* __restrict__ tile_count, const uint64_t* __restrict__ pairs,
                  uint32_t* __restrict__ point_list, uint32_t* __restrict__ ranges, uint32_t slab, uint32_t* __restrict__ stats,
-                 const uint32_t* __restrict__ counters, uint32_t* __restrict__ bucket_fill, uint32_t* __restrict__ bucket_list)
+                 const uint32_t* __restrict__ counters)
 {
     __shared__ __attribute__((aligned(16))) uint64_t skeys[TILE_SORT_SMALL];        // 16 KB, phase 2 only
     const uint32_t tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -396,10 +396,6 @@ tile_sort_kernel(uint32_t T, const uint32_t* __restrict__ tile_count, const uint
         if (t < T) {
             const uint32_t n_true = wid == 0 ? cnt0 : wid == 1 ? cnt1 : wid == 2 ? cnt2 : cnt3;
             const size_t base = (size_t)t * slab;
-            if (lane == 0 && bucket_fill) {            // file the tile under its load class (common.h: tile_by_load)
-                const uint32_t c = load_class(n_true);
-                bucket_list[(size_t)c * T + atomicAdd(&bucket_fill[c], 1u)] = t;
-            }
             if (n_true > slab) {
                 if (lane == 0) { atomicMax(&stats[1], n_true); ranges[2 * t] = (uint32_t)base; ranges[2 * t + 1] = (uint32_t)base; }
             } else {
@@ -451,11 +447,9 @@ tile_sort_big_kernel(const uint32_t* __restrict__ tile_count, const uint64_t* __
 }
 
 hipError_t launch_tile_sort(hipStream_t s, uint32_t T, const uint32_t* tile_count, const uint64_t* pairs, uint32_t* point_list,
-                            uint32_t* ranges, uint32_t slab, uint32_t* stats, const uint32_t* counters, uint32_t* bucket_fill,
-                            uint32_t* bucket_list)
+                            uint32_t* ranges, uint32_t slab, uint32_t* stats, const uint32_t* counters)
 {
-    hipLaunchKernelGGL(tile_sort_kernel, dim3((T + 3) / 4), dim3(256), 0, s, T, tile_count, pairs, point_list, ranges, slab, stats, counters,
-                       bucket_fill, bucket_list);
+    hipLaunchKernelGGL(tile_sort_kernel, dim3((T + 3) / 4), dim3(256), 0, s, T, tile_count, pairs, point_list, ranges, slab, stats, counters);
     if (slab > TILE_SORT_SMALL) {
         static bool attr_set = false;
         if (!attr_set) {
