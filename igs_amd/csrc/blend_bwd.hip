@@ -101,7 +101,7 @@ blend_bwd_kernel(const BlendBwdArgs a)
     __shared__ __attribute__((aligned(16))) float red[4][NROWS * RED_STRIDE];
 
     uint32_t tile;
-    if (a.tile_order) {                                  // heaviest tiles first (common.h: build_tile_order)
+    if (a.tile_order && a.tile_order[a.gx * a.gy] == 1u) {      // heavy tiles: heaviest first (common.h: build_tile_order)
         if (blockIdx.x >= (uint32_t)(a.gx * a.gy)) return;
         tile = a.tile_order[blockIdx.x];
         if (tile >= (uint32_t)(a.gx * a.gy)) return;      // (a corrupt image buffer must not turn into an out-of-bounds access)

@@ -98,7 +98,7 @@ struct ImgLayout {
         stats = o;         o += 256;                       // ... [0] R, [1] largest tile that overflowed its slab (0 = none)
         counters = o;      o += (COUNTER_SHARDS + 1) * COUNTER_SHARD_STRIDE * 4;   // ... instance-count shards; these three are zeroed by one fill
         zero_end = o;
-        tile_order = o;    o += align_up(T * 4, 256);      // tile ids, heaviest load class first (written by blend_fwd's workgroup 0)
+        tile_order = o;    o += align_up((T + 1) * 4, 256);  // tile ids, heaviest load class first, then [T] = "use it" (blend_fwd's workgroup 0)
         total = o + 256;
     }
 };
@@ -307,7 +307,11 @@ static inline uint32_t tile_grid_blocks(uint32_t gx, uint32_t gy) { return 8u * 
 // workgroup, not from a tail).  The forward itself keeps the plain order: heaviest-first separates its compute-heavy tiles from the
 // store-heavy near-empty ones (every tile writes 15 floats per pixel) and the stores no longer hide under the blending: 62 -> 83 us.
 // (First version: the tile sort filed the tiles with one returning global atomic each -- 5440 atomics on a handful of words
-// serialise at ~12 ns each: tile_sort 17 -> 58 us.)
+// serialise at ~12 ns each: tile_sort 17 -> 58 us.)  The order gives up the XCD-aware placement (neighbouring tiles on one L2): on
+// the bench scene the backward then fetched 190 MB from HBM instead of 117 (rocprofv3 FETCH_SIZE) for no gain, so it is used only
+// where it pays -- when the tiles are heavy enough for their blend time to outweigh the fixed per-workgroup work: mean load >=
+// LOAD_ORDER_MIN_MEAN instances per tile; order[T] tells the backward.
+#define LOAD_ORDER_MIN_MEAN 192u
 __device__ __forceinline__ uint32_t load_class(uint32_t n) {            // 0 = empty ... 63 = heaviest; ~13 % of load per class
     if (n == 0u) return 0u;
     const uint32_t c = 1u + (uint32_t)(5.5f * __log2f((float)n));
@@ -318,8 +322,15 @@ __device__ __forceinline__ void build_tile_order(const uint32_t* __restrict__ ra
     const uint32_t tid = threadIdx.x;
     if (tid < 2 * LOAD_CLASSES) hist[tid] = 0u;
     __syncthreads();
-    for (uint32_t t = tid; t < T; t += 256) atomicAdd(&hist[load_class(ranges[2 * t + 1] - ranges[2 * t])], 1u);
+    uint32_t mine = 0u;
+    for (uint32_t t = tid; t < T; t += 256) { const uint32_t n = ranges[2 * t + 1] - ranges[2 * t]; mine += n; atomicAdd(&hist[load_class(n)], 1u); }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) mine += (uint32_t)__shfl_down((int)mine, off, 64);
+    if ((tid & 63u) == 0u) atomicAdd(&hist[LOAD_CLASSES], mine);             // (slot of class 0's start: rewritten below)
     __syncthreads();
+    const uint32_t total_load = hist[LOAD_CLASSES];
+    __syncthreads();
+    if (tid == 0) order[T] = (total_load >= LOAD_ORDER_MIN_MEAN * T) ? 1u : 0u;
     if (tid < 64) {                                                      // start of every class in descending order (one wave)
         const uint32_t c = hist[LOAD_CLASSES - 1 - tid];
         uint32_t incl = c;
