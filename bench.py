@@ -564,6 +564,22 @@ def main():
             except Exception as e:  # noqa: BLE001
                 roof["pairs_per_view"] = None
                 roof["pairs_note"] = "failed: %s" % e
+            # VALU-issue side (SURVEY 8d hard part 3): wave-instruction counts per launch are a property of binary + workload and come
+            # from the committed rocprofv3 PMC pass of this same workload; the launch time is this run's
+            try:
+                if cfg == "cfg3" and args.scene == "bench" and P == 200000 and (args.width, args.height) == (1352, 1014) and loss == "l1" and not dn:
+                    pm = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc.json")))
+                    vi = {}
+                    for k in ("blend_fwd", "blend_bwd"):
+                        if k in pm and per.get(k, 0) > 0:
+                            insts = pm[k]["SQ_INSTS_VALU"]
+                            vi[k] = {"valu_wave_insts_per_launch": insts,
+                                     "issue_frac": insts * 2.6 / 1024.0 / (per[k] * 1e-3 * 2.4e9)}
+                    roof["valu_issue"] = dict(vi, note="SQ_INSTS_VALU per launch from profiles/r02_pmc.json (not counted in this process) x 2.6 cycles per "
+                                              "wave64 instruction and SIMD (tools/ubench/valu_rate, profiles/r02_ubench_valu_rate.txt) / 1024 SIMDs / "
+                                              "(this run's launch time x 2.4 GHz peak clock)")
+            except Exception:  # noqa: BLE001
+                pass
             out["roofline"] = roof
         if world == 1 and not args.no_cpu_baseline:
             log("GPU part done; timing the CPU baselines (%d usable cores)" % usable_cores())
