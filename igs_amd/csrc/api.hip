@@ -758,3 +758,30 @@ extern "C" int igs_adam_sh_from_view_colors(void* stream, int P, int D, int M, i
                                  lr / bias_correction1, beta1, beta2, eps, 1.0f / bias_correction2_sqrt), "sh_adam_views launch");
     return 0;
 }
+
+// The whole optimiser step of an N > 1 rank in ONE launch (after the exchange): dL/dSH rebuilt from the gathered per-view colour
+// gradients and applied as in igs_adam_sh_from_view_colors, and the four small groups updated from their all-reduced gradients in
+// `grad` -- same arithmetic as igs_adam_step_groups.  param / exp_avg / exp_avg_sq / grad are the flat buffers of igs_refine_step,
+// off_* float offsets into them.  The directions use the positions as they are BEFORE this update (every thread reads its own
+// Gaussian's position first).
+extern "C" int igs_adam_exchange_step(void* stream, int P, int D, int M, int n_views, const float* campos, const float* color_grads,
+                                      float clamp_grads, float* param, float* exp_avg, float* exp_avg_sq, const float* grad,
+                                      size_t off_xyz, size_t off_rot, size_t off_sh, size_t off_opacity, size_t off_scale,
+                                      float lr_xyz, float lr_rot, float lr_sh, float lr_opacity, float lr_scale,
+                                      float beta1, float beta2, float eps, float bias_correction1, float bias_correction2_sqrt)
+{
+    if (P < 0 || M < 0 || M > 16 || D < 0 || D > 3 || n_views < 0 || n_views > IGS_MAX_EXCHANGE_VIEWS)
+        return fail(IGS_RAST_E_INVALID, "igs_adam_exchange_step: bad sizes (at most 64 views)");
+    if (P == 0) return 0;
+    if (!param || !exp_avg || !exp_avg_sq || !grad || (n_views > 0 && (!campos || !color_grads)))
+        return fail(IGS_RAST_E_INVALID, "igs_adam_exchange_step: NULL pointer");
+    SmallGroupsAdam sm;
+    sm.param = param; sm.exp_avg = exp_avg; sm.exp_avg_sq = exp_avg_sq; sm.grad = grad;
+    sm.off[0] = off_xyz; sm.off[1] = off_rot; sm.off[2] = off_opacity; sm.off[3] = off_scale;
+    sm.lr_over_bc1[0] = lr_xyz / bias_correction1; sm.lr_over_bc1[1] = lr_rot / bias_correction1;
+    sm.lr_over_bc1[2] = lr_opacity / bias_correction1; sm.lr_over_bc1[3] = lr_scale / bias_correction1;
+    HIP_TRY(launch_sh_adam_views((hipStream_t)stream, P, D, M, n_views, param + off_xyz, campos, color_grads, clamp_grads, param + off_sh,
+                                 exp_avg + off_sh, exp_avg_sq + off_sh, lr_sh / bias_correction1, beta1, beta2, eps, 1.0f / bias_correction2_sqrt,
+                                 &sm), "adam_exchange_step launch");
+    return 0;
+}

@@ -199,9 +199,11 @@ hipError_t launch_geom_bwd_adam(hipStream_t s, const GeomBwdArgs& a, const Refin
 #define IGS_MAX_EXCHANGE_VIEWS 64
 hipError_t launch_sh_grad_views(hipStream_t s, int P, int D, int M, int V, const float* means3D, const float* campos_host, const float* gc,
                                 float clamp, float* dsh_out);
+// flat optimiser state + flat gradient and the float offsets of {xyz, rotation, opacity, scale} in them (lr already divided by bias_correction1)
+struct SmallGroupsAdam { float *param, *exp_avg, *exp_avg_sq; const float* grad; size_t off[4]; float lr_over_bc1[4]; };
 hipError_t launch_sh_adam_views(hipStream_t s, int P, int D, int M, int V, const float* means3D, const float* campos_host, const float* gc,
                                 float clamp, float* param_sh, float* exp_avg_sh, float* exp_avg_sq_sh, float lr_over_bc1, float b1, float b2,
-                                float eps, float inv_sqrt_bc2);
+                                float eps, float inv_sqrt_bc2, const SmallGroupsAdam* sm = nullptr);
 hipError_t launch_depth_normal(hipStream_t s, int W, int H, float fx, float fy, const float* depth, const float* mdepth, const float* normal,
                                float weight, float depth_ratio, float* g_depth, float* g_mdepth, float* g_normal, float* loss_shards);
 // 0.8 L1 + 0.2 (1 - SSIM)-style loss, forward + backward (loss_ops.hip); scratch: igs_ssim_l1_scratch_bytes

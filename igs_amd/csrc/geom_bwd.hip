@@ -77,7 +77,11 @@ __device__ __forceinline__ float3 sh_backward(int deg, int M, const float* __res
 // gradients, and every rank rebuilds the sum here, views in rank order -- the same bits everywhere.  The basis expressions
 // and the order of operations are those of sh_backward above (W(k, b): b * g, then clamp for the clamp variant, then the sum).
 struct ShViewCams { float pos[3 * IGS_MAX_EXCHANGE_VIEWS]; };
-struct ShAdam { float *param, *exp_avg, *exp_avg_sq; float lr_over_bc1, b1, b2, eps, inv_sqrt_bc2; };     // SH spans ([P][M][3]) of the optimiser state
+struct ShAdam { float *param, *exp_avg, *exp_avg_sq; float lr_over_bc1, b1, b2, eps, inv_sqrt_bc2;     // SH spans ([P][M][3]) of the optimiser state
+                // optional: the four small groups (xyz 3 | rotation 4 | opacity 1 | scale 3 floats per Gaussian) updated by the same
+                // launch from their (already all-reduced) gradients -- one kernel per N > 1 step instead of two
+                float *sm_param = nullptr, *sm_exp_avg = nullptr, *sm_exp_avg_sq = nullptr; const float* sm_grad = nullptr;
+                size_t sm_off[4] = {0, 0, 0, 0}; float sm_lr_over_bc1[4] = {0, 0, 0, 0}; };
 template <bool ADAM>
 __global__ void __launch_bounds__(128)
 sh_grad_views_kernel(int P, int D, int M, int V, const float* __restrict__ means3D, const ShViewCams cams,
@@ -171,6 +175,20 @@ sh_grad_views_kernel(int P, int D, int M, int V, const float* __restrict__ means
             adam_update(pp, mm, vv, rows[g * 49 + k], ad.lr_over_bc1, ad.b1, ad.b2, ad.eps, ad.inv_sqrt_bc2);
             ad.param[base + e] = pp; ad.exp_avg[base + e] = mm; ad.exp_avg_sq[base + e] = vv;
         }
+        if (ad.sm_param && live) {
+            // this Gaussian's 11 small parameters (its position was read above, before it moves)
+            constexpr int KS[4] = { 3, 4, 1, 3 };
+#pragma unroll
+            for (int gk = 0; gk < 4; gk++) {
+                const size_t o = ad.sm_off[gk] + (size_t)idx * KS[gk];
+#pragma unroll
+                for (int c = 0; c < KS[gk]; c++) {
+                    float pp = ad.sm_param[o + c], mm = ad.sm_exp_avg[o + c], vv = ad.sm_exp_avg_sq[o + c];
+                    adam_update(pp, mm, vv, ad.sm_grad[o + c], ad.sm_lr_over_bc1[gk], ad.b1, ad.b2, ad.eps, ad.inv_sqrt_bc2);
+                    ad.sm_param[o + c] = pp; ad.sm_exp_avg[o + c] = mm; ad.sm_exp_avg_sq[o + c] = vv;
+                }
+            }
+        }
         return;
     }
     float* dst = dsh_out + (size_t)idx * M * 3;
@@ -195,12 +213,16 @@ hipError_t launch_sh_grad_views(hipStream_t s, int P, int D, int M, int V, const
 
 hipError_t launch_sh_adam_views(hipStream_t s, int P, int D, int M, int V, const float* means3D, const float* campos_host, const float* gc,
                                 float clamp, float* param_sh, float* exp_avg_sh, float* exp_avg_sq_sh, float lr_over_bc1, float b1, float b2,
-                                float eps, float inv_sqrt_bc2)
+                                float eps, float inv_sqrt_bc2, const SmallGroupsAdam* sm)
 {
     ShViewCams cams;
     for (int i = 0; i < 3 * V; i++) cams.pos[i] = campos_host[i];
     ShAdam ad; ad.param = param_sh; ad.exp_avg = exp_avg_sh; ad.exp_avg_sq = exp_avg_sq_sh;
     ad.lr_over_bc1 = lr_over_bc1; ad.b1 = b1; ad.b2 = b2; ad.eps = eps; ad.inv_sqrt_bc2 = inv_sqrt_bc2;
+    if (sm) {
+        ad.sm_param = sm->param; ad.sm_exp_avg = sm->exp_avg; ad.sm_exp_avg_sq = sm->exp_avg_sq; ad.sm_grad = sm->grad;
+        for (int k = 0; k < 4; k++) { ad.sm_off[k] = sm->off[k]; ad.sm_lr_over_bc1[k] = sm->lr_over_bc1[k]; }
+    }
     hipLaunchKernelGGL(sh_grad_views_kernel<true>, dim3((P + 127) / 128), dim3(128), 0, s, P, D, M, V, means3D, cams, gc, clamp, (float*)nullptr, ad);
     return hipGetLastError();
 }

@@ -487,17 +487,20 @@ class Refiner:
             # floats through the all-reduce and the grouped Adam launch
             b1, b2 = p.betas
             t = p.step_count + 1
-            rc = L.igs_adam_sh_from_view_colors(stream, P, 3, 16, N, p.flat.data_ptr() + 4 * p.spans["xyz"][0], C.cast(campos, C.c_void_p),
-                                                self._gc.data_ptr(), clamp, p.flat.data_ptr() + 4 * sh0, p.exp_avg.data_ptr() + 4 * sh0,
-                                                p.exp_avg_sq.data_ptr() + 4 * sh0, p.lrs["shs"], b1, b2, p.eps, 1.0 - b1 ** t,
-                                                math.sqrt(1.0 - b2 ** t))
-            _rast._check(rc, "igs_adam_sh_from_view_colors")
             with self._Timed(self):
                 if sh0 > 0:
                     dist.all_reduce(p.grad[:sh0], op=dist.ReduceOp.SUM)
                 if sh0 + shn < p.grad.numel():
                     dist.all_reduce(p.grad[sh0 + shn:], op=dist.ReduceOp.SUM)
-            p.adam_step(skip_sh=True)
+            # ONE launch for the whole optimiser step: SH coefficients from the gathered colours, the 11 small floats from their
+            # all-reduced gradients (igs_adam_exchange_step)
+            sp = p.spans
+            rc = L.igs_adam_exchange_step(stream, P, 3, 16, N, C.cast(campos, C.c_void_p), self._gc.data_ptr(), clamp, p.flat.data_ptr(),
+                                          p.exp_avg.data_ptr(), p.exp_avg_sq.data_ptr(), p.grad.data_ptr(), sp["xyz"][0], sp["rotation"][0],
+                                          sp["shs"][0], sp["opacity"][0], sp["scaling"][0], p.lrs["xyz"], p.lrs["rotation"], p.lrs["shs"],
+                                          p.lrs["opacity"], p.lrs["scaling"], b1, b2, p.eps, 1.0 - b1 ** t, math.sqrt(1.0 - b2 ** t))
+            _rast._check(rc, "igs_adam_exchange_step")
+            p.step_count += 1
             return pkg
         rc = L.igs_sh_grad_from_view_colors(stream, P, 3, 16, N, p.flat.data_ptr() + 4 * p.spans["xyz"][0],
                                             C.cast(campos, C.c_void_p), self._gc.data_ptr(), clamp,

@@ -277,6 +277,14 @@ int igs_sh_grad_from_view_colors(void* stream, int P, int D, int M, int n_views,
 int igs_adam_sh_from_view_colors(void* stream, int P, int D, int M, int n_views, const float* means3D, const float* campos,
                                  const float* color_grads, float clamp_grads, float* param_sh, float* exp_avg_sh, float* exp_avg_sq_sh,
                                  float lr, float beta1, float beta2, float eps, float bias_correction1, float bias_correction2_sqrt);
+/* The whole optimiser step of an N > 1 rank in one launch, after the exchange: the SH update as igs_adam_sh_from_view_colors plus the
+ * four small groups (xyz, rotation, opacity, scale) from their all-reduced gradients in the flat `grad` buffer (same arithmetic as
+ * igs_adam_step_groups).  Flat buffers and float offsets as in igs_refine_step_args; M = 0 skips the SH part. */
+int igs_adam_exchange_step(void* stream, int P, int D, int M, int n_views, const float* campos, const float* color_grads,
+                           float clamp_grads, float* param, float* exp_avg, float* exp_avg_sq, const float* grad,
+                           size_t off_xyz, size_t off_rot, size_t off_sh, size_t off_opacity, size_t off_scale,
+                           float lr_xyz, float lr_rot, float lr_sh, float lr_opacity, float lr_scale,
+                           float beta1, float beta2, float eps, float bias_correction1, float bias_correction2_sqrt);
 size_t igs_refine_loss_scratch_bytes(int width, int height);
 
 /* Photometric loss of the refine loop, forward + backward in two launches (igs/utils/loss_utils.py:17-63; infer_batch.py:300-306):

@@ -1329,3 +1329,52 @@ def test_autograd_path_direct_adam_equals_flat_buffer_path(dev):
         d = (pa.flat - pb.flat).abs().cpu().numpy()
         # (|dp| <= lr per step; float-atomic order differs between two backward launches)
         assert np.quantile(d, 0.98) < 5e-6 and d.max() <= 0.16, (loss, np.quantile(d, 0.98), d.max())
+
+
+def test_exchange_step_in_one_launch_equals_sh_update_plus_grouped_adam(dev):
+    """igs_adam_exchange_step (the N > 1 rank's whole optimiser step in one launch: SH coefficients from the gathered colour
+    gradients + the four small groups from their all-reduced gradients) against igs_adam_sh_from_view_colors followed by
+    igs_adam_step_groups on the same state: identical bits."""
+    import ctypes as C
+    import math
+    from igs_amd import _cabi
+    from igs_amd.refine import GaussianParams
+    L = _cabi.lib()
+    raw, cams, _ = sear_steak_like_scene(P=5000, n_cams=3, width=64, height=48, focal=40.0)
+    g = torch.Generator().manual_seed(17)
+    P, V = 5000, 3
+    pa, pb = GaussianParams(raw, dev), GaussianParams(raw, dev)
+    for p in (pa, pb):
+        gen = torch.Generator().manual_seed(5)
+        p.grad.copy_((torch.randn(p.grad.numel(), generator=gen) * 1e-3).to(dev))
+        p.exp_avg.copy_((torch.randn(p.grad.numel(), generator=gen) * 1e-4).to(dev))
+        p.exp_avg_sq.copy_((torch.rand(p.grad.numel(), generator=gen) * 1e-7).to(dev))
+    gc = (torch.randn(V, P, 3, generator=g) * 1e-3)
+    gc[1, ::3] = 0.0                                            # Gaussians a view does not see: exact zeros
+    gc = gc.to(dev).contiguous()
+    campos = (C.c_float * (3 * V))(*[float(x) for c in cams for x in c.camera_center.reshape(3).tolist()])
+    b1, b2, eps, t = 0.9, 0.999, 1e-15, 4
+    bc1, bc2s = 1.0 - b1 ** t, math.sqrt(1.0 - b2 ** t)
+    st = torch.cuda.current_stream(dev).cuda_stream
+    sp = pa.spans
+    sh0 = sp["shs"][0]
+    # (a) two launches
+    rc = L.igs_adam_sh_from_view_colors(st, P, 3, 16, V, pa.flat.data_ptr() + 4 * sp["xyz"][0], C.cast(campos, C.c_void_p), gc.data_ptr(), 15.0,
+                                        pa.flat.data_ptr() + 4 * sh0, pa.exp_avg.data_ptr() + 4 * sh0, pa.exp_avg_sq.data_ptr() + 4 * sh0,
+                                        pa.lrs["shs"], b1, b2, eps, bc1, bc2s)
+    assert rc == 0
+    pa.step_count = t - 1
+    pa.adam_step(skip_sh=True)
+    # (b) one launch
+    rc = L.igs_adam_exchange_step(st, P, 3, 16, V, C.cast(campos, C.c_void_p), gc.data_ptr(), 15.0, pb.flat.data_ptr(), pb.exp_avg.data_ptr(),
+                                  pb.exp_avg_sq.data_ptr(), pb.grad.data_ptr(), sp["xyz"][0], sp["rotation"][0], sp["shs"][0], sp["opacity"][0],
+                                  sp["scaling"][0], pb.lrs["xyz"], pb.lrs["rotation"], pb.lrs["shs"], pb.lrs["opacity"], pb.lrs["scaling"],
+                                  b1, b2, eps, bc1, bc2s)
+    assert rc == 0
+    torch.cuda.synchronize()
+    shn = sp["shs"][1]
+    for A, B in ((pa.flat, pb.flat), (pa.exp_avg, pb.exp_avg), (pa.exp_avg_sq, pb.exp_avg_sq)):
+        assert torch.equal(A[sh0:sh0 + shn], B[sh0:sh0 + shn])                         # SH: the same kernel code
+        # small groups: the same formula in two kernels (the compiler may contract a multiply-add differently): last-bit agreement
+        torch.testing.assert_close(A[:sh0], B[:sh0], rtol=2e-6, atol=1e-12)
+    assert not torch.equal(pa.flat[:sh0], GaussianParams(raw, dev).flat[:sh0])        # the small groups moved
