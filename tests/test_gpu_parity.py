@@ -1378,3 +1378,34 @@ def test_exchange_step_in_one_launch_equals_sh_update_plus_grouped_adam(dev):
         # small groups: the same formula in two kernels (the compiler may contract a multiply-add differently): last-bit agreement
         torch.testing.assert_close(A[:sh0], B[:sh0], rtol=2e-6, atol=1e-12)
     assert not torch.equal(pa.flat[:sh0], GaussianParams(raw, dev).flat[:sh0])        # the small groups moved
+
+
+@pytest.mark.parametrize("size", [64, 80])
+def test_dense_tiles_backward_with_load_ordered_dispatch(dev, size):
+    """Mean load >= 192 instances per tile switches the backward blend to the heaviest-first tile order that the forward blend's
+    workgroup 0 builds (common.h: build_tile_order) -- 6000 splats on 16 / 25 tiles here, several staging rounds per tile; images,
+    lists and gradients against the oracle (the sparse scenes of the other tests keep the plain XCD-aware order)."""
+    from igs_amd import rasterizer as R
+    raw, cams, _ = cfg1_scene(P=6000, size=size)
+    bg = torch.tensor([0.3, 0.1, 0.5])
+    cam, a = cams[0], activate(raw)
+    out, ad, mats = hip_forward(a, cam, bg, dev, debug=False)
+    nr_o, oo, st = oracle_forward(a, cam, bg)
+    T = ((size + 15) // 16) ** 2
+    assert out[0] == nr_o and nr_o >= 192 * T, (nr_o, T)
+    d = R.debug_dump(6000, out[0], cam.width, cam.height, out[9], out[10], out[11])
+    np.testing.assert_array_equal(d["point_list"].cpu().numpy().astype(np.uint32), st.intermediates()["point_list"])
+    check_images(out, oo)
+    for seed, keys in ((1, KEYS), (2, ["color"])):               # all seven upstream gradients, then the colour-only instance
+        grads = rand_grads(oo, seed)
+        g = {k: (grads[k] if k in keys else np.zeros_like(grads[k])) for k in KEYS}
+        if keys == ["color"]:
+            gt = [torch.from_numpy(g["color"]).to(dev)] + [None] * 6
+            nr, color, coord, mcoord, alpha, normal, depth, mdepth, radii, gb, bb, ib = out
+            poison_lds(dev)
+            gout = R.rasterize_gaussians_backward(bg.to(dev), ad["means3D"], radii, E, ad["scales"], ad["rotations"], 1.0, E, mats[0], mats[1],
+                                                  cam.tanfovx, cam.tanfovy, 0.0, *gt, normal, ad["shs"], 3, mats[2], gb, nr, bb, ib, alpha,
+                                                  True, True, False)
+        else:
+            gout = hip_backward(out, ad, mats, cam, bg, dev, g)
+        check_grads(gout, oracle_backward(st, oo, a, cam, bg, g), bulk=0.90, p99=3e-2, worst=1.0)
