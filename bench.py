@@ -354,6 +354,31 @@ def main():
                     r_sum, calls = r_sum2, calls2
             else:
                 stages = stages_timed
+            # BASELINE configs[1] on the side (the reference's own throughput figure is a forward-only fps, infer_batch.py:125-145):
+            # 60 forward renders of the refined scene through the drop-in entry point, one host wait per frame, device-synchronised
+            try:
+                a_f = {k: v.detach() for k, v in params.activated().items()}
+                bufs_f = rasterizer.RasterBuffers()
+                E_f = torch.Tensor([])
+
+                def fwd_only(i):
+                    cam = cams[(i * world + rank) % len(cams)]
+                    rasterizer.rasterize_gaussians(bg, a_f["means3D"], E_f, a_f["opacities"], a_f["scales"], a_f["rotations"], 1.0, E_f,
+                                                   cam.world_view_transform, cam.full_proj_transform, cam.tanfovx, cam.tanfovy, 0.0, cam.height,
+                                                   cam.width, a_f["shs"], 3, cam.camera_center, False, True, True, False, buffers=bufs_f)
+                for i in range(10):
+                    fwd_only(i)
+                torch.cuda.synchronize()
+                tf0 = time.perf_counter()
+                for i in range(60):
+                    fwd_only(i)
+                torch.cuda.synchronize()
+                ms_f = 1000.0 * (time.perf_counter() - tf0) / 60
+                out_extra["forward_only"] = {"ms_per_frame": ms_f, "gaussians_per_s": params.P / (ms_f * 1e-3), "frames_per_s": 1000.0 / ms_f,
+                                             "note": "BASELINE configs[1] on this rank after the timed region: forward-only render (coord, depth, normal on) "
+                                                     "through igs_rast_forward, 60 frames; `--config cfg2` is the full-length version"}
+            except Exception as e:  # noqa: BLE001
+                out_extra["forward_only"] = {"error": str(e)}
         else:
             # cfg2: forward-only render through the drop-in entry point (one host wait per frame, like rasterizer_impl.cu:354)
             a = {k: v.detach() for k, v in params.activated().items()}

@@ -19,7 +19,9 @@
 // T is recovered exactly like the reference does (T_final = 1 - out_alpha, T <- T / (1 - alpha), backward.cu:706,857).
 #include "blend_common.h"
 
-#define BCHUNK 128            // splats staged per round in the backward (LDS is shared with the reduction scratch)
+// splats staged per round in the backward (LDS is shared with the reduction scratch): 128 for the colour-only instance, 64 for the
+// instances with geometry, whose 15..25-row transpose buffers already take 16..27 KB of the workgroup's LDS
+#define BCHUNK_MAX 128
 
 // Column writes of the transpose buffer: lane l stores its value of moment r at  base + r * stride + 4 l.  That is exactly the
 // address pattern of ds_write_addtid_b32 (address = M0 + offset + 4 * lane, no address VGPR), which moves 4 B per lane to the LDS
@@ -80,9 +82,11 @@ blend_bwd_kernel(const BlendBwdArgs a)
 {
     constexpr bool GEO = COORD || DEPTH || NORMAL;
     constexpr int NQ = GEO ? 6 : 3;
+    constexpr int BCHUNK = GEO ? 64 : 128;
+    constexpr int NSW = BCHUNK / 64;                    // staging waves
     __shared__ float4 chunk[BCHUNK * NQ];
     __shared__ uint32_t chunk_id[BCHUNK];
-    __shared__ uint64_t quad_bits[4][2];                // [quad][staging wave pair]: BCHUNK = 2 x 64 splats
+    __shared__ uint64_t quad_bits[4][NSW];              // [quad][staging wave]
     __shared__ int wave_max[4];
     constexpr int NROWS = 9 + (ABS ? 1 : 0) + (COORD ? 9 : 0) + (DEPTH ? 3 : 0) + (NORMAL ? 3 : 0);   // live moments of this instance
     // floats per row of the per-wave transpose buffer: 16-byte aligned rows for the b128 row reads.  Columns are written with
@@ -228,7 +232,7 @@ blend_bwd_kernel(const BlendBwdArgs a)
                 qmask = quad_reach_mask(q0, q1, tile_x0, tile_y0);
             }
         }
-        if (wid < 2) {
+        if (wid < NSW) {
 #pragma unroll
             for (int q = 0; q < 4; q++) {
                 const uint64_t b = __ballot((qmask >> q) & 1u);
@@ -236,7 +240,7 @@ blend_bwd_kernel(const BlendBwdArgs a)
             }
         }
         __syncthreads();
-        for (int sw = 0; sw < 2; sw++) {
+        for (int sw = 0; sw < NSW; sw++) {
             uint64_t bits = quad_bits[wid][sw];
             bits = uniform64(bits);
             while (bits != 0ull) {
