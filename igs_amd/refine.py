@@ -108,8 +108,14 @@ class GaussianParams:
             out[k] = v.detach()[inv] if inv is not None else v.detach()
         return out
 
-    def activated(self):
+    def activated(self, fused=False):
+        """Activated parameters as the reference's model properties give them (gaussian_model.py:90-127); `fused`: the same from one
+        autograd Function (igs_amd/activations.py) instead of separate PyTorch ops."""
         L = self.leaves
+        if fused:
+            from .activations import activate
+            o, s, r = activate(L["opacity"], L["scaling"], L["rotation"])
+            return dict(means3D=L["xyz"], shs=L["shs"], opacities=o, scales=s, rotations=r)
         return dict(means3D=L["xyz"], shs=L["shs"], opacities=torch.sigmoid(L["opacity"]), scales=torch.exp(L["scaling"]),
                     rotations=F.normalize(L["rotation"]))
 
@@ -569,7 +575,7 @@ class Refiner:
                   and getattr(self, "direct_adam", False))      # opt-in: tests and callers that read `.grad` keep the flat buffer
         if not direct:
             p.zero_grad()
-        act = p.activated()
+        act = p.activated(fused=getattr(self, "fused_activations", False) and self.render_fn is render and p.flat.is_cuda)
         pkg = self.render_fn(act, cam, self.bg, clamp=True) if (getattr(self, "clamp", False) and self.render_fn is render) else self.render_fn(act, cam, self.bg)
         img = pkg["images_pred"]
         if direct:

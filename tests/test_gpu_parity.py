@@ -1409,3 +1409,22 @@ def test_dense_tiles_backward_with_load_ordered_dispatch(dev, size):
         else:
             gout = hip_backward(out, ad, mats, cam, bg, dev, g)
         check_grads(gout, oracle_backward(st, oo, a, cam, bg, g), bulk=0.90, p99=3e-2, worst=1.0)
+
+
+def test_fused_activations_match_torch(dev):
+    """igs_amd.activations.activate (one launch forward, one backward) against sigmoid / exp / F.normalize and their autograd."""
+    from igs_amd.activations import activate
+    g = torch.Generator().manual_seed(8)
+    P = 3001
+    lo, ls, rt = (torch.randn(P, 1, generator=g) * 2).to(dev), (torch.randn(P, 3, generator=g) - 3).to(dev), torch.randn(P, 4, generator=g).to(dev)
+    w = [torch.randn(P, k, generator=g).to(dev) for k in (1, 3, 4)]
+    a = [t.clone().requires_grad_(True) for t in (lo, ls, rt)]
+    b = [t.clone().requires_grad_(True) for t in (lo, ls, rt)]
+    oa = activate(*a)
+    ob = (torch.sigmoid(b[0]), torch.exp(b[1]), torch.nn.functional.normalize(b[2]))
+    for x, y in zip(oa, ob):
+        torch.testing.assert_close(x, y, rtol=2e-6, atol=1e-7)
+    sum((x * ww).sum() for x, ww in zip(oa, w)).backward()
+    sum((y * ww).sum() for y, ww in zip(ob, w)).backward()
+    for x, y in zip(a, b):
+        torch.testing.assert_close(x.grad, y.grad, rtol=2e-5, atol=1e-6)

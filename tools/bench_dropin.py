@@ -28,12 +28,14 @@ def main():
     out = {}
     for name, kw, nan in (("python_api_autograd_nan_checks_on", dict(native=False), True),
                           ("python_api_autograd", dict(native=False), False),
+                          ("python_api_autograd_fused_activations", dict(native=False), False),
                           ("c_abi_unfused", dict(native=True, fused=False), False),
                           ("igs_refine_step", dict(native=True, fused=True), False)):
         rasterizer.NAN_CHECKS = nan
         for loss in ("l1", "l1_ssim"):
             p = GaussianParams(raw, dev); p.spatial_sort()
             r = Refiner(p, cams, gts, bg, loss=loss, **kw)
+            r.fused_activations = name.endswith("fused_activations")
             r.direct_adam = True         # autograd path: gradients straight from autograd into the fused Adam (set_to_none semantics, infer_batch.py:324)
             out["%s/%s" % (name, loss)] = round(run(r), 4)
     print(json.dumps(out))
