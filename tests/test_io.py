@@ -38,6 +38,41 @@ def test_ply_round_trip_and_channel_major_sh_layout(tmp_path):
         torch.testing.assert_close(back[k].reshape(raw[k].shape), raw[k].float(), rtol=0, atol=0)
 
 
+def test_reads_a_ply_assembled_byte_for_byte_like_the_reference_writer(tmp_path):
+    """The reference's `save_ply` (igs/models/gs.py:317-342) fills a numpy record array of '<f4' fields in
+    `construct_list_of_attributes()` order and hands it to plyfile, which writes the header
+    `ply / format binary_little_endian 1.0 / element vertex N / property float <name> ... / end_header` followed by the packed
+    records.  The file is assembled here with struct / numpy only -- not with this repository's writer -- and must come back through
+    `load_start_gaussians` with the channel-major f_rest layout undone (`load_ply`, gs.py:400-462).  (No reference-written PLY
+    exists in the reference tree to test against; this pins the reader against the FORMAT, independently of our own writer.)"""
+    import struct
+    N = 5
+    rng = np.random.default_rng(3)
+    names = ["x", "y", "z", "nx", "ny", "nz"] + ["f_dc_%d" % i for i in range(3)] + ["f_rest_%d" % i for i in range(45)] \
+        + ["opacity"] + ["scale_%d" % i for i in range(3)] + ["rot_%d" % i for i in range(4)]
+    assert len(names) == 62
+    vals = rng.standard_normal((N, 62)).astype("<f4")
+    p = str(tmp_path / "ref_like.ply")
+    with open(p, "wb") as f:
+        f.write(("ply\nformat binary_little_endian 1.0\nelement vertex %d\n" % N).encode("ascii"))
+        for n in names:
+            f.write(("property float %s\n" % n).encode("ascii"))
+        f.write(b"end_header\n")
+        for row in vals:
+            f.write(struct.pack("<62f", *[float(v) for v in row]))
+    back = gio.load_start_gaussians(p)
+    col = {n: vals[:, i] for i, n in enumerate(names)}
+    np.testing.assert_array_equal(back["xyz"].numpy(), vals[:, 0:3])
+    np.testing.assert_array_equal(back["opacity"].numpy().reshape(-1), col["opacity"])
+    np.testing.assert_array_equal(back["scaling"].numpy(), vals[:, 55:58])
+    np.testing.assert_array_equal(back["rotation"].numpy(), vals[:, 58:62])
+    shs = back["shs"].numpy().reshape(N, 16, 3)
+    for c in range(3):
+        np.testing.assert_array_equal(shs[:, 0, c], col["f_dc_%d" % c])
+        for k in range(1, 16):                               # features_extra.reshape(P, 3, 15) then transposed (gs.py:421-424)
+            np.testing.assert_array_equal(shs[:, k, c], col["f_rest_%d" % (c * 15 + k - 1)])
+
+
 def test_filter_3d_is_folded_into_scale_and_opacity(tmp_path):
     raw = _raw(64)
     f3 = torch.rand(64, 1) * 0.05 + 0.01
