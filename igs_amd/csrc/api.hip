@@ -154,6 +154,7 @@ static thread_local PendingFwd g_pending;
 // what the extended entry points ask of the forward on top of the reference's argument list
 struct FwdExtra {
     bool defer_status = false;          // igs_rast_forward_async / igs_refine_step: do not wait for {R, overflow}
+    bool no_latch = false;              // igs_rast_forward_nowait: ... and do not expect an igs_rast_forward_finish either
     bool raw_activations = false;       // igs_refine_step: opacities / scales / rotations are the raw optimiser leaves
     float* zero_gacc = nullptr;         // ... backward accumulators / loss shards the preprocess kernel zero-fills on the side
     float* zero_loss = nullptr;
@@ -253,7 +254,7 @@ static int forward_impl(
         point_list = (uint32_t*)(bbase + KL.point_list);
         uint64_t* pairs = (uint64_t*)(bbase + KL.pairs);
         counters = (uint32_t*)(ibase + IL.counters);
-        HIP_TRY(hipMemsetAsync(tile_count, 0, IL.zero_end - IL.tile_count, s), "memset tile counters");   // tile_count + stats + counters
+        HIP_TRY(zero_fill_async(s, tile_count, IL.zero_end - IL.tile_count), "zero tile counters");   // tile_count + stats + counters
         prof_mark(s, ST_GAP);
         HIP_TRY(launch_preprocess_fwd(s, fp, rec, tiles, nullptr, nullptr, radii, counters, nullptr, 0, tile_count, pairs, slab_size),
                 "preprocess_fwd launch");
@@ -352,7 +353,7 @@ static int forward_impl(
     DBG_SYNC("blend_fwd");
     prof_mark(s, ST_BLEND_FWD);
     if (slab_pending && ex.defer_status) {
-        g_pending.active = true; g_pending.slab = slab_size;
+        if (!ex.no_latch) { g_pending.active = true; g_pending.slab = slab_size; }
         if (g_prof.on) g_prof.calls++;
         return 0x7FFFFFFF;                       // "unknown yet": an upper bound that igs_rast_backward accepts as R
     }
@@ -448,6 +449,55 @@ extern "C" int igs_rast_forward_finish(void)
     return (int)R_dev;
 }
 
+// Forward for stream capture (hipGraph): identical launches, NO host-side wait, no pending latch -- nothing in it is illegal
+// while the stream is capturing (the pinned status slot must exist already: run one ordinary forward on this thread and device
+// first).  Every replay of the captured launches posts its {R, overflow, prefilter flag} into the slot;
+// igs_rast_last_status() reads it back once the caller has synchronised the stream.
+extern "C" int igs_rast_forward_nowait(
+    void* stream,
+    igs_rast_alloc_fn geometry_buffer, void* geometry_user, igs_rast_alloc_fn binning_buffer, void* binning_user,
+    igs_rast_alloc_fn image_buffer, void* image_user,
+    int P, int D, int M, const float* background, int width, int height,
+    const float* means3D, const float* shs, const float* colors_precomp, const float* opacities,
+    const float* scales, float scale_modifier, const float* rotations, const float* cov3D_precomp,
+    const float* viewmatrix, const float* projmatrix, const float* cam_pos,
+    float tan_fovx, float tan_fovy, float kernel_size, int prefiltered,
+    float* out_color, float* out_coord, float* out_mcoord, float* out_depth, float* out_mdepth, float* out_alpha,
+    float* out_normal, int* radii, int require_coord, int require_depth, int debug)
+{
+    if (g_pending.active) return fail(IGS_RAST_E_INVALID, "igs_rast_forward_nowait: an asynchronous forward is pending on this thread; call igs_rast_forward_finish() first");
+    if (debug) return fail(IGS_RAST_E_INVALID, "igs_rast_forward_nowait: debug (a synchronisation after every launch) cannot be captured");
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= IGS_MAX_DEVICES || !g_slots.slot[dev].pinned)
+        return fail(IGS_RAST_E_INVALID, "igs_rast_forward_nowait: no status slot on this thread and device yet (run one igs_rast_forward first: pinned memory cannot be allocated during capture)");
+    prof_new_frame();
+    FwdExtra ex; ex.defer_status = true; ex.no_latch = true;
+    return forward_impl(stream, geometry_buffer, geometry_user, binning_buffer, binning_user, image_buffer, image_user, P, D, M,
+                        background, width, height, means3D, shs, colors_precomp, opacities, scales, scale_modifier, rotations,
+                        cov3D_precomp, viewmatrix, projmatrix, cam_pos, tan_fovx, tan_fovy, kernel_size, prefiltered, out_color,
+                        out_coord, out_mcoord, out_depth, out_mdepth, out_alpha, out_normal, radii, require_coord, require_depth,
+                        0, false, 0, ex);
+}
+// What the last slab-binned forward of this thread and device posted.  *overflow != 0: a tile needed that many instance slots and
+// the per-tile slabs were smaller -- the frame (and everything computed from it) is invalid; the slab hint has been raised, so a
+// new capture / an ordinary igs_rast_forward will fit.  Only meaningful once the stream has been synchronised.
+extern "C" int igs_rast_last_status(int* num_rendered, unsigned* overflow, unsigned* prefilter_flag)
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= IGS_MAX_DEVICES || !g_slots.slot[dev].pinned)
+        return fail(IGS_RAST_E_INVALID, "igs_rast_last_status: no forward has run on this thread and device");
+    const uint32_t* p = g_slots.slot[dev].pinned;
+    const uint32_t R = __atomic_load_n(&p[0], __ATOMIC_ACQUIRE), ov = __atomic_load_n(&p[1], __ATOMIC_ACQUIRE);
+    if (num_rendered) *num_rendered = R > 0x7FFFFFFFu ? 0x7FFFFFFF : (int)R;
+    if (overflow) *overflow = ov;
+    if (prefilter_flag) *prefilter_flag = p[2];
+    if (ov) {
+        const uint64_t want = ((uint64_t)ov + ov / 4 + 255) / 256 * 256;
+        if (want > g_hint.slab) g_hint.slab = (uint32_t)(want > TILE_SORT_BIG ? TILE_SORT_BIG : want);
+    }
+    return 0;
+}
+
 extern "C" void igs_rast_set_slab_hint(unsigned slots_per_tile) { g_hint.slab = slots_per_tile > TILE_SORT_BIG ? TILE_SORT_BIG : slots_per_tile; }
 extern "C" unsigned igs_rast_get_slab_hint(void) { return g_hint.slab; }
 
@@ -498,7 +548,7 @@ static int backward_impl(
     prof_mark(s, ST_GAP);
     float* loss_shards = (float*)((char*)gacc + ws_gacc_bytes(P));
     if (!(fuse && fuse->prezeroed))                // (igs_refine_step: the forward's preprocess kernel zero-filled the accumulators)
-        HIP_TRY(hipMemsetAsync(gacc, 0, l1_gt ? ws_gacc_bytes(P) + WS_LOSS_BYTES : (size_t)P * GACC_F * 4, s), "memset gacc");
+        HIP_TRY(zero_fill_async(s, gacc, l1_gt ? ws_gacc_bytes(P) + WS_LOSS_BYTES : (size_t)P * GACC_F * 4), "zero gacc");
     prof_mark(s, ST_MEMSET);
     BlendBwdArgs ba;
     ba.W = width; ba.H = height; ba.gx = gx; ba.gy = gy; ba.fx = fx; ba.fy = fy; ba.bg = background;
@@ -661,7 +711,7 @@ extern "C" int igs_refine_step(const igs_refine_step_args* a)
             // depth-normal regulariser on the maps just rendered: its three gradient maps switch the blend backward to the
             // <depth, normal> instance
             hipStream_t ms = (hipStream_t)a->stream;
-            HIP_TRY(hipMemsetAsync(dn_shards, 0, 4096, ms), "memset shards");
+            HIP_TRY(zero_fill_async(ms, dn_shards, 4096), "zero shards");
             const float fx = a->width / (2.0f * a->tan_fovx), fy = a->height / (2.0f * a->tan_fovy);
             HIP_TRY(launch_depth_normal(ms, a->width, a->height, fx, fy, depth, mdepth, normal, a->loss_weight * a->lambda_depth_normal,
                                         a->depth_ratio > 0.f ? a->depth_ratio : 0.6f, dn_gd, dn_gm, dn_gn, dn_shards), "depth_normal launch");

@@ -351,3 +351,9 @@ __device__ __forceinline__ uint32_t xcd_remap(uint32_t b, uint32_t n) {
     return base + k;
 }
 #endif
+
+// Zero-fill of a 4-byte-aligned span by a kernel of this library (refine_ops.hip) instead of hipMemsetAsync: the same cost on the
+// stream (the runtime's memset is a fill kernel too), and a plain kernel node when the stream is being captured into a hipGraph --
+// captured memset nodes misbehaved on this runtime (round 2: stale counters in the replay, a crash at hipStreamEndCapture).
+hipError_t zero_fill_async(hipStream_t s, void* p, size_t bytes);
+

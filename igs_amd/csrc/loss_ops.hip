@@ -242,7 +242,7 @@ hipError_t launch_ssim_l1(hipStream_t s, int W, int H, const float* pred, const 
     float* maps = (float*)scratch;
     float* shards = scratch_shards(scratch, W, H);
     if (zero_shards) {
-        const hipError_t e = hipMemsetAsync(shards, 0, 2 * 4096, s);
+        const hipError_t e = zero_fill_async(s, shards, 2 * 4096);
         if (e != hipSuccess) return e;
     }
     const dim3 grid((W + SSIM_T - 1) / SSIM_T, (H + SSIM_T - 1) / SSIM_T, 3), block(256);
@@ -396,7 +396,7 @@ extern "C" int igs_depth_normal_loss_fwd_bwd(void* stream, int width, int height
 {
     if (width <= 0 || height <= 0) return 0;
     if (!depth || !mdepth || !normal || !g_depth || !g_mdepth || !g_normal || !loss_shards) return IGS_RAST_E_INVALID;
-    if (hipMemsetAsync(loss_shards, 0, 4096, (hipStream_t)stream) != hipSuccess) return IGS_RAST_E_HIP;
+    if (zero_fill_async((hipStream_t)stream, loss_shards, 4096) != hipSuccess) return IGS_RAST_E_HIP;
     // fx = W / (2 tan(FoVx / 2)) as graphics_utils.py:99-100
     const float fx = width / (2.0f * tan_fovx), fy = height / (2.0f * tan_fovy);
     return launch_depth_normal((hipStream_t)stream, width, height, fx, fy, depth, mdepth, normal, weight, depth_ratio, g_depth, g_mdepth,

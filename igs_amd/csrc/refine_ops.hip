@@ -269,3 +269,30 @@ extern "C" int igs_densify_remap(void* stream, int P_new, int M, const int* src,
     hipLaunchKernelGGL(densify_remap_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
     return hipGetLastError() == hipSuccess ? 0 : IGS_RAST_E_HIP;
 }
+
+__global__ void __launch_bounds__(256) zero_fill_kernel(uint32_t* __restrict__ p, size_t words)
+{
+    // 16-byte stores over the aligned middle, single words at the ragged ends
+    const size_t head = min(words, (size_t)((16u - ((uintptr_t)p & 15u)) & 15u) / 4);
+    const size_t n4 = (words - head) / 4;
+    uint4* q = (uint4*)(p + head);
+    const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) q[i] = z;
+    if (blockIdx.x == 0) {
+        if (threadIdx.x < head) p[threadIdx.x] = 0u;
+        const size_t tail0 = head + 4 * n4;
+        if (tail0 + threadIdx.x < words) p[tail0 + threadIdx.x] = 0u;
+    }
+}
+hipError_t zero_fill_async(hipStream_t s, void* p, size_t bytes)
+{
+    if (bytes == 0) return hipSuccess;
+    if ((((uintptr_t)p) | bytes) & 3u) return hipMemsetAsync(p, 0, bytes, s);      // (not word-granular: never the case in this library)
+    const size_t words = bytes / 4;
+    size_t blocks = (words / 4 + 255) / 256;
+    if (blocks < 1) blocks = 1;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(zero_fill_kernel, dim3((unsigned)blocks), dim3(256), 0, s, (uint32_t*)p, words);
+    return hipGetLastError();
+}
+

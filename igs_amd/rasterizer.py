@@ -140,7 +140,9 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
     `buffers` (extension) is a RasterBuffers object whose image / radii / scratch tensors are reused across calls;
     `scratch` (extension) a (geometry, binning, image) triple of _Scratch objects to use instead of fresh byte tensors.
     `defer=True` (extension) does not wait for the instance count: num_rendered is then an upper bound (accepted by
-    rasterize_gaussians_backward) and `rasterize_finish()` must be called before the results are trusted."""
+    rasterize_gaussians_backward) and `rasterize_finish()` must be called before the results are trusted.
+    On a CAPTURING stream (torch.cuda.graph) the no-wait entry point igs_rast_forward_nowait is used by itself: the launches are
+    recorded, num_rendered is the same upper bound, and `capture_status()` reports on a replay after the fact."""
     if means3D.dim() != 2 or means3D.size(1) != 3:
         raise RasterizerError("means3D must have dimensions (num_points, 3)")
     if not means3D.is_cuda:
@@ -168,7 +170,10 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
         rendered = 0
         if P != 0:
             stream = torch.cuda.current_stream(dev).cuda_stream
-            rendered = (L.igs_rast_forward_async if defer else L.igs_rast_forward)(
+            fwd = L.igs_rast_forward_async if defer else L.igs_rast_forward
+            if torch.cuda.is_current_stream_capturing():
+                fwd = L.igs_rast_forward_nowait
+            rendered = fwd(
                 stream, geom.cb, None, binning.cb, None, img.cb, None, P, int(degree), M, _ptr(bg_c), W, H,
                 _ptr(means3D_c), _ptr(sh_c), _ptr(colors_c), _ptr(opacity_c), _ptr(scales_c), float(scale_modifier),
                 _ptr(rotations_c), _ptr(cov_c), _ptr(view_c), _ptr(proj_c), _ptr(campos_c), float(tan_fovx), float(tan_fovy),
@@ -187,6 +192,18 @@ def rasterize_finish():
         return None
     _check(rc, "igs_rast_forward_finish")
     return rc
+
+
+def capture_status():
+    """(num_rendered, overflow) of the last forward of this host thread on the current device -- for forwards that ran as part of
+    a replayed graph (`torch.cuda.graph`), after the caller has synchronised.  overflow != 0: a tile needed that many instance
+    slots and the slabs baked into the capture were smaller; the results of that replay are invalid -- capture again (the slab
+    hint has been raised)."""
+    n, ov, pf = C.c_int(0), C.c_uint(0), C.c_uint(0)
+    _check(_cabi.lib().igs_rast_last_status(C.byref(n), C.byref(ov), C.byref(pf)), "igs_rast_last_status")
+    if pf.value:
+        raise RasterizerError("Point is filtered although prefiltered is set. This shouldn't happen!")
+    return n.value, ov.value
 
 
 def _backward(background, means3D, radii, colors, scales, rotations, scale_modifier, cov3D_precomp,
@@ -375,7 +392,7 @@ def _make_function(clamp_grads):
                 grad_opacities = torch.clamp(grad_opacities, -15, 15)
                 grad_scales = torch.clamp(grad_scales, -15, 15)
                 grad_rotations = torch.clamp(grad_rotations, -15, 15)
-            if NAN_CHECKS:
+            if NAN_CHECKS and not torch.cuda.is_current_stream_capturing():      # (a host-side assert cannot be captured)
                 # the reference asserts on seven tensors with seven `.any()` host syncs (__init__.py:156-162); six of them are
                 # one dense block here (its first 17 floats per Gaussian; the cov3D gradient behind them is not checked there
                 # either), so: two reductions, one host sync

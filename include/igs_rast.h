@@ -114,6 +114,27 @@ int igs_rast_forward_async(
     float* out_normal, int* radii, int require_coord, int require_depth, int debug);
 int igs_rast_forward_finish(void);
 
+/* Forward for stream capture (hipGraph / torch.cuda.graph; no reference counterpart -- the reference's forward reads its
+ * instance count back in the middle, rasterizer_impl.cu:354, and cannot be captured): the launches of igs_rast_forward with no
+ * host-side wait and no pending latch; returns INT_MAX like igs_rast_forward_async.  Nothing it does is illegal on a capturing
+ * stream PROVIDED one ordinary igs_rast_forward has run on this host thread and device before (the pinned status slot is
+ * allocated then) and the scratch callbacks do not allocate illegally (PyTorch's graph-pool allocations are fine).
+ * Every replay posts {num_rendered, overflow, prefilter flag} into the thread's status slot; igs_rast_last_status() returns
+ * them once the caller has synchronised the stream.  overflow != 0 means the per-tile instance slabs baked into the capture
+ * were too small for that replay: its results are invalid, the slab hint has been raised, capture again. */
+int igs_rast_forward_nowait(
+    void* stream,
+    igs_rast_alloc_fn geometry_buffer, void* geometry_user, igs_rast_alloc_fn binning_buffer, void* binning_user,
+    igs_rast_alloc_fn image_buffer, void* image_user,
+    int P, int D, int M, const float* background, int width, int height,
+    const float* means3D, const float* shs, const float* colors_precomp, const float* opacities,
+    const float* scales, float scale_modifier, const float* rotations, const float* cov3D_precomp,
+    const float* viewmatrix, const float* projmatrix, const float* cam_pos,
+    float tan_fovx, float tan_fovy, float kernel_size, int prefiltered,
+    float* out_color, float* out_coord, float* out_mcoord, float* out_depth, float* out_mdepth, float* out_alpha,
+    float* out_normal, int* radii, int require_coord, int require_depth, int debug);
+int igs_rast_last_status(int* num_rendered, unsigned* overflow, unsigned* prefilter_flag);
+
 /* Binning scratch tuning (no reference counterpart).  The default path gives every 16x16 tile a slab of `slots_per_tile`
  * instance slots (12 bytes each) in binningBuffer; a frame in which some tile needs more is redone automatically with larger
  * slabs (and, beyond 16384 per tile, with the global radix sort), and the size then sticks for the calling thread.  Setting the

@@ -1468,3 +1468,71 @@ def test_full_size_stream_step_fused_equals_autograd(dev, cfg):
         if ldn:
             ref_loss = ref_loss + ldn * depth_normal_loss(pk, cams[1])
     assert abs(float(pka["loss"].item()) - float(ref_loss)) < 2e-5 * max(1.0, abs(float(ref_loss))), (float(pka["loss"].item()), float(ref_loss))
+
+
+def test_drop_in_step_captured_in_a_graph(dev):
+    """The autograd drop-in under `torch.cuda.graph` (no reference counterpart: the reference's forward reads its instance count back
+    in the middle, rasterizer_impl.cu:354, so it cannot be captured).  On a capturing stream the binding takes igs_rast_forward_nowait
+    (same launches, no host wait); render -> L1 -> backward is captured once and replayed for OTHER cameras through static camera
+    tensors; every replay must reproduce the eager gradients of that camera, and `capture_status()` the eager num_rendered."""
+    import copy
+    from igs_amd.refine import render
+    from igs_amd.rasterizer import capture_status
+    raw, cams, bg = sear_steak_like_scene(P=20000, n_cams=3, width=400, height=300, focal=220.0)
+    cams = [c.to(dev) for c in cams]
+    bg = bg.to(dev)
+    leaves = {k: v.to(dev).clone().requires_grad_(True) for k, v in activate(raw).items()}
+    gts = [torch.rand(3, 300, 400, device=dev, generator=torch.Generator(device=dev).manual_seed(i)) for i in range(3)]
+
+    def eager(i):
+        for v in leaves.values():
+            v.grad = None
+        pk = render(leaves, cams[i], bg)
+        loss = torch.abs(pk["images_pred"] - gts[i]).mean()
+        loss.backward()
+        return float(loss.detach()), {k: v.grad.clone() for k, v in leaves.items()}, int((pk["radii"] > 0).sum())
+
+    # static inputs of the graph
+    cam_s = copy.copy(cams[0])
+    cam_s.world_view_transform = cams[0].world_view_transform.clone()
+    cam_s.full_proj_transform = cams[0].full_proj_transform.clone()
+    cam_s.camera_center = cams[0].camera_center.clone()
+    gt_s = gts[0].clone()
+    side = torch.cuda.Stream(device=dev)
+    side.wait_stream(torch.cuda.current_stream(dev))
+    with torch.cuda.stream(side):                      # warm-up on a side stream (PyTorch's capture recipe)
+        for _ in range(2):
+            for v in leaves.values():
+                v.grad = None
+            torch.abs(render(leaves, cam_s, bg)["images_pred"] - gt_s).mean().backward()
+    torch.cuda.current_stream(dev).wait_stream(side)
+    for v in leaves.values():
+        v.grad = None
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        pk_s = render(leaves, cam_s, bg)
+        loss_s = torch.abs(pk_s["images_pred"] - gt_s).mean()
+        loss_s.backward()
+    got = []
+    for i in (1, 2, 0, 1):
+        cam_s.world_view_transform.copy_(cams[i].world_view_transform)
+        cam_s.full_proj_transform.copy_(cams[i].full_proj_transform)
+        cam_s.camera_center.copy_(cams[i].camera_center)
+        gt_s.copy_(gts[i])
+        for v in leaves.values():
+            v.grad.zero_()                             # (the captured backward accumulates into the .grad tensors it found)
+        g.replay()
+        torch.cuda.synchronize()
+        n, overflow = capture_status()
+        assert overflow == 0 and n > 0
+        got.append((i, float(loss_s.detach()), {k: v.grad.clone() for k, v in leaves.items()}, int((pk_s["radii"] > 0).sum()), n))
+    # ordinary eager calls afterwards (they wait for their own status again) give the reference values
+    want = [eager(i) for i in range(3)]
+    assert len({g_[4] for g_ in got}) > 1           # (the cameras really differ)
+    for i, loss, grads, visible, n in got:
+        assert abs(loss - want[i][0]) < 1e-6 * max(1.0, abs(want[i][0]))
+        assert visible == want[i][2]
+        for k in leaves:
+            A, B = grads[k].cpu().numpy(), want[i][1][k].cpu().numpy()
+            r = rel(A, B)
+            assert np.quantile(r, 0.99) < 5e-3 and np.median(r) < 1e-4, (i, k, np.quantile(r, 0.99), np.median(r))
