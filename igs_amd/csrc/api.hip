@@ -159,6 +159,7 @@ struct FwdExtra {
     float* zero_gacc = nullptr;         // ... backward accumulators / loss shards the preprocess kernel zero-fills on the side
     float* zero_loss = nullptr;
     float* zero_loss2 = nullptr;
+    bool skip_bwd_state = false;        // ... the loss is colour-only: blend_fwd need not store the geometry branches' backward state
 };
 // where the last slab-binned forward left its device-side validity words (refine step guards)
 struct LastFwd { const uint32_t* overflow = nullptr; const uint32_t* prefilter = nullptr; };
@@ -220,6 +221,7 @@ static int forward_impl(
     fp.view = viewmatrix; fp.proj = projmatrix; fp.campos = cam_pos;
     fp.raw_activations = ex.raw_activations ? 1 : 0;
     fp.zero_gacc = ex.zero_gacc; fp.zero_loss = ex.zero_loss; fp.zero_loss2 = ex.zero_loss2;
+    fp.zero_gacc_stride = ex.skip_bwd_state ? GACC_COMPACT_F : GACC_F;      // (colour-only loss <=> compact accumulator rows)
     g_last_fwd = LastFwd();
 
     const size_t counter_bytes = (COUNTER_SHARDS + 1) * COUNTER_SHARD_STRIDE * 4;
@@ -346,6 +348,7 @@ static int forward_impl(
     ba.normal_length = (float*)(ibase + IL.normal_length);
     ba.stats_src = slab_stats; ba.flag_src = counters + 1; ba.host_dst = slab_pending ? g_slot.pinned_dev : nullptr;
     ba.tile_order = (uint32_t*)(ibase + IL.tile_order);          // built on the side for the backward (both binning paths)
+    ba.skip_bwd_state = ex.skip_bwd_state ? 1 : 0;
     if (slab_pending) { g_host_seq = g_host_seq + 1 ? g_host_seq + 1 : 1; g_slot.pinned[3] = 0; }
     ba.host_seq = g_host_seq;
     g_status_stream = s;
@@ -547,8 +550,13 @@ static int backward_impl(
 
     prof_mark(s, ST_GAP);
     float* loss_shards = (float*)((char*)gacc + ws_gacc_bytes(P));
-    if (!(fuse && fuse->prezeroed))                // (igs_refine_step: the forward's preprocess kernel zero-filled the accumulators)
-        HIP_TRY(zero_fill_async(s, gacc, l1_gt ? ws_gacc_bytes(P) + WS_LOSS_BYTES : (size_t)P * GACC_F * 4), "zero gacc");
+    // which blend instance will run (launch_blend_bwd decides the same way): the colour-only one packs its moments into 64-byte rows
+    const bool will_compact = !(require_coord && (dL_dpix_coord || dL_dpix_mcoord)) && !(require_depth && (dL_dpix_depth || dL_dpix_mdepth))
+                              && !((require_coord || require_depth) && dL_dpixel_normals);
+    if (!(fuse && fuse->prezeroed)) {              // (igs_refine_step: the forward's preprocess kernel zero-filled the accumulators)
+        HIP_TRY(zero_fill_async(s, gacc, (size_t)P * (will_compact ? GACC_COMPACT_F : GACC_F) * 4), "zero gacc");
+        if (l1_gt) HIP_TRY(zero_fill_async(s, loss_shards, WS_LOSS_BYTES), "zero loss shards");
+    }
     prof_mark(s, ST_MEMSET);
     BlendBwdArgs ba;
     ba.W = width; ba.H = height; ba.gx = gx; ba.gy = gy; ba.fx = fx; ba.fy = fy; ba.bg = background;
@@ -564,10 +572,11 @@ static int backward_impl(
     ba.l1_gt = l1_gt; ba.l1_color = l1_color; ba.l1_scale = l1_scale; ba.l1_loss = loss_shards;
     ba.want_absgrad = (fuse && !dL_dmean2D) ? 0 : 1;
     ba.tile_order = (const uint32_t*)(ibase + IL.tile_order);    // the forward's blend kernel ordered the tiles heaviest-first
-    bool gacc_compact = false;
+    bool gacc_compact = will_compact;
     int inst_bits = -1;
     if (R > 0) {
         HIP_TRY(launch_blend_bwd(s, ba, require_coord != 0, require_depth != 0, &gacc_compact, &inst_bits), "blend_bwd launch");
+        if (gacc_compact != will_compact) return fail(IGS_RAST_E_INVALID, "internal: accumulator layout mismatch");
         __atomic_store_n(&g_last_bwd_instance, inst_bits, __ATOMIC_RELAXED);
         DBG_SYNC("blend_bwd");
         prof_mark(s, ST_BLEND_BWD);
@@ -694,6 +703,7 @@ extern "C" int igs_refine_step(const igs_refine_step_args* a)
         ex.zero_loss2 = dssim ? ssim_shards + 1024 : nullptr;
         ex.defer_status = attempt == 0;            // second attempt: synchronous forward, which sorts out its scratch sizes itself
         ex.raw_activations = true;
+        ex.skip_bwd_state = !dn;                   // (colour-only backward instance: see BlendFwdArgs)
         const int R = forward_impl(a->stream, capture_alloc, &cg, capture_alloc, &cb, capture_alloc, &ci, a->P, a->D, a->M, a->background,
                                    a->width, a->height, xyz, shs, nullptr, opac, scal, 1.0f, rotn, nullptr, a->viewmatrix, a->projmatrix,
                                    a->cam_pos, a->tan_fovx, a->tan_fovy, 0.0f, 0, color, coord, mcoord, depth, mdepth, alpha, normal,

@@ -123,7 +123,8 @@ blend_bwd_kernel(const BlendBwdArgs a)
     const uint2 range = ((const uint2*)a.ranges)[tile];
     // clamped to the tile's list length: a corrupt image buffer must not turn into an out-of-bounds gather
     int last_contributor = inside ? (int)min(a.n_contrib[pix], range.y - range.x) : 0;
-    const uint32_t max_contributor = inside ? a.n_contrib[pix + HW] : 0u;
+    uint32_t max_contributor = 0u;                 // (the median index: only the coordinate / depth branches use it)
+    if constexpr (COORD || DEPTH) max_contributor = inside ? a.n_contrib[pix + HW] : 0u;
 
     // ---- per-pixel upstream gradients (backward.cu:732-781); zero for pixels nothing was blended into, whose
     //      normalisations would otherwise be 0/0 (the reference never consumes those values either)
@@ -339,7 +340,7 @@ blend_bwd_kernel(const BlendBwdArgs a)
                     tot = __uint_as_float(s16[0]) + __uint_as_float(s16[1]);
                 }
                 const uint32_t gid = GEO ? chunk_id[j] : __float_as_uint(q2.y);
-                if (lane < NROWS) atomicAdd(&a.gacc[(size_t)gid * GACC_F + slot_of_row], tot);
+                if (lane < NROWS) atomicAdd(&a.gacc[(size_t)gid * (COMPACT ? GACC_COMPACT_F : GACC_F) + slot_of_row], tot);
             }
         }
     }

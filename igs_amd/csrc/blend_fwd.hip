@@ -160,7 +160,7 @@ blend_fwd_kernel(const BlendFwdArgs a)
             }
         }
         a.n_contrib[pix] = last_contributor;
-        a.n_contrib[pix + HW] = max_contributor;
+        if (!a.skip_bwd_state) a.n_contrib[pix + HW] = max_contributor;
         a.out_color[pix] = C0 + T * a.bg[0];
         a.out_color[HW + pix] = C1 + T * a.bg[1];
         a.out_color[2 * HW + pix] = C2 + T * a.bg[2];
@@ -171,7 +171,7 @@ blend_fwd_kernel(const BlendFwdArgs a)
             a.out_coord[pix] = last_contributor ? Co0 / weight : 0.f;
             a.out_coord[HW + pix] = last_contributor ? Co1 / weight : 0.f;
             a.out_coord[2 * HW + pix] = last_contributor ? Co2 / weight : 0.f;
-            a.accum_coord[pix] = Co0; a.accum_coord[HW + pix] = Co1; a.accum_coord[2 * HW + pix] = Co2;
+            if (!a.skip_bwd_state) { a.accum_coord[pix] = Co0; a.accum_coord[HW + pix] = Co1; a.accum_coord[2 * HW + pix] = Co2; }
             a.out_mcoord[pix] = mC0; a.out_mcoord[HW + pix] = mC1; a.out_mcoord[2 * HW + pix] = mC2;
         } else {
             a.out_coord[pix] = 0.f; a.out_coord[HW + pix] = 0.f; a.out_coord[2 * HW + pix] = 0.f;
@@ -179,7 +179,7 @@ blend_fwd_kernel(const BlendFwdArgs a)
         }
         if constexpr (DEPTH) {
             const float depth_ln = Depth / ln;
-            a.accum_depth[pix] = depth_ln;
+            if (!a.skip_bwd_state) a.accum_depth[pix] = depth_ln;
             a.out_depth[pix] = last_contributor ? depth_ln / weight : 0.f;
             a.out_mdepth[pix] = mDepth / ln;
         } else {
@@ -188,11 +188,11 @@ blend_fwd_kernel(const BlendFwdArgs a)
         if constexpr (NORMAL) {
             if (last_contributor) {
                 float len = sqrtf(N0 * N0 + N1 * N1 + N2 * N2);
-                a.normal_length[pix] = len;
+                if (!a.skip_bwd_state) a.normal_length[pix] = len;
                 len = fmaxf(len, 1.0E-12F);
                 a.out_normal[pix] = N0 / len; a.out_normal[HW + pix] = N1 / len; a.out_normal[2 * HW + pix] = N2 / len;
             } else {
-                a.normal_length[pix] = 1.f;
+                if (!a.skip_bwd_state) a.normal_length[pix] = 1.f;
                 a.out_normal[pix] = 0.f; a.out_normal[HW + pix] = 0.f; a.out_normal[2 * HW + pix] = 0.f;
             }
         } else {

@@ -30,6 +30,7 @@
 //   18,19 dL_dmean2D.xy (NDC-scaled)  20 dL_dmean2D.z (abs sum)
 //   21..23 dL_dconic (x, y, w)  24 dL_dopacity (before coef)
 #define GACC_F 32
+#define GACC_COMPACT_F 16              // row stride of the colour-only instance's 10 moments: one 64-byte atomic request, two Gaussians per line
 enum { GA_COLOR = 0, GA_VP = 3, GA_CP = 6, GA_TS = 12, GA_RP = 13, GA_NRM = 15, GA_M2D = 18, GA_M2DZ = 20,
        GA_CONIC = 21, GA_OPA = 24, GA_USED = 25 };
 
@@ -110,6 +111,7 @@ struct FwdParams {
     float scale_modifier, tan_fovx, tan_fovy, fx, fy, kernel_size;
     int prefiltered;
     const float *view, *proj, *campos;      // device pointers (transposed 4x4 matrices, camera centre)
+    int zero_gacc_stride = GACC_F;      // floats per accumulator row to zero (GACC_COMPACT_F when the colour-only backward will run)
     float* zero_gacc; float* zero_loss; float* zero_loss2;     // refine step: backward accumulators / loss shards to zero-fill on the side (NULL = no)
     int raw_activations;                    // refine step: opacities / scales / rotations are the raw optimiser leaves
                                             // (sigmoid / exp / normalize applied here: gaussian_model.py:90-127)
@@ -146,6 +148,8 @@ struct BlendFwdArgs {
     uint32_t* n_contrib; float *accum_coord, *accum_depth, *normal_length;
     // slab binning: workgroup 0 forwards {R, overflow, prefilter flag} to host-visible memory (no copy kernels on the stream)
     const uint32_t* stats_src; const uint32_t* flag_src; uint32_t* host_dst; uint32_t host_seq;      // host_dst[3] = host_seq, written last
+    int skip_bwd_state = 0;      // igs_refine_step with a colour-only loss: the backward instance that will run reads none of accum_coord /
+                                 // accum_depth / normal_length / the median index -- do not write them (24 of 88 bytes per pixel)
     uint32_t* tile_order = nullptr;            // [T] out: tile ids by descending load class, built by workgroup 0 on the side (for the backward)
 };
 hipError_t launch_blend_fwd(hipStream_t s, const BlendFwdArgs& a, bool coord, bool depth);

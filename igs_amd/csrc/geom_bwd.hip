@@ -268,7 +268,7 @@ geom_bwd_kernel(const GBArgs args)
 
     if (active && a.radii[idx] > 0) {
         const float4* R4 = (const float4*)(a.rec + (size_t)idx * REC_F);
-        const float4* G4 = (const float4*)(a.gacc + (size_t)idx * GACC_F);
+        const float4* G4 = (const float4*)(a.gacc + (size_t)idx * (a.gacc_compact ? GACC_COMPACT_F : GACC_F));
         const float4 r0 = R4[0], r1 = R4[1], r2 = R4[2], r4 = R4[4], r5 = R4[5], r6 = R4[6], r7 = R4[7];
         float4 g0, g1, g2, g3, g4, g5, g6;
         if (a.gacc_compact) {

@@ -56,10 +56,11 @@ preprocess_fwd_kernel(const PreArgs a, float* __restrict__ rec, uint32_t* __rest
         // refine step: this kernel is latency-bound and leaves the memory pipes idle -- zero-fill the backward's accumulator
         // line of this Gaussian (and the loss shards) here instead of in a 25 MB fill of its own
         if (idx < p.P) {
-            float4* Z4 = (float4*)(p.zero_gacc + (size_t)idx * GACC_F);
+            float4* Z4 = (float4*)(p.zero_gacc + (size_t)idx * p.zero_gacc_stride);
             const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-            for (int k = 0; k < GACC_F / 4; k++) Z4[k] = z;
+            for (int k = 0; k < GACC_F / 4; k++)
+                if (4 * k < p.zero_gacc_stride) Z4[k] = z;
         }
         if (blockIdx.x == 0 && threadIdx.x < 64) {
             p.zero_loss[16 * threadIdx.x] = 0.f;
