@@ -18,7 +18,12 @@
 #define CHUNK 192
 #define NSW (CHUNK / 64)     // staging waves
 
-template <bool COORD, bool DEPTH, bool NORMAL>
+// LEAN = the refine step with a colour-only loss (BlendFwdArgs::skip_bwd_state): the geometry branches' backward state (accumulated
+// coordinate / depth, normal length, median index: 24 of 88 bytes per pixel) is not stored -- the colour-only backward instance
+// reads none of it.  (Storing the coordinate / depth / normal maps, which nothing reads again in such a step, with the
+// non-temporal policy was measured too: 59.5 -> 86 us -- a quad row is 32 bytes of a line, and nt stores give up the L2's
+// write combining.)
+template <bool COORD, bool DEPTH, bool NORMAL, bool LEAN = false>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8)))
 blend_fwd_kernel(const BlendFwdArgs a)
 {
@@ -160,7 +165,7 @@ blend_fwd_kernel(const BlendFwdArgs a)
             }
         }
         a.n_contrib[pix] = last_contributor;
-        if (!a.skip_bwd_state) a.n_contrib[pix + HW] = max_contributor;
+        if constexpr (!LEAN) a.n_contrib[pix + HW] = max_contributor;
         a.out_color[pix] = C0 + T * a.bg[0];
         a.out_color[HW + pix] = C1 + T * a.bg[1];
         a.out_color[2 * HW + pix] = C2 + T * a.bg[2];
@@ -171,7 +176,7 @@ blend_fwd_kernel(const BlendFwdArgs a)
             a.out_coord[pix] = last_contributor ? Co0 / weight : 0.f;
             a.out_coord[HW + pix] = last_contributor ? Co1 / weight : 0.f;
             a.out_coord[2 * HW + pix] = last_contributor ? Co2 / weight : 0.f;
-            if (!a.skip_bwd_state) { a.accum_coord[pix] = Co0; a.accum_coord[HW + pix] = Co1; a.accum_coord[2 * HW + pix] = Co2; }
+            if constexpr (!LEAN) { a.accum_coord[pix] = Co0; a.accum_coord[HW + pix] = Co1; a.accum_coord[2 * HW + pix] = Co2; }
             a.out_mcoord[pix] = mC0; a.out_mcoord[HW + pix] = mC1; a.out_mcoord[2 * HW + pix] = mC2;
         } else {
             a.out_coord[pix] = 0.f; a.out_coord[HW + pix] = 0.f; a.out_coord[2 * HW + pix] = 0.f;
@@ -179,7 +184,7 @@ blend_fwd_kernel(const BlendFwdArgs a)
         }
         if constexpr (DEPTH) {
             const float depth_ln = Depth / ln;
-            if (!a.skip_bwd_state) a.accum_depth[pix] = depth_ln;
+            if constexpr (!LEAN) a.accum_depth[pix] = depth_ln;
             a.out_depth[pix] = last_contributor ? depth_ln / weight : 0.f;
             a.out_mdepth[pix] = mDepth / ln;
         } else {
@@ -188,11 +193,11 @@ blend_fwd_kernel(const BlendFwdArgs a)
         if constexpr (NORMAL) {
             if (last_contributor) {
                 float len = sqrtf(N0 * N0 + N1 * N1 + N2 * N2);
-                if (!a.skip_bwd_state) a.normal_length[pix] = len;
+                if constexpr (!LEAN) a.normal_length[pix] = len;
                 len = fmaxf(len, 1.0E-12F);
                 a.out_normal[pix] = N0 / len; a.out_normal[HW + pix] = N1 / len; a.out_normal[2 * HW + pix] = N2 / len;
             } else {
-                if (!a.skip_bwd_state) a.normal_length[pix] = 1.f;
+                if constexpr (!LEAN) a.normal_length[pix] = 1.f;
                 a.out_normal[pix] = 0.f; a.out_normal[HW + pix] = 0.f; a.out_normal[2 * HW + pix] = 0.f;
             }
         } else {
@@ -205,7 +210,8 @@ hipError_t launch_blend_fwd(hipStream_t s, const BlendFwdArgs& a, bool coord, bo
 {
     const dim3 grid(tile_grid_blocks(a.gx, a.gy)), block(256);
     // dispatch of forward.cu:732-739: NORMAL is on whenever COORD or DEPTH is
-    if (coord && depth) hipLaunchKernelGGL((blend_fwd_kernel<true, true, true>), grid, block, 0, s, a);
+    if (a.skip_bwd_state && coord && depth) hipLaunchKernelGGL((blend_fwd_kernel<true, true, true, true>), grid, block, 0, s, a);
+    else if (coord && depth) hipLaunchKernelGGL((blend_fwd_kernel<true, true, true>), grid, block, 0, s, a);
     else if (coord) hipLaunchKernelGGL((blend_fwd_kernel<true, false, true>), grid, block, 0, s, a);
     else if (depth) hipLaunchKernelGGL((blend_fwd_kernel<false, true, true>), grid, block, 0, s, a);
     else hipLaunchKernelGGL((blend_fwd_kernel<false, false, false>), grid, block, 0, s, a);
