@@ -148,8 +148,8 @@ sh_grad_views_kernel(int P, int D, int M, int V, const float* __restrict__ means
         for (int i0 = threadIdx.x; i0 < total4; i0 += 2 * 128) {
             const int i1 = i0 + 128;
             const bool two = i1 < total4;
-            float4 Pa = P4p[i0], Ma = M4p[i0], Va = V4p[i0], Pb, Mb, Vb;
-            if (two) { Pb = P4p[i1]; Mb = M4p[i1]; Vb = V4p[i1]; }
+            float4 Pa = P4p[i0], Ma = ld_moment(M4p + i0), Va = ld_moment(V4p + i0), Pb, Mb, Vb;
+            if (two) { Pb = P4p[i1]; Mb = ld_moment(M4p + i1); Vb = ld_moment(V4p + i1); }
             {
                 const int f = 4 * i0, g = f / F, k = f - g * F;
                 const float* sp = rows + g * 49 + k;
@@ -157,7 +157,7 @@ sh_grad_views_kernel(int P, int D, int M, int V, const float* __restrict__ means
                 adam_update(Pa.y, Ma.y, Va.y, sp[1], ad.lr_over_bc1, ad.b1, ad.b2, ad.eps, ad.inv_sqrt_bc2);
                 adam_update(Pa.z, Ma.z, Va.z, sp[2], ad.lr_over_bc1, ad.b1, ad.b2, ad.eps, ad.inv_sqrt_bc2);
                 adam_update(Pa.w, Ma.w, Va.w, sp[3], ad.lr_over_bc1, ad.b1, ad.b2, ad.eps, ad.inv_sqrt_bc2);
-                P4p[i0] = Pa; M4p[i0] = Ma; V4p[i0] = Va;
+                P4p[i0] = Pa; st_moment(M4p + i0, Ma); st_moment(V4p + i0, Va);
             }
             if (two) {
                 const int f = 4 * i1, g = f / F, k = f - g * F;
@@ -166,7 +166,7 @@ sh_grad_views_kernel(int P, int D, int M, int V, const float* __restrict__ means
                 adam_update(Pb.y, Mb.y, Vb.y, sp[1], ad.lr_over_bc1, ad.b1, ad.b2, ad.eps, ad.inv_sqrt_bc2);
                 adam_update(Pb.z, Mb.z, Vb.z, sp[2], ad.lr_over_bc1, ad.b1, ad.b2, ad.eps, ad.inv_sqrt_bc2);
                 adam_update(Pb.w, Mb.w, Vb.w, sp[3], ad.lr_over_bc1, ad.b1, ad.b2, ad.eps, ad.inv_sqrt_bc2);
-                P4p[i1] = Pb; M4p[i1] = Mb; V4p[i1] = Vb;
+                P4p[i1] = Pb; st_moment(M4p + i1, Mb); st_moment(V4p + i1, Vb);
             }
         }
         for (int e = 4 * total4 + threadIdx.x; e < total; e += 128) {
@@ -228,40 +228,6 @@ hipError_t launch_sh_adam_views(hipStream_t s, int P, int D, int M, int V, const
 }
 
 struct GBArgs { GeomBwdArgs a; RefineFuse f; };
-
-// Adam moments are read once and written once per step and there are 189 MB of them per step: streamed past the caches with the
-// non-temporal policy (GEOM_NT: 1 = moments, 2 = the parameters' stores too) so that they do not evict what the next kernels re-read
-#ifndef GEOM_NT
-#define GEOM_NT 1          // (same-box A/B, round 2: 0.2798 -> 0.2738 ms/step; 2 = no further gain)
-#endif
-typedef float v4f_t __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ float4 ld_moment(const float4* p)
-{
-#if GEOM_NT >= 1
-    const v4f_t v = __builtin_nontemporal_load((const v4f_t*)p);
-    return make_float4(v.x, v.y, v.z, v.w);
-#else
-    return *p;
-#endif
-}
-__device__ __forceinline__ void st_moment(float4* p, const float4& x)
-{
-#if GEOM_NT >= 1
-    v4f_t v; v.x = x.x; v.y = x.y; v.z = x.z; v.w = x.w;
-    __builtin_nontemporal_store(v, (v4f_t*)p);
-#else
-    *p = x;
-#endif
-}
-__device__ __forceinline__ void st_param(float4* p, const float4& x)
-{
-#if GEOM_NT >= 2
-    v4f_t v; v.x = x.x; v.y = x.y; v.z = x.z; v.w = x.w;
-    __builtin_nontemporal_store(v, (v4f_t*)p);
-#else
-    *p = x;
-#endif
-}
 
 #ifndef GEOM_WAVES_PER_EU
 #define GEOM_WAVES_PER_EU 2

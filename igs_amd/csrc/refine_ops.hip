@@ -12,7 +12,7 @@ adam_kernel(size_t n4, size_t n, float* __restrict__ p, const float* __restrict_
 {
     const size_t stride = (size_t)gridDim.x * 256;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
-        float4 P4 = ((float4*)p)[i], M4 = ((float4*)m)[i], V4 = ((float4*)v)[i];
+        float4 P4 = ((float4*)p)[i], M4 = ld_moment((const float4*)m + i), V4 = ld_moment((const float4*)v + i);
         const float4 G4 = ((const float4*)g)[i];
         float* pp = (float*)&P4; float* mm = (float*)&M4; float* vv = (float*)&V4; const float* gg = (const float*)&G4;
 #pragma unroll
@@ -21,7 +21,7 @@ adam_kernel(size_t n4, size_t n, float* __restrict__ p, const float* __restrict_
             vv[k] = b2 * vv[k] + (1.f - b2) * gg[k] * gg[k];
             pp[k] -= lr_over_bc1 * mm[k] / (sqrtf(vv[k]) * inv_sqrt_bc2 + eps);
         }
-        ((float4*)p)[i] = P4; ((float4*)m)[i] = M4; ((float4*)v)[i] = V4;
+        ((float4*)p)[i] = P4; st_moment((float4*)m + i, M4); st_moment((float4*)v + i, V4);
     }
     // tail
     for (size_t i = n4 * 4 + (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
@@ -63,7 +63,7 @@ adam_groups_kernel(const AdamGroups G, float* __restrict__ p, const float* __res
     const size_t n4 = aligned ? n / 4 : 0;
     const size_t stride = (size_t)gridDim.x * 256;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
-        float4 P4 = ((float4*)pp)[i], M4 = ((float4*)mm)[i], V4 = ((float4*)vv)[i];
+        float4 P4 = ((float4*)pp)[i], M4 = ld_moment((const float4*)mm + i), V4 = ld_moment((const float4*)vv + i);
         const float4 G4 = ((const float4*)gg)[i];
         float* a = (float*)&P4; float* b = (float*)&M4; float* c = (float*)&V4; const float* d = (const float*)&G4;
 #pragma unroll
@@ -72,7 +72,7 @@ adam_groups_kernel(const AdamGroups G, float* __restrict__ p, const float* __res
             c[q] = b2 * c[q] + (1.f - b2) * d[q] * d[q];
             a[q] -= lr * b[q] / (sqrtf(c[q]) * inv_sqrt_bc2 + eps);
         }
-        ((float4*)pp)[i] = P4; ((float4*)mm)[i] = M4; ((float4*)vv)[i] = V4;
+        ((float4*)pp)[i] = P4; st_moment((float4*)mm + i, M4); st_moment((float4*)vv + i, V4);
     }
     for (size_t i = n4 * 4 + (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
         const float gi = gg[i];
