@@ -203,12 +203,20 @@ blend_bwd_kernel(const BlendBwdArgs a)
     // LDS byte offset of this wave's transpose buffer (the low half of the flat address of a __shared__ object is its LDS offset)
     const unsigned myred_m0 = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(size_t)myred);
     constexpr int LPR = NROWS <= 16 ? 4 : 2;             // lanes per row of the transpose buffer
-    const int rrow = lane & (64 / LPR - 1), rpart = lane / (64 / LPR);
-    const int rseg = LPR == 4 ? ((rpart + (int)((SEG_ROT >> (2 * (rrow & 15))) & 3u)) & 3) : rpart;      // which column segment this lane sums
+#ifndef BWD_ADJ
+#define BWD_ADJ 1             // (same-box A/B, round 2: blend_bwd 82.6 -> 80.2 us against the rotated 16-lanes-apart assignment + permlane swaps)
+#endif
+    // ADJ (rows of <= 15 moments): the LPR lanes of a row are NEIGHBOURS (lane = 4 row + part), so the active lanes fill whole 16-lane
+    // service groups from the bottom (36 lanes for 9 rows: two groups and a quarter; the last group stays empty) and the partials fold
+    // with two quad-permute DPP adds; at stride 68 that assignment is conflict-free as it stands (rows 4g..4g+3 x segments 0..3 of a
+    // group start 16 different multiples of four banks)
+    constexpr bool ADJ = BWD_ADJ && LPR == 4 && NROWS < 16;
+    const int rrow = ADJ ? (int)(lane >> 2) : (int)(lane & (64 / LPR - 1)), rpart = ADJ ? (int)(lane & 3) : (int)(lane / (64 / LPR));
+    const int rseg = ADJ ? rpart : LPR == 4 ? ((rpart + (int)((SEG_ROT >> (2 * (rrow & 15))) & 3u)) & 3) : rpart;      // which column segment this lane sums
     // gacc slot of compact row `lane` (rows are emitted in slot order with the dead groups left out)
     // (the colour-only instance packs its 10 moments into slots 0..9 instead: one 64-byte atomic request per row, not two --
     //  float atomics execute at the memory side in 64-byte requests, ~20 G requests/s for the whole chip)
-    int slot_of_row = (int)lane;
+    int slot_of_row = ADJ ? (int)(lane >> 2) : (int)lane;
     constexpr bool COMPACT = !COORD && !DEPTH && !NORMAL;
     if (!COMPACT && !COORD && slot_of_row >= 3) slot_of_row += 9;
     if (!COMPACT && !DEPTH && slot_of_row >= 12) slot_of_row += 3;
@@ -333,14 +341,21 @@ blend_bwd_kernel(const BlendBwdArgs a)
                 // the LPR partials of a row sit 64 / LPR lanes apart: v_permlane32_swap / v_permlane16_swap (gfx950) fold them in the
                 // vector ALU -- no trip through the LDS crossbar (ds_bpermute: 6 LDS cycles each on the kernel's busiest unit, and a
                 // round trip of latency in the middle of the row's dependency chain)
-                const auto s32 = __builtin_amdgcn_permlane32_swap(__float_as_uint(part), __float_as_uint(part), false, false);
-                float tot = __uint_as_float(s32[0]) + __uint_as_float(s32[1]);
-                if constexpr (LPR == 4) {
-                    const auto s16 = __builtin_amdgcn_permlane16_swap(__float_as_uint(tot), __float_as_uint(tot), false, false);
-                    tot = __uint_as_float(s16[0]) + __uint_as_float(s16[1]);
+                float tot;
+                if constexpr (ADJ) {
+                    tot = part + __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(part), 0xB1, 0xF, 0xF, false));   // quad_perm [1,0,3,2]
+                    tot = tot + __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(tot), 0x4E, 0xF, 0xF, false));     // quad_perm [2,3,0,1]
+                } else {
+                    const auto s32 = __builtin_amdgcn_permlane32_swap(__float_as_uint(part), __float_as_uint(part), false, false);
+                    tot = __uint_as_float(s32[0]) + __uint_as_float(s32[1]);
+                    if constexpr (LPR == 4) {
+                        const auto s16 = __builtin_amdgcn_permlane16_swap(__float_as_uint(tot), __float_as_uint(tot), false, false);
+                        tot = __uint_as_float(s16[0]) + __uint_as_float(s16[1]);
+                    }
                 }
                 const uint32_t gid = GEO ? chunk_id[j] : __float_as_uint(q2.y);
-                if (lane < NROWS) atomicAdd(&a.gacc[(size_t)gid * (COMPACT ? GACC_COMPACT_F : GACC_F) + slot_of_row], tot);
+                if (ADJ ? ((lane & 3u) == 0u && lane < 4u * NROWS) : (lane < (uint32_t)NROWS))
+                    atomicAdd(&a.gacc[(size_t)gid * (COMPACT ? GACC_COMPACT_F : GACC_F) + slot_of_row], tot);
             }
         }
     }
