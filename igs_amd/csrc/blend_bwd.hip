@@ -222,51 +222,19 @@ blend_bwd_kernel(const BlendBwdArgs a)
     if (!COMPACT && !DEPTH && slot_of_row >= 12) slot_of_row += 3;
     if (!COMPACT && !NORMAL && slot_of_row >= 15) slot_of_row += 3;
 
-    for (int i = 0; i < rounds; i++) {
-        __syncthreads();
-        uint32_t qmask = 0;
-        if (tid < BCHUNK) {
-            const int progress = i * BCHUNK + (int)tid;      // position counted from the back of [0, n)
-            if (progress < n) {
-                const uint32_t id = a.point_list[range.x + (uint32_t)(n - 1 - progress)];
-                const float4* src = (const float4*)(a.rec + (size_t)id * REC_F);
-                float4 q0 = src[0], q1 = src[1], q2 = src[2];
-                if (a.colors_precomp) {
-                    q1.z = a.colors_precomp[3 * (size_t)id]; q1.w = a.colors_precomp[3 * (size_t)id + 1];
-                    q2.x = a.colors_precomp[3 * (size_t)id + 2];
-                }
-                if constexpr (!GEO) q2.y = __uint_as_float(id);      // the colour-only row never reads ts: the id rides in its slot
-                chunk[tid * NQ + 0] = q0; chunk[tid * NQ + 1] = q1; chunk[tid * NQ + 2] = q2;
-                if constexpr (GEO) { chunk[tid * NQ + 3] = src[3]; chunk[tid * NQ + 4] = src[4]; chunk[tid * NQ + 5] = src[5]; chunk_id[tid] = id; }
-                qmask = quad_reach_mask(q0, q1, tile_x0, tile_y0);
-            }
-        }
-        if (wid < NSW) {
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-                const uint64_t b = __ballot((qmask >> q) & 1u);
-                if (lane == 0) quad_bits[q][wid] = b;
-            }
-        }
-        __syncthreads();
-        for (int sw = 0; sw < NSW; sw++) {
-            uint64_t bits = quad_bits[wid][sw];
-            bits = uniform64(bits);
-            while (bits != 0ull) {
-                const int j = sw * 64 + __builtin_ctzll(bits);
-                bits &= bits - 1;
-                const int eidx = n - 1 - (i * BCHUNK + j);      // 0-based position in the tile's list = the reference's `contributor`
-                if (eidx >= my_wave_max) continue;              // (scalar test) behind every pixel of this quad: another quad's tail
-                const float4 q0 = chunk[j * NQ + 0];
-                const float4 q1 = chunk[j * NQ + 1];
+    // ---- one (wave, splat) row: `R` hands out the splat's record (q0 = {x, y, conic.x, conic.y}, q1 = {conic.z, opacity, r, g},
+    //      q2 = {b, ...}) and its Gaussian id (LdsRec below: the staged LDS copy)
+    auto process_row = [&](const int j, const int eidx, auto R) {
+                const float4 q0 = R.q0();
+                const float4 q1 = R.q1();
                 const float dx = q0.x - pixfx, dy = q0.y - pixfy;
                 const float power = gauss_power(q0.z, q0.w, q1.x, dx, dy);
                 const float G = __expf(power);
                 const float alpha = fminf(0.99f, q1.y * G);
                 const bool valid = (eidx < last_contributor) && !(power > 0.0f) && !(alpha < 1.0f / 255.0f);
-                if (__ballot(valid) == 0ull) continue;
+                if (__ballot(valid) == 0ull) return;
 
-                const float4 q2 = chunk[j * NQ + 2];
+                const float4 q2 = R.q2();
                 // 1/(1-alpha) once (v_rcp_f32, 1 ulp) instead of two IEEE divisions; 1-alpha >= 0.01
                 const float inv_one_m = __builtin_amdgcn_rcpf(1.f - alpha);
                 T = valid ? T * inv_one_m : T;
@@ -338,14 +306,13 @@ blend_bwd_kernel(const BlendBwdArgs a)
                     part = (acc4.x + acc4.y) + (acc4.z + acc4.w);
                 }
                 __builtin_amdgcn_wave_barrier();      // ... and the next splat's column writes must stay behind these row reads
-                // the LPR partials of a row sit 64 / LPR lanes apart: v_permlane32_swap / v_permlane16_swap (gfx950) fold them in the
-                // vector ALU -- no trip through the LDS crossbar (ds_bpermute: 6 LDS cycles each on the kernel's busiest unit, and a
-                // round trip of latency in the middle of the row's dependency chain)
                 float tot;
                 if constexpr (ADJ) {
                     tot = part + __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(part), 0xB1, 0xF, 0xF, false));   // quad_perm [1,0,3,2]
                     tot = tot + __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(tot), 0x4E, 0xF, 0xF, false));     // quad_perm [2,3,0,1]
                 } else {
+                    // the LPR partials of a row sit 64 / LPR lanes apart: v_permlane32_swap / v_permlane16_swap (gfx950) fold them in the
+                    // vector ALU -- no trip through the LDS crossbar (ds_bpermute: 6 LDS cycles each, and a round trip of latency)
                     const auto s32 = __builtin_amdgcn_permlane32_swap(__float_as_uint(part), __float_as_uint(part), false, false);
                     tot = __uint_as_float(s32[0]) + __uint_as_float(s32[1]);
                     if constexpr (LPR == 4) {
@@ -353,9 +320,58 @@ blend_bwd_kernel(const BlendBwdArgs a)
                         tot = __uint_as_float(s16[0]) + __uint_as_float(s16[1]);
                     }
                 }
-                const uint32_t gid = GEO ? chunk_id[j] : __float_as_uint(q2.y);
+                const uint32_t gid = R.gid(q2);
                 if (ADJ ? ((lane & 3u) == 0u && lane < 4u * NROWS) : (lane < (uint32_t)NROWS))
                     atomicAdd(&a.gacc[(size_t)gid * (COMPACT ? GACC_COMPACT_F : GACC_F) + slot_of_row], tot);
+    };
+    // the record of staged splat j, read back from LDS as wave-uniform (broadcast) ds_read_b128
+    struct LdsRec {
+        const float4* r; const uint32_t* idp;
+        __device__ __forceinline__ float4 q0() const { return r[0]; }
+        __device__ __forceinline__ float4 q1() const { return r[1]; }
+        __device__ __forceinline__ float4 q2() const { return r[2]; }
+        __device__ __forceinline__ uint32_t gid(const float4& q2v) const { return GEO ? *idp : __float_as_uint(q2v.y); }
+    };
+    // (Measured and dropped, round 2: fetching the row's record -- wave-uniform data -- with scalar loads straight from the record array
+    //  into SGPRs, one row ahead (s_load_dwordx8 + x2, the vector ALU taking the values as scalar operands, no staged copy and no
+    //  broadcast ds_read_b128 at all): parity-green, blend_bwd 80.0 -> 88.5 us -- the scalar cache does not keep up with 32 waves
+    //  per CU pulling a fresh 40 bytes each per row.)
+    for (int i = 0; i < rounds; i++) {
+        __syncthreads();
+        uint32_t qmask = 0;
+        if (tid < BCHUNK) {
+            const int progress = i * BCHUNK + (int)tid;      // position counted from the back of [0, n)
+            if (progress < n) {
+                const uint32_t id = a.point_list[range.x + (uint32_t)(n - 1 - progress)];
+                const float4* src = (const float4*)(a.rec + (size_t)id * REC_F);
+                float4 q0 = src[0], q1 = src[1], q2 = src[2];
+                if (a.colors_precomp) {
+                    q1.z = a.colors_precomp[3 * (size_t)id]; q1.w = a.colors_precomp[3 * (size_t)id + 1];
+                    q2.x = a.colors_precomp[3 * (size_t)id + 2];
+                }
+                if constexpr (!GEO) q2.y = __uint_as_float(id);      // the colour-only row never reads ts: the id rides in its slot
+                chunk[tid * NQ + 0] = q0; chunk[tid * NQ + 1] = q1; chunk[tid * NQ + 2] = q2;
+                if constexpr (GEO) { chunk[tid * NQ + 3] = src[3]; chunk[tid * NQ + 4] = src[4]; chunk[tid * NQ + 5] = src[5]; chunk_id[tid] = id; }
+                qmask = quad_reach_mask(q0, q1, tile_x0, tile_y0);
+            }
+        }
+        if (wid < NSW) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const uint64_t b = __ballot((qmask >> q) & 1u);
+                if (lane == 0) quad_bits[q][wid] = b;
+            }
+        }
+        __syncthreads();
+        for (int sw = 0; sw < NSW; sw++) {
+            uint64_t bits = quad_bits[wid][sw];
+            bits = uniform64(bits);
+            while (bits != 0ull) {
+                const int j = sw * 64 + __builtin_ctzll(bits);
+                bits &= bits - 1;
+                const int eidx = n - 1 - (i * BCHUNK + j);      // 0-based position in the tile's list = the reference's `contributor`
+                if (eidx >= my_wave_max) continue;              // (scalar test) behind every pixel of this quad: another quad's tail
+                process_row(j, eidx, LdsRec{ &chunk[j * NQ], &chunk_id[j] });
             }
         }
     }
