@@ -436,13 +436,16 @@ def main():
         dcfg = DensifyConfig(until_iter=100, from_iter=0, interval=20, grad_threshold=0.00015, max_num=int(args.points * 1.05),
                              extent=15.0) if args.densify else None
         cur = {k: v.clone() for k, v in raw.items()}
-        psnr_b, psnr_a = [], []
+        psnr_b, psnr_a, psnr_a_sampled = [], [], []
+        SORT_EVERY = 10
         gv = 0
 
         def one_frame(f, gts_f, timed):
             nonlocal cur, gv, ref
             params = GaussianParams(cur, dev)                 # load_fromstream: new leaves and a NEW optimiser for every frame
-            if not args.no_spatial_sort:
+            # Morton order (0.58 ms of PyTorch argsort + one gather pass): the store handed on by the previous frame is still in
+            # the order of its last sort and a frame moves a Gaussian by ~0.01, so every SORT_EVERY-th frame is enough
+            if not args.no_spatial_sort and f % SORT_EVERY == 0:
                 params.spatial_sort()
             ref = Refiner(params, cams, gts_f[:-1], bg, loss=loss, world_size=world, rank=rank, seed=f, densify=dcfg,
                           lambda_depth_normal=ldn)
@@ -451,8 +454,12 @@ def main():
             ref.start_frame()
             if timed and world > 1:
                 ref.exchange_events = []
-            with torch.no_grad():
-                pb = psnr(render(params.activated(), test_cam, bg)["images_pred"], gts_f[-1])
+            # (the reference evaluates the held-out view once per frame, after the refinement: infer_batch.py:350-353; the
+            #  "before" value is this benchmark's own addition and is sampled on every SORT_EVERY-th frame only)
+            pb = None
+            if f % SORT_EVERY == 0 or f == warm_frames:
+                with torch.no_grad():
+                    pb = psnr(render(params.activated(), test_cam, bg)["images_pred"], gts_f[-1])
             for _ in range(ITERS_PER_FRAME):
                 ref.step()
                 if timed:
@@ -460,7 +467,9 @@ def main():
             with torch.no_grad():
                 pa = psnr(render(params.activated(), test_cam, bg)["images_pred"], gts_f[-1])
             if timed:
-                psnr_b.append(pb); psnr_a.append(pa)
+                psnr_a.append(pa)
+                if pb is not None:
+                    psnr_b.append(pb); psnr_a_sampled.append(pa)
             cur = {k: v.detach().clone() for k, v in params.leaves.items()}          # convert2stream: next frame starts from here
             return ref
 
@@ -488,9 +497,11 @@ def main():
             stages, r_sum, calls = _cabi.profile_read(reset=True)
             stages_timed = stages
             _cabi.profile_enable(False)
-        pb = [float(x) for x in psnr_b]; pa = [float(x) for x in psnr_a]
-        out_extra["psnr"] = {"camera": "held-out view (never trained on), evaluated against each frame's target before / after its %d iterations" % ITERS_PER_FRAME,
-                             "before": sum(pb) / len(pb), "after": sum(pa) / len(pa), "first_frame": [pb[0], pa[0]], "last_frame": [pb[-1], pa[-1]],
+        pb = [float(x) for x in psnr_b]; pa = [float(x) for x in psnr_a]; pas = [float(x) for x in psnr_a_sampled]
+        out_extra["psnr"] = {"camera": "held-out view (never trained on), evaluated against each frame's target after its %d iterations "
+                                       "(every frame) and before them (first frame and every %dth)" % (ITERS_PER_FRAME, SORT_EVERY),
+                             "before": sum(pb) / len(pb), "after": sum(pa) / len(pa), "after_on_the_sampled_frames": sum(pas) / len(pas),
+                             "first_frame": [pb[0], pas[0]], "last_sampled_frame": [pb[-1], pas[-1]],
                              "frames": frames, "refine_steps_between": ITERS_PER_FRAME}
         gauss_views = gv
         if ref is not None and ref.densify_log:
