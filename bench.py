@@ -11,7 +11,7 @@ N > 1) it reads RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* as usual.
 
 Configurations (BASELINE.json `configs`; every scene is the synthetic "sear_steak-like" stand-in):
   cfg3 (default, the headline)  200k Gaussians, 10 train cams @1352x1014; one step = ONE view per rank: activations + forward
-        (coord, depth, normal on) + L1 + backward + Adam -- one library call per rank (igs_refine_step, 6 launches); for N > 1 the
+        (coord, depth, normal on) + L1 + backward + Adam -- one library call per rank (igs_refine_step, 5 launches); for N > 1 the
         call ends in the gradient, the ranks exchange it over RCCL and apply the identical Adam step.
   cfg2  forward-only render of the same scene through the drop-in entry point (one host wait per frame, as the reference);
         one step = one rendered view per rank.

@@ -34,7 +34,7 @@ class RefineStepArgs(C.Structure):
                 ("loss_scratch", C.c_void_p),
                 ("out_images", C.c_void_p), ("radii", C.c_void_p), ("dL_dmean2D", C.c_void_p), ("loss_out", C.c_void_p),
                 ("require_coord", C.c_int), ("require_depth", C.c_int), ("clamp_grads", C.c_float),
-                ("color_grad_out", C.c_void_p)]
+                ("color_grad_out", C.c_void_p), ("scratch_clean", C.c_int)]
 
 
 EXPORTS = ["igs_rast_version", "igs_rast_last_error", "igs_rast_forward", "igs_rast_backward_workspace_bytes",
@@ -42,7 +42,7 @@ EXPORTS = ["igs_rast_version", "igs_rast_last_error", "igs_rast_forward", "igs_r
            "igs_rast_profile_enable", "igs_rast_profile_read", "igs_adam_step", "igs_adam_step_groups", "igs_densify_stats", "igs_densify_remap", "igs_refine_step", "igs_refine_loss_scratch_bytes", "igs_ssim_l1_scratch_bytes", "igs_ssim_l1_loss_fwd_bwd", "igs_depth_normal_loss_fwd_bwd", "igs_l1_loss_fwd_bwd", "igs_activate_fwd", "igs_activate_bwd",
            "igs_sh_grad_from_view_colors", "igs_adam_sh_from_view_colors", "igs_rast_last_backward_instance", "igs_refine_step_args_size", "igs_rast_debug_poison_lds", "igs_adam_exchange_step"]
 
-VERSION = 2       # IGS_RAST_VERSION this binding was written against (include/igs_rast.h)
+VERSION = 3       # IGS_RAST_VERSION this binding was written against (include/igs_rast.h)
 
 STAGES = ["preprocess", "depth_sort", "scan", "emit", "tile_sort", "ranges", "blend_fwd", "memset", "blend_bwd", "geom_bwd"]
 

@@ -159,11 +159,14 @@ struct FwdExtra {
     float* zero_gacc = nullptr;         // ... backward accumulators / loss shards the preprocess kernel zero-fills on the side
     float* zero_loss = nullptr;
     float* zero_loss2 = nullptr;
+    bool scratch_clean = false;         // igs_refine_step_args::scratch_clean: the image buffer's binning counters are known clean
     bool skip_bwd_state = false;        // ... the loss is colour-only: blend_fwd need not store the geometry branches' backward state
 };
 // where the last slab-binned forward left its device-side validity words (refine step guards)
 struct LastFwd { const uint32_t* overflow = nullptr; const uint32_t* prefilter = nullptr; };
 static thread_local LastFwd g_last_fwd;
+// a slab-binned forward of this thread got as far as its binning kernel but not to its tile sort: some buffer's counters are not clean
+static thread_local bool g_counters_dirty = false;
 
 static int forward_impl(
     void* stream,
@@ -256,17 +259,23 @@ static int forward_impl(
         point_list = (uint32_t*)(bbase + KL.point_list);
         uint64_t* pairs = (uint64_t*)(bbase + KL.pairs);
         counters = (uint32_t*)(ibase + IL.counters);
-        HIP_TRY(zero_fill_async(s, tile_count, IL.zero_end - IL.tile_count), "zero tile counters");   // tile_count + stats + counters
+        // The tile sort leaves the fill cursors and the count shards zeroed behind it, so a buffer that was clean before a frame is clean
+        // after it: a caller that vouches for its buffer (igs_refine_step_args::scratch_clean) skips the zero-fill launch, unless
+        // something on this thread was cut short between a binning kernel and its tile sort (g_counters_dirty).
+        if (ex.scratch_clean && !g_counters_dirty) fp.zero_stats = stats;
+        else HIP_TRY(zero_fill_async(s, tile_count, IL.zero_end - IL.tile_count), "zero tile counters");   // tile_count + stats + counters
+        g_counters_dirty = true;
         prof_mark(s, ST_GAP);
         HIP_TRY(launch_preprocess_fwd(s, fp, rec, tiles, nullptr, nullptr, radii, counters, nullptr, 0, tile_count, pairs, slab_size),
                 "preprocess_fwd launch");
         DBG_SYNC("preprocess_fwd");
         prof_mark(s, ST_PREPROCESS);
-        HIP_TRY(launch_tile_sort(s, (uint32_t)Tn, tile_count, pairs, point_list, ranges, slab_size, stats, counters), "tile_sort launch");
+        HIP_TRY(launch_tile_sort(s, (uint32_t)Tn, tile_count, pairs, point_list, ranges, slab_size, stats, counters, (uint32_t)P), "tile_sort launch");
+        g_counters_dirty = false;
         DBG_SYNC("tile_sort");
         prof_mark(s, ST_TILE_SORT);
         slab_stats = stats;
-        g_last_fwd.overflow = stats + 1; g_last_fwd.prefilter = counters + 1;
+        g_last_fwd.overflow = stats + 1; g_last_fwd.prefilter = stats + 2;      // (the tile sort moved the flag there)
         slab_pending = true;
     } else {
         // ---------------- global radix binning (fallback for tiles denser than TILE_SORT_BIG) ----------------
@@ -346,7 +355,7 @@ static int forward_impl(
     ba.n_contrib = (uint32_t*)(ibase + IL.n_contrib);
     ba.accum_coord = (float*)(ibase + IL.accum_coord); ba.accum_depth = (float*)(ibase + IL.accum_depth);
     ba.normal_length = (float*)(ibase + IL.normal_length);
-    ba.stats_src = slab_stats; ba.flag_src = counters + 1; ba.host_dst = slab_pending ? g_slot.pinned_dev : nullptr;
+    ba.stats_src = slab_stats; ba.flag_src = slab_stats ? slab_stats + 2 : counters + 1; ba.host_dst = slab_pending ? g_slot.pinned_dev : nullptr;
     ba.tile_order = (uint32_t*)(ibase + IL.tile_order);          // built on the side for the backward (both binning paths)
     ba.skip_bwd_state = ex.skip_bwd_state ? 1 : 0;
     if (slab_pending) { g_host_seq = g_host_seq + 1 ? g_host_seq + 1 : 1; g_slot.pinned[3] = 0; }
@@ -704,6 +713,7 @@ extern "C" int igs_refine_step(const igs_refine_step_args* a)
         ex.defer_status = attempt == 0;            // second attempt: synchronous forward, which sorts out its scratch sizes itself
         ex.raw_activations = true;
         ex.skip_bwd_state = !dn;                   // (colour-only backward instance: see BlendFwdArgs)
+        ex.scratch_clean = a->scratch_clean != 0;
         const int R = forward_impl(a->stream, capture_alloc, &cg, capture_alloc, &cb, capture_alloc, &ci, a->P, a->D, a->M, a->background,
                                    a->width, a->height, xyz, shs, nullptr, opac, scal, 1.0f, rotn, nullptr, a->viewmatrix, a->projmatrix,
                                    a->cam_pos, a->tan_fovx, a->tan_fovy, 0.0f, 0, color, coord, mcoord, depth, mdepth, alpha, normal,

@@ -96,7 +96,7 @@ struct ImgLayout {
         accum_depth = o;   o += align_up(HW * 4, 256);
         normal_length = o; o += align_up(HW * 4, 256);
         tile_count = o;    o += align_up(T * 4, 256);      // slab binning: instances per tile (fill cursor)
-        stats = o;         o += 256;                       // ... [0] R, [1] largest tile that overflowed its slab (0 = none)
+        stats = o;         o += 256;                       // ... [0] R, [1] largest tile that overflowed its slab (0 = none), [2] prefilter flag
         counters = o;      o += (COUNTER_SHARDS + 1) * COUNTER_SHARD_STRIDE * 4;   // ... instance-count shards; these three are zeroed by one fill
         zero_end = o;
         tile_order = o;    o += align_up((T + 1) * 4, 256);  // tile ids, heaviest load class first, then [T] = "use it" (blend_fwd's workgroup 0)
@@ -111,6 +111,7 @@ struct FwdParams {
     float scale_modifier, tan_fovx, tan_fovy, fx, fy, kernel_size;
     int prefiltered;
     const float *view, *proj, *campos;      // device pointers (transposed 4x4 matrices, camera centre)
+    uint32_t* zero_stats = nullptr;     // slab binning on a buffer whose counters are known clean: workgroup 0 zeroes the four status words here
     int zero_gacc_stride = GACC_F;      // floats per accumulator row to zero (GACC_COMPACT_F when the colour-only backward will run)
     float* zero_gacc; float* zero_loss; float* zero_loss2;     // refine step: backward accumulators / loss shards to zero-fill on the side (NULL = no)
     int raw_activations;                    // refine step: opacities / scales / rotations are the raw optimiser leaves
@@ -122,8 +123,8 @@ hipError_t launch_preprocess_fwd(hipStream_t s, const FwdParams& p, float* rec, 
                                  uint32_t* ident, int* radii, uint32_t* counters, uint32_t* hist0, uint32_t per_block,
                                  uint32_t* tile_count, uint64_t* pairs, uint32_t slab);
 void sort_geometry(uint32_t n, uint32_t* nb, uint32_t* per);
-hipError_t launch_tile_sort(hipStream_t s, uint32_t T, const uint32_t* tile_count, const uint64_t* pairs, uint32_t* point_list,
-                            uint32_t* ranges, uint32_t slab, uint32_t* stats, const uint32_t* counters);
+hipError_t launch_tile_sort(hipStream_t s, uint32_t T, uint32_t* tile_count, const uint64_t* pairs, uint32_t* point_list,
+                            uint32_t* ranges, uint32_t slab, uint32_t* stats, uint32_t* counters, uint32_t P);
 hipError_t launch_compact_lists(hipStream_t s, uint32_t T, const uint32_t* ranges_in, const uint32_t* list_in, uint32_t* ranges_out,
                                 uint32_t* list_out, uint32_t out_capacity);
 hipError_t launch_mark_visible(hipStream_t s, int P, const float* means3D, const float* view, uint8_t* present);

@@ -52,6 +52,7 @@ preprocess_fwd_kernel(const PreArgs a, float* __restrict__ rec, uint32_t* __rest
     uint32_t my_tiles = 0;
     int rect_x0 = 0, rect_y0 = 0, rect_w = 1;
     uint32_t my_dkey = 0;
+    if (p.zero_stats && blockIdx.x == 0 && threadIdx.x < 4) p.zero_stats[threadIdx.x] = 0u;      // (nothing reads them before the tile sort)
     if (p.zero_gacc) {
         // refine step: this kernel is latency-bound and leaves the memory pipes idle -- zero-fill the backward's accumulator
         // line of this Gaussian (and the loss shards) here instead of in a 25 MB fill of its own

@@ -357,39 +357,51 @@ __device__ __forceinline__ void wave_bitonic_sort(uint64_t (&v)[E], uint32_t lan
     }
 }
 template <int E>
-__device__ __forceinline__ void wave_sort_tile(const uint64_t* __restrict__ src, uint32_t* __restrict__ dst, uint32_t n, uint32_t lane)
+__device__ __forceinline__ void wave_sort_tile(const uint64_t* __restrict__ src, uint32_t* __restrict__ dst, uint32_t n, uint32_t lane, uint32_t id_max)
 {
     uint64_t v[E];
 #pragma unroll
     for (int r = 0; r < E; r++) { const uint32_t i = lane * E + r; v[r] = i < n ? src[i] : ~0ull; }
     wave_bitonic_sort<E>(v, lane);
 #pragma unroll
-    for (int r = 0; r < E; r++) { const uint32_t i = lane * E + r; if (i < n) dst[i] = (uint32_t)v[r]; }
+    for (int r = 0; r < E; r++) { const uint32_t i = lane * E + r; if (i < n) dst[i] = min((uint32_t)v[r], id_max); }
 }
 
 // A workgroup of 4 waves owns 4 consecutive tiles.  Tiles of up to TILE_SORT_WAVE instances (nearly all of them) are sorted
 // by one wave each in registers; the few denser ones (up to TILE_SORT_SMALL) by the whole workgroup in LDS afterwards.
 // Tiles in (TILE_SORT_SMALL, slab] are left to tile_sort_big_kernel; tiles that overflowed their slab get an empty range and
 // report their size in stats[1] (the host then redoes the frame with larger slabs).
+// The binning counters CLEAN UP AFTER THEMSELVES: whichever kernel reads a tile's fill cursor last resets it (this one when
+// `clean_counts`, otherwise tile_sort_big_kernel), and workgroup 0 folds the instance-count shards into stats[0], the prefilter
+// flag into stats[2], and resets both -- an image buffer that was clean before a slab-binned forward is clean again after it, so a
+// caller that keeps its buffers (igs_refine_step, scratch_clean) needs no zero-fill launch per frame.  Every id written to the
+// sorted list is clamped to id_max = P - 1: whatever a caller's broken promise puts into the slabs, the blend kernels never gather
+// outside the record array.
 __global__ void __launch_bounds__(256)
-tile_sort_kernel(uint32_t T, const uint32_t* __restrict__ tile_count, const uint64_t* __restrict__ pairs,
+tile_sort_kernel(uint32_t T, uint32_t* __restrict__ tile_count, const uint64_t* __restrict__ pairs,
                  uint32_t* __restrict__ point_list, uint32_t* __restrict__ ranges, uint32_t slab, uint32_t* __restrict__ stats,
-                 const uint32_t* __restrict__ counters)
+                 uint32_t* __restrict__ counters, uint32_t id_max, int clean_counts)
 {
     __shared__ __attribute__((aligned(16))) uint64_t skeys[TILE_SORT_SMALL];        // 16 KB, phase 2 only
     const uint32_t tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     if (blockIdx.x == 0 && wid == 0 && counters) {
         // R = sum of the preprocess kernel's counter shards
         uint32_t v = counters[COUNTER_SHARD_STRIDE * (1 + lane)];
+        counters[COUNTER_SHARD_STRIDE * (1 + lane)] = 0u;
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-        if (lane == 0) stats[0] = v;
+        if (lane == 0) { stats[0] = v; stats[2] = counters[1]; counters[1] = 0u; }
     }
     const uint32_t t0 = blockIdx.x * 4;
     // the four counts of the workgroup, fetched once (lane q of every wave loads tile t0+q)
     const uint32_t my_cnt = (lane < 4 && t0 + lane < T) ? tile_count[t0 + lane] : 0u;
     const uint32_t cnt0 = (uint32_t)__shfl((int)my_cnt, 0, 64), cnt1 = (uint32_t)__shfl((int)my_cnt, 1, 64);
     const uint32_t cnt2 = (uint32_t)__shfl((int)my_cnt, 2, 64), cnt3 = (uint32_t)__shfl((int)my_cnt, 3, 64);
+    if (clean_counts) {
+        // all four waves hold the counts in registers before any of them resets the words
+        __syncthreads();
+        if (wid == 0 && lane < 4 && t0 + lane < T) tile_count[t0 + lane] = 0u;
+    }
     // ---- phase 1: one wave per tile
     {
         const uint32_t t = t0 + wid;
@@ -403,11 +415,11 @@ tile_sort_kernel(uint32_t T, const uint32_t* __restrict__ tile_count, const uint
                 const uint64_t* src = pairs + base;
                 uint32_t* dst = point_list + base;
                 if (n_true == 0) {}
-                else if (n_true <= 64) wave_sort_tile<1>(src, dst, n_true, lane);
-                else if (n_true <= 128) wave_sort_tile<2>(src, dst, n_true, lane);
-                else if (n_true <= 256) wave_sort_tile<4>(src, dst, n_true, lane);
-                else if (n_true <= 512) wave_sort_tile<8>(src, dst, n_true, lane);
-                else if (n_true <= 1024) wave_sort_tile<16>(src, dst, n_true, lane);
+                else if (n_true <= 64) wave_sort_tile<1>(src, dst, n_true, lane, id_max);
+                else if (n_true <= 128) wave_sort_tile<2>(src, dst, n_true, lane, id_max);
+                else if (n_true <= 256) wave_sort_tile<4>(src, dst, n_true, lane, id_max);
+                else if (n_true <= 512) wave_sort_tile<8>(src, dst, n_true, lane, id_max);
+                else if (n_true <= 1024) wave_sort_tile<16>(src, dst, n_true, lane, id_max);
             }
         }
     }
@@ -424,17 +436,20 @@ tile_sort_kernel(uint32_t T, const uint32_t* __restrict__ tile_count, const uint
         for (uint32_t i = tid; i < N; i += 256) skeys[i] = (i < n) ? pairs[base + i] : ~0ull;
         __syncthreads();
         BITONIC_SORT(skeys, N, tid, 256, __syncthreads())
-        for (uint32_t i = tid; i < n; i += 256) point_list[base + i] = (uint32_t)skeys[i];
+        for (uint32_t i = tid; i < n; i += 256) point_list[base + i] = min((uint32_t)skeys[i], id_max);
     }
 }
 
-// one workgroup per tile of (TILE_SORT_SMALL, TILE_SORT_BIG] instances (only launched when the slabs are that large)
+// one workgroup per tile of (TILE_SORT_SMALL, TILE_SORT_BIG] instances (only launched when the slabs are that large); the last reader
+// of the fill cursors in that case, so it is the one that resets them
 __global__ void __launch_bounds__(1024)
-tile_sort_big_kernel(const uint32_t* __restrict__ tile_count, const uint64_t* __restrict__ pairs, uint32_t* __restrict__ point_list,
-                     uint32_t* __restrict__ ranges, uint32_t slab)
+tile_sort_big_kernel(uint32_t* __restrict__ tile_count, const uint64_t* __restrict__ pairs, uint32_t* __restrict__ point_list,
+                     uint32_t* __restrict__ ranges, uint32_t slab, uint32_t id_max)
 {
     extern __shared__ __attribute__((aligned(16))) uint64_t bkeys[];
     const uint32_t t = blockIdx.x, n = tile_count[t];
+    __syncthreads();                                   // every thread has its copy of n
+    if (threadIdx.x == 0) tile_count[t] = 0u;
     if (n <= TILE_SORT_SMALL || n > slab || n > TILE_SORT_BIG) return;
     const size_t base = (size_t)t * slab;
     uint32_t N = 2;
@@ -442,21 +457,24 @@ tile_sort_big_kernel(const uint32_t* __restrict__ tile_count, const uint64_t* __
     for (uint32_t i = threadIdx.x; i < N; i += 1024) bkeys[i] = (i < n) ? pairs[base + i] : ~0ull;
     __syncthreads();
     BITONIC_SORT(bkeys, N, threadIdx.x, 1024, __syncthreads())
-    for (uint32_t i = threadIdx.x; i < n; i += 1024) point_list[base + i] = (uint32_t)bkeys[i];
+    for (uint32_t i = threadIdx.x; i < n; i += 1024) point_list[base + i] = min((uint32_t)bkeys[i], id_max);
     if (threadIdx.x == 0) { ranges[2 * t] = (uint32_t)base; ranges[2 * t + 1] = (uint32_t)(base + n); }
 }
 
-hipError_t launch_tile_sort(hipStream_t s, uint32_t T, const uint32_t* tile_count, const uint64_t* pairs, uint32_t* point_list,
-                            uint32_t* ranges, uint32_t slab, uint32_t* stats, const uint32_t* counters)
+hipError_t launch_tile_sort(hipStream_t s, uint32_t T, uint32_t* tile_count, const uint64_t* pairs, uint32_t* point_list,
+                            uint32_t* ranges, uint32_t slab, uint32_t* stats, uint32_t* counters, uint32_t P)
 {
-    hipLaunchKernelGGL(tile_sort_kernel, dim3((T + 3) / 4), dim3(256), 0, s, T, tile_count, pairs, point_list, ranges, slab, stats, counters);
-    if (slab > TILE_SORT_SMALL) {
+    const bool big = slab > TILE_SORT_SMALL;
+    const uint32_t id_max = P ? P - 1u : 0u;
+    hipLaunchKernelGGL(tile_sort_kernel, dim3((T + 3) / 4), dim3(256), 0, s, T, tile_count, pairs, point_list, ranges, slab, stats, counters,
+                       id_max, big ? 0 : 1);
+    if (big) {
         static bool attr_set = false;
         if (!attr_set) {
             (void)hipFuncSetAttribute((const void*)tile_sort_big_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, TILE_SORT_BIG * 8);
             attr_set = true;
         }
-        hipLaunchKernelGGL(tile_sort_big_kernel, dim3(T), dim3(1024), TILE_SORT_BIG * 8, s, tile_count, pairs, point_list, ranges, slab);
+        hipLaunchKernelGGL(tile_sort_big_kernel, dim3(T), dim3(1024), TILE_SORT_BIG * 8, s, tile_count, pairs, point_list, ranges, slab, id_max);
     }
     return hipGetLastError();
 }

@@ -55,7 +55,10 @@ class _Scratch:
     def _alloc(self, _user, nbytes):
         try:
             if self.tensor.numel() < int(nbytes):          # persistent scratch only grows (by 25 % to avoid churn)
-                self.tensor = torch.empty(int(nbytes * (1.25 if self.persistent else 1.0)), dtype=torch.uint8, device=self.device)
+                # persistent scratch is born zero-filled: the library leaves its binning counters zeroed after every frame, which
+                # lets igs_refine_step (scratch_clean) skip its per-frame zero-fill launch
+                self.tensor = (torch.zeros if self.persistent else torch.empty)(int(nbytes * (1.25 if self.persistent else 1.0)),
+                                                                                dtype=torch.uint8, device=self.device)
             return self.tensor.data_ptr()
         except Exception:  # noqa: BLE001  (an exception must not cross the C frame)
             return None

@@ -15,6 +15,7 @@ is five contiguous fused-kernel launches.  Views are sharded over ranks: at step
 every rank applies the same averaged gradient, so replicas stay identical without a broadcast.
 """
 import math
+import os
 
 import torch
 import torch.nn.functional as F
@@ -371,7 +372,7 @@ class Refiner:
 
     def _fused_step(self, cam, gt, grads_only=False, color_out=None):
         """Single-GPU step entirely inside the library: `igs_refine_step` (include/igs_rast.h) -- activations, render, L1,
-        backward and the Adam update in 6 launches; no gradient array is materialised."""
+        backward and the Adam update in 5 launches; no gradient array is materialised."""
         import ctypes as C
         p = self.params
         L = _cabi.lib()
@@ -416,6 +417,7 @@ class Refiner:
         a.require_coord, a.require_depth = rq, rq
         a.clamp_grads = 15.0 if getattr(self, "clamp", False) else 0.0
         a.color_grad_out = color_out.data_ptr() if color_out is not None else None
+        a.scratch_clean = 0 if os.environ.get("IGS_SCRATCH_CLEAN") == "0" else 1      # (RasterBuffers: zero-filled at allocation, touched by this library only)
         with torch.cuda.device(dev):
             nr = L.igs_refine_step(C.byref(a))
         _rast._check(nr, "igs_refine_step")

@@ -45,7 +45,7 @@
 extern "C" {
 #endif
 
-#define IGS_RAST_VERSION 2
+#define IGS_RAST_VERSION 3
 
 #define IGS_RAST_E_INVALID   (-1)   /* bad argument (NULL required pointer, negative size, ...) */
 #define IGS_RAST_E_HIP       (-2)   /* a HIP runtime call or kernel launch failed */
@@ -241,7 +241,7 @@ int igs_adam_step_groups(void* stream, int ngroups, const size_t* offset, const 
  * Everything is enqueued on `stream` without a host wait; the gradients never reach HBM (the per-Gaussian backward kernel
  * applies the update itself).  `param` / `exp_avg` / `exp_avg_sq` are flat fp32 buffers holding the five groups at the given
  * float offsets: xyz [P][3], rotation [P][4] (raw quaternion), shs [P][M][3], opacity [P] (logit), scale [P][3] (log).
- * Multi-GPU runs need the gradients for the exchange: with `grad_out` set the same 6 launches end in the flat gradient
+ * Multi-GPU runs need the gradients for the exchange: with `grad_out` set the same launches end in the flat gradient
  * instead of the update (then all-reduce it and call igs_adam_step_groups -- or, with `color_grad_out` set as well, gather the
  * per-view colour gradients, all-reduce only the 11 small-group floats, and let igs_adam_sh_from_view_colors update the SH
  * coefficients: the SH span of `grad_out` is then left untouched).
@@ -280,6 +280,10 @@ typedef struct igs_refine_step_args {
                                                  +-clamp_grads before they go on (diff_gaussian_rasterization_rade_clamp, 15); 0: off */
     float* color_grad_out;                    /* [P][3] or NULL: dL/d(colour) of this view per Gaussian (clamped channels and unseen Gaussians
                                                  zero) -- what the ranks of a multi-GPU step gather instead of all-reducing dL/dSH */
+    int scratch_clean;                        /* != 0: the caller vouches that the image buffer the callback hands out was zero-filled when
+                                                 it was allocated and has since been used by this library only (every slab-binned forward
+                                                 leaves the binning counters in it zeroed again): the per-frame zero-fill launch is skipped.
+                                                 0: no assumption (a fresh, uninitialised buffer is fine) */
 } igs_refine_step_args;
 int igs_refine_step(const igs_refine_step_args* args);
 size_t igs_refine_step_args_size(void);       /* sizeof(igs_refine_step_args) of the loaded library: bindings check it before the first call */

@@ -1536,3 +1536,50 @@ def test_drop_in_step_captured_in_a_graph(dev):
             A, B = grads[k].cpu().numpy(), want[i][1][k].cpu().numpy()
             r = rel(A, B)
             assert np.quantile(r, 0.99) < 5e-3 and np.median(r) < 1e-4, (i, k, np.quantile(r, 0.99), np.median(r))
+
+
+@pytest.mark.parametrize("poison", ["small_words", "huge_words"])
+def test_self_cleaning_binning_counters_survive_a_broken_promise(dev, poison):
+    """igs_refine_step with scratch_clean skips its per-frame zero-fill launch: the tile sort leaves the fill cursors and the count
+    shards zeroed behind it, workgroup 0 of the binning kernel zeroes the status words.  (a) Steps on a clean buffer equal the unfused
+    step (every fused test runs that way); (b) a caller that LIES -- the image buffer is overwritten with garbage between two
+    steps -- gets one wrong (or redone) frame but no fault: ids from the slabs are clamped to P - 1 before the blend kernels gather
+    with them, garbage cursors beyond the slab size take the ordinary overflow-redo path; and the frame AFTER it is right again,
+    because the poisoned frame's tile sort has cleaned up."""
+    from igs_amd.refine import GaussianParams, Refiner, render
+    from igs_amd.scenes import perturbed_copy
+    raw, cams, bg = cfg1_scene(P=3000, size=128)
+    cams = [cams[0].to(dev)]
+    bg = bg.to(dev)
+    gt_raw = {k: v.to(dev) for k, v in perturbed_copy(raw, sigma=0.03).items()}
+    with torch.no_grad():
+        gts = [render(activate(gt_raw), cams[0], bg)["images_pred"].clone()]
+    pa, pb = GaussianParams(raw, dev), GaussianParams(raw, dev)
+    ra = Refiner(pa, cams, gts, bg, loss="l1", native=True, fused=True)
+    rb = Refiner(pb, cams, gts, bg, loss="l1", native=True, fused=False)
+    ra.adam_fn = lambda: None            # gradients only: the parameters stay put, every step renders the same frame
+    rb.adam_fn = lambda: None
+    ra.step(view=0); rb.step(view=0)
+    want = {k: v.grad.clone() for k, v in pb.leaves.items()}
+
+    def check():
+        for k in pa.leaves:
+            r = rel(pa.leaves[k].grad.cpu().numpy(), want[k].cpu().numpy())
+            assert np.quantile(r, 0.999) < 2e-3 and np.median(r) < 1e-5, (poison, k, np.quantile(r, 0.999), np.median(r))
+    check()
+    img_scratch = ra._bufs.scratch[2].tensor
+    torch.cuda.synchronize()
+    if poison == "small_words":          # every 32-bit word = 3: cursors start at 3, the shards add 192 to R
+        img_scratch.view(torch.int32)[:] = 3
+    else:                                # cursors far beyond any slab: every tile "overflows"
+        img_scratch.fill_(0x7F)
+    pa.grad.zero_()
+    from igs_amd.rasterizer import RasterizerError
+    try:
+        ra.step(view=0)                  # the poisoned frame: a wrong frame, a redone frame or an error code -- anything but a fault
+    except RasterizerError:              # (word 1 of the count shards is the "prefiltered point was culled" flag: garbage there is reported)
+        pass
+    torch.cuda.synchronize()
+    pa.grad.zero_()
+    ra.step(view=0)                      # ... and the buffer is clean again
+    check()

@@ -20,7 +20,7 @@ def test_cabi_library_exports_every_declared_symbol():
     assert {"igs_rast_forward", "igs_rast_backward", "igs_rast_mark_visible", "igs_rast_backward_workspace_bytes"} <= names
     for n in sorted(names):
         assert hasattr(L, n), "libigs_rast.so does not export %s" % n
-    assert L.igs_rast_version() == _cabi.VERSION == 2
+    assert L.igs_rast_version() == _cabi.VERSION == 3
     assert L.igs_refine_step_args_size() > 0
     assert L.igs_rast_backward_workspace_bytes(1000) >= 1000 * 25 * 4
     assert set(_cabi.EXPORTS) <= names | {"igs_rast_last_error", "igs_rast_version"}
