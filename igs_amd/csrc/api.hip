@@ -167,6 +167,9 @@ struct LastFwd { const uint32_t* overflow = nullptr; const uint32_t* prefilter =
 static thread_local LastFwd g_last_fwd;
 // a slab-binned forward of this thread got as far as its binning kernel but not to its tile sort: some buffer's counters are not clean
 static thread_local bool g_counters_dirty = false;
+// one-shot promise for the NEXT forward of this thread (igs_rast_hint_scratch_clean)
+static thread_local bool g_hint_clean = false;
+extern "C" void igs_rast_hint_scratch_clean(int on) { g_hint_clean = on != 0; }
 
 static int forward_impl(
     void* stream,
@@ -408,11 +411,12 @@ extern "C" int igs_rast_forward(
     prof_new_frame();
     const char* e = getenv("IGS_BINNING");                    // "radix" forces the global-sort path (tests)
     const bool radix = e && strcmp(e, "radix") == 0;
+    FwdExtra ex0; ex0.scratch_clean = g_hint_clean; g_hint_clean = false;
     return forward_impl(stream, geometry_buffer, geometry_user, binning_buffer, binning_user, image_buffer, image_user, P, D, M,
                         background, width, height, means3D, shs, colors_precomp, opacities, scales, scale_modifier, rotations,
                         cov3D_precomp, viewmatrix, projmatrix, cam_pos, tan_fovx, tan_fovy, kernel_size, prefiltered, out_color,
                         out_coord, out_mcoord, out_depth, out_mdepth, out_alpha, out_normal, radii, require_coord, require_depth,
-                        debug, radix, 0, FwdExtra());
+                        debug, radix, 0, ex0);
 }
 
 // Asynchronous variant for callers that keep enqueueing work (the native refine step): identical to igs_rast_forward but
@@ -436,7 +440,7 @@ extern "C" int igs_rast_forward_async(
     // the status slot is single: a second frame must not be started before the first one's count has been collected
     if (g_pending.active) return fail(IGS_RAST_E_INVALID, "igs_rast_forward_async: the previous asynchronous forward has not been finished (igs_rast_forward_finish)");
     prof_new_frame();
-    FwdExtra ex; ex.defer_status = true;
+    FwdExtra ex; ex.defer_status = true; ex.scratch_clean = g_hint_clean; g_hint_clean = false;
     const int rc = forward_impl(stream, geometry_buffer, geometry_user, binning_buffer, binning_user, image_buffer, image_user, P, D, M,
                                 background, width, height, means3D, shs, colors_precomp, opacities, scales, scale_modifier, rotations,
                                 cov3D_precomp, viewmatrix, projmatrix, cam_pos, tan_fovx, tan_fovy, kernel_size, prefiltered, out_color,
@@ -483,7 +487,7 @@ extern "C" int igs_rast_forward_nowait(
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= IGS_MAX_DEVICES || !g_slots.slot[dev].pinned)
         return fail(IGS_RAST_E_INVALID, "igs_rast_forward_nowait: no status slot on this thread and device yet (run one igs_rast_forward first: pinned memory cannot be allocated during capture)");
     prof_new_frame();
-    FwdExtra ex; ex.defer_status = true; ex.no_latch = true;
+    FwdExtra ex; ex.defer_status = true; ex.no_latch = true; ex.scratch_clean = g_hint_clean; g_hint_clean = false;
     return forward_impl(stream, geometry_buffer, geometry_user, binning_buffer, binning_user, image_buffer, image_user, P, D, M,
                         background, width, height, means3D, shs, colors_precomp, opacities, scales, scale_modifier, rotations,
                         cov3D_precomp, viewmatrix, projmatrix, cam_pos, tan_fovx, tan_fovy, kernel_size, prefiltered, out_color,

@@ -12,6 +12,7 @@ torch is used for device memory and the current stream only; all arithmetic runs
 There is no CPU path: calling these functions without the HIP library / a GPU raises.
 """
 import ctypes as C
+import os
 from typing import NamedTuple
 
 import torch
@@ -176,6 +177,8 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
             fwd = L.igs_rast_forward_async if defer else L.igs_rast_forward
             if torch.cuda.is_current_stream_capturing():
                 fwd = L.igs_rast_forward_nowait
+            if buffers is not None and os.environ.get("IGS_SCRATCH_CLEAN") != "0":
+                L.igs_rast_hint_scratch_clean(1)          # RasterBuffers scratch: zero-filled at allocation, used by this library only
             rendered = fwd(
                 stream, geom.cb, None, binning.cb, None, img.cb, None, P, int(degree), M, _ptr(bg_c), W, H,
                 _ptr(means3D_c), _ptr(sh_c), _ptr(colors_c), _ptr(opacity_c), _ptr(scales_c), float(scale_modifier),

@@ -135,6 +135,12 @@ int igs_rast_forward_nowait(
     float* out_normal, int* radii, int require_coord, int require_depth, int debug);
 int igs_rast_last_status(int* num_rendered, unsigned* overflow, unsigned* prefilter_flag);
 
+/* One-shot promise for the NEXT igs_rast_forward / _async / _nowait of the calling thread: the image buffer its callback will hand out
+ * was zero-filled when it was allocated and has been used by this library only since.  Every slab-binned forward leaves the binning
+ * counters in the image buffer zeroed behind it, so such a forward needs no zero-fill launch (igs_refine_step_args::scratch_clean is
+ * the same promise for the fused step).  A broken promise costs a wrong or redone frame or an error code, never a fault. */
+void igs_rast_hint_scratch_clean(int on);
+
 /* Binning scratch tuning (no reference counterpart).  The default path gives every 16x16 tile a slab of `slots_per_tile`
  * instance slots (12 bytes each) in binningBuffer; a frame in which some tile needs more is redone automatically with larger
  * slabs (and, beyond 16384 per tile, with the global radix sort), and the size then sticks for the calling thread.  Setting the
