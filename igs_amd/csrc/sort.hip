@@ -322,6 +322,40 @@ hipError_t launch_tile_ranges(hipStream_t s, uint32_t R, const uint32_t* tile_ke
 // Bitonic sort of 64*E keys held in registers by one wave: element i = lane*E + r lives in v[r] of `lane`.  Strides below E
 // are register-to-register, strides of E and more are lane exchanges (partner lane = lane ^ stride/E): no LDS, no barriers,
 // every loop bound a compile-time constant.
+// value of lane (lane ^ LM) without a trip through the LDS crossbar (ds_bpermute: ~6 LDS cycles per CU each, and a wave sorting 512-1024
+// keys makes 336-672 of them): quad permutes for LM 1 / 2, a row rotate for 8, two row shifts and a select for 4, and the gfx950 row
+// swaps for 16 / 32 (v_permlane16_swap / v_permlane32_swap leave each half of the exchange in one of their two results)
+#ifndef SORT_DPP
+#define SORT_DPP 1
+#endif
+template <int LM>
+__device__ __forceinline__ uint32_t lane_xor32(uint32_t x, uint32_t lane)
+{
+#if SORT_DPP
+    if constexpr (LM == 1) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0xB1, 0xF, 0xF, false);
+    else if constexpr (LM == 2) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x4E, 0xF, 0xF, false);
+    else if constexpr (LM == 8) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x128, 0xF, 0xF, false);      // row_ror:8
+    else if constexpr (LM == 4) {
+        const uint32_t up = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x104, 0xF, 0xF, false);                 // row_shl:4 -> lane + 4
+        const uint32_t dn = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xF, 0xF, false);                 // row_shr:4 -> lane - 4
+        return (lane & 4u) ? dn : up;
+    } else if constexpr (LM == 16) {
+        const auto r = __builtin_amdgcn_permlane16_swap(x, x, false, false);
+        return (lane & 16u) ? r[0] : r[1];
+    } else {
+        const auto r = __builtin_amdgcn_permlane32_swap(x, x, false, false);
+        return (lane & 32u) ? r[0] : r[1];
+    }
+#else
+    return (uint32_t)__shfl_xor((int)x, LM, 64);
+#endif
+}
+template <int LM>
+__device__ __forceinline__ uint64_t lane_xor64(uint64_t v, uint32_t lane)
+{
+    return (uint64_t)lane_xor32<LM>((uint32_t)v, lane) | ((uint64_t)lane_xor32<LM>((uint32_t)(v >> 32), lane) << 32);
+}
+
 template <int E>
 __device__ __forceinline__ void wave_bitonic_sort(uint64_t (&v)[E], uint32_t lane)
 {
@@ -335,7 +369,8 @@ __device__ __forceinline__ void wave_bitonic_sort(uint64_t (&v)[E], uint32_t lan
 #pragma unroll
                 for (int r = 0; r < E; r++) {
                     const uint32_t i = lane * E + r;
-                    const uint64_t o = __shfl_xor((unsigned long long)v[r], lm, 64);
+                    const uint64_t o = lm == 1 ? lane_xor64<1>(v[r], lane) : lm == 2 ? lane_xor64<2>(v[r], lane) : lm == 4 ? lane_xor64<4>(v[r], lane)
+                                     : lm == 8 ? lane_xor64<8>(v[r], lane) : lm == 16 ? lane_xor64<16>(v[r], lane) : lane_xor64<32>(v[r], lane);
                     const bool up = (i & (uint32_t)k) == 0;
                     const uint64_t lo = v[r] < o ? v[r] : o, hi = v[r] < o ? o : v[r];
                     v[r] = (lower == up) ? lo : hi;
@@ -380,9 +415,8 @@ __device__ __forceinline__ void wave_sort_tile(const uint64_t* __restrict__ src,
 __global__ void __launch_bounds__(256)
 tile_sort_kernel(uint32_t T, uint32_t* __restrict__ tile_count, const uint64_t* __restrict__ pairs,
                  uint32_t* __restrict__ point_list, uint32_t* __restrict__ ranges, uint32_t slab, uint32_t* __restrict__ stats,
-                 uint32_t* __restrict__ counters, uint32_t id_max, int clean_counts)
+                 uint32_t* __restrict__ counters, uint32_t id_max, int clean_counts, uint32_t wave_max)
 {
-    __shared__ __attribute__((aligned(16))) uint64_t skeys[TILE_SORT_SMALL];        // 16 KB, phase 2 only
     const uint32_t tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     if (blockIdx.x == 0 && wid == 0 && counters) {
         // R = sum of the preprocess kernel's counter shards
@@ -414,7 +448,7 @@ tile_sort_kernel(uint32_t T, uint32_t* __restrict__ tile_count, const uint64_t* 
                 if (lane == 0 && n_true <= TILE_SORT_SMALL) { ranges[2 * t] = (uint32_t)base; ranges[2 * t + 1] = (uint32_t)(base + n_true); }
                 const uint64_t* src = pairs + base;
                 uint32_t* dst = point_list + base;
-                if (n_true == 0) {}
+                if (n_true == 0 || n_true > wave_max) {}          // (denser tiles: tile_sort_mid_kernel / tile_sort_big_kernel)
                 else if (n_true <= 64) wave_sort_tile<1>(src, dst, n_true, lane, id_max);
                 else if (n_true <= 128) wave_sort_tile<2>(src, dst, n_true, lane, id_max);
                 else if (n_true <= 256) wave_sort_tile<4>(src, dst, n_true, lane, id_max);
@@ -423,21 +457,31 @@ tile_sort_kernel(uint32_t T, uint32_t* __restrict__ tile_count, const uint64_t* 
             }
         }
     }
-    // ---- phase 2: the workgroup sorts its tiles of (TILE_SORT_WAVE, TILE_SORT_SMALL] instances one after the other
-    for (uint32_t q = 0; q < 4; q++) {
-        const uint32_t t = t0 + q;
-        if (t >= T) break;
-        const uint32_t n = q == 0 ? cnt0 : q == 1 ? cnt1 : q == 2 ? cnt2 : cnt3;      // block-uniform
-        if (n <= TILE_SORT_WAVE || n > TILE_SORT_SMALL || n > slab) continue;
-        const size_t base = (size_t)t * slab;
-        __syncthreads();                                                   // previous tile done with skeys
-        uint32_t N = 2;
-        while (N < n) N <<= 1;
-        for (uint32_t i = tid; i < N; i += 256) skeys[i] = (i < n) ? pairs[base + i] : ~0ull;
-        __syncthreads();
-        BITONIC_SORT(skeys, N, tid, 256, __syncthreads())
-        for (uint32_t i = tid; i < n; i += 256) point_list[base + i] = min((uint32_t)skeys[i], id_max);
+}
+
+// one workgroup per tile of (wave_max, TILE_SORT_SMALL] instances, in a launch of its own (only when the slabs are larger than
+// TILE_SORT_WAVE_ALONE): four waves and 16 KB of LDS bring a 512-key tile home in ~45 barrier-separated stages of ONE compare-exchange
+// per thread, where a single wave walks 2 400-5 300 dependent instructions for 512-1024 keys in registers.  (As a second phase of
+// tile_sort_kernel the tiles above 1024 were sorted one after the other by the workgroup that owned them, behind its four register
+// sorts: on the dense diagnostic scene -- mean 430 instances per tile -- that tail and the long single-wave sorts made 85 us.)
+__global__ void __launch_bounds__(256)
+tile_sort_mid_kernel(uint32_t* __restrict__ tile_count, const uint64_t* __restrict__ pairs, uint32_t* __restrict__ point_list,
+                     uint32_t slab, uint32_t id_max, int clean_counts, uint32_t wave_max)
+{
+    __shared__ __attribute__((aligned(16))) uint64_t skeys[TILE_SORT_SMALL];        // 16 KB
+    const uint32_t t = blockIdx.x, tid = threadIdx.x, n = tile_count[t];
+    if (clean_counts) {
+        __syncthreads();                               // every thread has its copy of n
+        if (tid == 0) tile_count[t] = 0u;
     }
+    if (n <= wave_max || n > TILE_SORT_SMALL || n > slab) return;           // (the range was written by tile_sort_kernel)
+    const size_t base = (size_t)t * slab;
+    uint32_t N = 2;
+    while (N < n) N <<= 1;
+    for (uint32_t i = tid; i < N; i += 256) skeys[i] = (i < n) ? pairs[base + i] : ~0ull;
+    __syncthreads();
+    BITONIC_SORT(skeys, N, tid, 256, __syncthreads())
+    for (uint32_t i = tid; i < n; i += 256) point_list[base + i] = min((uint32_t)skeys[i], id_max);
 }
 
 // one workgroup per tile of (TILE_SORT_SMALL, TILE_SORT_BIG] instances (only launched when the slabs are that large); the last reader
@@ -449,7 +493,7 @@ tile_sort_big_kernel(uint32_t* __restrict__ tile_count, const uint64_t* __restri
     extern __shared__ __attribute__((aligned(16))) uint64_t bkeys[];
     const uint32_t t = blockIdx.x, n = tile_count[t];
     __syncthreads();                                   // every thread has its copy of n
-    if (threadIdx.x == 0) tile_count[t] = 0u;
+    if (threadIdx.x == 0) tile_count[t] = 0u;          // (the last reader of the fill cursors whenever it is launched)
     if (n <= TILE_SORT_SMALL || n > slab || n > TILE_SORT_BIG) return;
     const size_t base = (size_t)t * slab;
     uint32_t N = 2;
@@ -461,13 +505,22 @@ tile_sort_big_kernel(uint32_t* __restrict__ tile_count, const uint64_t* __restri
     if (threadIdx.x == 0) { ranges[2 * t] = (uint32_t)base; ranges[2 * t + 1] = (uint32_t)(base + n); }
 }
 
+#ifndef TILE_SORT_WAVE_ALONE
+#define TILE_SORT_WAVE_ALONE 1024         // slabs up to this size: every tile by one wave in registers, no second launch
+#endif
+#ifndef TILE_SORT_WAVE_WITH_MID
+#define TILE_SORT_WAVE_WITH_MID 1024      // ... larger slabs: the register sort keeps the tiles up to this size, the LDS kernel takes the rest
+#endif                                    // (256 / 512 measured: no better on the dense scene, and a second launch for nothing on the bench scene's 1024-slot slabs)
 hipError_t launch_tile_sort(hipStream_t s, uint32_t T, uint32_t* tile_count, const uint64_t* pairs, uint32_t* point_list,
                             uint32_t* ranges, uint32_t slab, uint32_t* stats, uint32_t* counters, uint32_t P)
 {
-    const bool big = slab > TILE_SORT_SMALL;
+    const bool mid = slab > TILE_SORT_WAVE_ALONE, big = slab > TILE_SORT_SMALL;
     const uint32_t id_max = P ? P - 1u : 0u;
+    const uint32_t wave_max = mid ? TILE_SORT_WAVE_WITH_MID : TILE_SORT_WAVE;
+    // whichever launch reads the fill cursors last resets them
     hipLaunchKernelGGL(tile_sort_kernel, dim3((T + 3) / 4), dim3(256), 0, s, T, tile_count, pairs, point_list, ranges, slab, stats, counters,
-                       id_max, big ? 0 : 1);
+                       id_max, mid ? 0 : 1, wave_max);
+    if (mid) hipLaunchKernelGGL(tile_sort_mid_kernel, dim3(T), dim3(256), 0, s, tile_count, pairs, point_list, slab, id_max, big ? 0 : 1, wave_max);
     if (big) {
         static bool attr_set = false;
         if (!attr_set) {
