@@ -12,7 +12,7 @@
 #include <vector>
 #include <algorithm>
 
-enum { OP_FMA = 0, OP_EXP = 1, OP_RCP = 2, OP_MIX = 3, OP_LDSB128 = 4, OP_DPP = 5, OP_SWAP32 = 6, OP_SWAP16 = 7, OP_CNDMASK = 8, OP_BPERM = 9, OP_PKFMA = 10, OP_PKADD = 11, OP_MUL = 12 };
+enum { OP_FMA = 0, OP_EXP = 1, OP_RCP = 2, OP_MIX = 3, OP_LDSB128 = 4, OP_DPP = 5, OP_SWAP32 = 6, OP_SWAP16 = 7, OP_CNDMASK = 8, OP_BPERM = 9, OP_PKFMA = 10, OP_PKADD = 11, OP_MUL = 12, OP_FMA_LO32 = 13, OP_FMA_LO16 = 14, OP_FMA_HI32 = 15, OP_FMA_ROWS02 = 16 };
 
 template <int OP>
 __global__ void __launch_bounds__(256) k(float* out, int iters, unsigned long long* cyc, float seed)
@@ -25,11 +25,16 @@ __global__ void __launch_bounds__(256) k(float* out, int iters, unsigned long lo
     float4 q = make_float4(0, 0, 0, 0);
     typedef float f2 __attribute__((ext_vector_type(2)));
     f2 p0 = {a0, a1}, p1 = {a2, a3}, p2 = {a4, a5}, p3 = {a6, a7}, pb = {b, b}, pc = {c, c};
+    // partial EXEC masks: does the SIMD skip a 32-lane half (or a 16-lane row) of a wave64 instruction in which no lane is active?
+    constexpr bool MASKED = OP >= OP_FMA_LO32;
+    constexpr unsigned long long EXECMASK = OP == OP_FMA_LO32 ? 0x00000000FFFFFFFFull : OP == OP_FMA_LO16 ? 0x000000000000FFFFull
+                                            : OP == OP_FMA_HI32 ? 0xFFFFFFFF00000000ull : 0x0000FFFF0000FFFFull;
+    if (MASKED) asm volatile("s_mov_b64 exec, %0" :: "s"(EXECMASK));
     const unsigned long long t0 = __builtin_amdgcn_s_memtime();
     for (int i = 0; i < iters; i++) {
 #pragma unroll
         for (int u = 0; u < 8; u++) {
-            if (OP == OP_FMA) {
+            if (OP == OP_FMA || MASKED) {
                 asm volatile("v_fma_f32 %0, %0, %8, %9\n v_fma_f32 %1, %1, %8, %9\n v_fma_f32 %2, %2, %8, %9\n v_fma_f32 %3, %3, %8, %9\n"
                              "v_fma_f32 %4, %4, %8, %9\n v_fma_f32 %5, %5, %8, %9\n v_fma_f32 %6, %6, %8, %9\n v_fma_f32 %7, %7, %8, %9\n"
                              : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c));
@@ -90,6 +95,7 @@ __global__ void __launch_bounds__(256) k(float* out, int iters, unsigned long lo
         }
     }
     const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    if (MASKED) asm volatile("s_mov_b64 exec, -1");
     const float s = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + q.x + q.y + q.z + q.w + p0.x + p0.y + p1.x + p1.y + p2.x + p2.y + p3.x + p3.y;
     if (s == 12345.678f) out[0] = s;
     if ((threadIdx.x & 63) == 0) cyc[blockIdx.x * 4 + (threadIdx.x >> 6)] = t1 - t0;
@@ -123,6 +129,10 @@ int main()
 {
     printf("wave64 VALU issue cost on gfx950 (W = waves per SIMD; 'cyc/inst/SIMD' from wall time at 2.4 GHz, i.e. an upper bound if the clock is lower)\n");
     run<OP_FMA>("v_fma_f32 (8 independent chains)", 64);
+    run<OP_FMA_LO32>("v_fma_f32, EXEC = lanes 0-31", 64);
+    run<OP_FMA_HI32>("v_fma_f32, EXEC = lanes 32-63", 64);
+    run<OP_FMA_LO16>("v_fma_f32, EXEC = lanes 0-15", 64);
+    run<OP_FMA_ROWS02>("v_fma_f32, EXEC = lanes 0-15, 32-47", 64);
     run<OP_EXP>("v_exp_f32", 64);
     run<OP_RCP>("v_rcp_f32", 64);
     run<OP_MIX>("1 v_exp_f32 + 7 v_fma_f32", 64);
