@@ -31,6 +31,7 @@ static thread_local HostSlots g_slots;
 static thread_local HostSlot g_slot;                // the current device's slot (a copy of the table entry)
 static thread_local hipStream_t g_status_stream = nullptr;
 static thread_local uint32_t g_host_seq = 0;      // sequence number of the last status the blend kernel was asked to post
+static thread_local uint32_t g_nowait_seq = 0;    // ... and the one baked into the last igs_rast_forward_nowait (a capture): what igs_rast_last_status expects
 static int ensure_slot()
 {
     int dev = 0;
@@ -363,6 +364,7 @@ static int forward_impl(
     ba.skip_bwd_state = ex.skip_bwd_state ? 1 : 0;
     if (slab_pending) { g_host_seq = g_host_seq + 1 ? g_host_seq + 1 : 1; g_slot.pinned[3] = 0; }
     ba.host_seq = g_host_seq;
+    if (slab_pending && ex.no_latch) g_nowait_seq = g_host_seq;
     g_status_stream = s;
     HIP_TRY(launch_blend_fwd(s, ba, require_coord != 0, require_depth != 0), "blend_fwd launch");
     DBG_SYNC("blend_fwd");
@@ -407,11 +409,12 @@ extern "C" int igs_rast_forward(
     float* out_color, float* out_coord, float* out_mcoord, float* out_depth, float* out_mdepth, float* out_alpha,
     float* out_normal, int* radii, int require_coord, int require_depth, int debug)
 {
+    const bool hint_clean = g_hint_clean; g_hint_clean = false;      // one-shot promise: consumed by THIS call, even a refused one
     if (g_pending.active) return fail(IGS_RAST_E_INVALID, "igs_rast_forward: an asynchronous forward is pending on this thread; call igs_rast_forward_finish() first");
     prof_new_frame();
     const char* e = getenv("IGS_BINNING");                    // "radix" forces the global-sort path (tests)
     const bool radix = e && strcmp(e, "radix") == 0;
-    FwdExtra ex0; ex0.scratch_clean = g_hint_clean; g_hint_clean = false;
+    FwdExtra ex0; ex0.scratch_clean = hint_clean;
     return forward_impl(stream, geometry_buffer, geometry_user, binning_buffer, binning_user, image_buffer, image_user, P, D, M,
                         background, width, height, means3D, shs, colors_precomp, opacities, scales, scale_modifier, rotations,
                         cov3D_precomp, viewmatrix, projmatrix, cam_pos, tan_fovx, tan_fovy, kernel_size, prefiltered, out_color,
@@ -438,9 +441,10 @@ extern "C" int igs_rast_forward_async(
     float* out_normal, int* radii, int require_coord, int require_depth, int debug)
 {
     // the status slot is single: a second frame must not be started before the first one's count has been collected
+    const bool hint_clean = g_hint_clean; g_hint_clean = false;      // (consumed by this call, even a refused one)
     if (g_pending.active) return fail(IGS_RAST_E_INVALID, "igs_rast_forward_async: the previous asynchronous forward has not been finished (igs_rast_forward_finish)");
     prof_new_frame();
-    FwdExtra ex; ex.defer_status = true; ex.scratch_clean = g_hint_clean; g_hint_clean = false;
+    FwdExtra ex; ex.defer_status = true; ex.scratch_clean = hint_clean;
     const int rc = forward_impl(stream, geometry_buffer, geometry_user, binning_buffer, binning_user, image_buffer, image_user, P, D, M,
                                 background, width, height, means3D, shs, colors_precomp, opacities, scales, scale_modifier, rotations,
                                 cov3D_precomp, viewmatrix, projmatrix, cam_pos, tan_fovx, tan_fovy, kernel_size, prefiltered, out_color,
@@ -481,13 +485,14 @@ extern "C" int igs_rast_forward_nowait(
     float* out_color, float* out_coord, float* out_mcoord, float* out_depth, float* out_mdepth, float* out_alpha,
     float* out_normal, int* radii, int require_coord, int require_depth, int debug)
 {
+    const bool hint_clean = g_hint_clean; g_hint_clean = false;      // (consumed by this call, even a refused one)
     if (g_pending.active) return fail(IGS_RAST_E_INVALID, "igs_rast_forward_nowait: an asynchronous forward is pending on this thread; call igs_rast_forward_finish() first");
     if (debug) return fail(IGS_RAST_E_INVALID, "igs_rast_forward_nowait: debug (a synchronisation after every launch) cannot be captured");
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= IGS_MAX_DEVICES || !g_slots.slot[dev].pinned)
         return fail(IGS_RAST_E_INVALID, "igs_rast_forward_nowait: no status slot on this thread and device yet (run one igs_rast_forward first: pinned memory cannot be allocated during capture)");
     prof_new_frame();
-    FwdExtra ex; ex.defer_status = true; ex.no_latch = true; ex.scratch_clean = g_hint_clean; g_hint_clean = false;
+    FwdExtra ex; ex.defer_status = true; ex.no_latch = true; ex.scratch_clean = hint_clean;
     return forward_impl(stream, geometry_buffer, geometry_user, binning_buffer, binning_user, image_buffer, image_user, P, D, M,
                         background, width, height, means3D, shs, colors_precomp, opacities, scales, scale_modifier, rotations,
                         cov3D_precomp, viewmatrix, projmatrix, cam_pos, tan_fovx, tan_fovy, kernel_size, prefiltered, out_color,
@@ -503,6 +508,10 @@ extern "C" int igs_rast_last_status(int* num_rendered, unsigned* overflow, unsig
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= IGS_MAX_DEVICES || !g_slots.slot[dev].pinned)
         return fail(IGS_RAST_E_INVALID, "igs_rast_last_status: no forward has run on this thread and device");
     const uint32_t* p = g_slots.slot[dev].pinned;
+    // the sequence word is stored last by the kernel (release): if it is not the number baked into the last igs_rast_forward_nowait of this
+    // thread (the last capture), no replay of that capture has posted yet and the other three words still belong to an EARLIER (eager) frame
+    if (__atomic_load_n(&p[3], __ATOMIC_ACQUIRE) != (g_nowait_seq ? g_nowait_seq : g_host_seq))
+        return fail(IGS_RAST_E_RETRY, "igs_rast_last_status: the captured forward has not posted its status yet (replay the graph and synchronise the stream first)");
     const uint32_t R = __atomic_load_n(&p[0], __ATOMIC_ACQUIRE), ov = __atomic_load_n(&p[1], __ATOMIC_ACQUIRE);
     if (num_rendered) *num_rendered = R > 0x7FFFFFFFu ? 0x7FFFFFFF : (int)R;
     if (overflow) *overflow = ov;

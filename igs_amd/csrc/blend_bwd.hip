@@ -34,19 +34,19 @@
 template <int STRIDE_B, int R0, int N> struct ColWrite;
 template <int STRIDE_B, int R0> struct ColWrite<STRIDE_B, R0, 1> {
     static __device__ __forceinline__ void run(unsigned m0, const float* v) {
-        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tds_write_addtid_b32 %0 offset:%2" :: "v"(v[R0]), "s"(m0), "n"(R0 * STRIDE_B) : "memory");
+        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tds_write_addtid_b32 %0 offset:%2" :: "v"(v[R0]), "s"(m0), "n"(R0 * STRIDE_B) : "memory", "m0");
     }
 };
 template <int STRIDE_B, int R0> struct ColWrite<STRIDE_B, R0, 2> {
     static __device__ __forceinline__ void run(unsigned m0, const float* v) {
         asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tds_write_addtid_b32 %0 offset:%3\n\tds_write_addtid_b32 %1 offset:%4"
-                     :: "v"(v[R0]), "v"(v[R0 + 1]), "s"(m0), "n"(R0 * STRIDE_B), "n"((R0 + 1) * STRIDE_B) : "memory");
+                     :: "v"(v[R0]), "v"(v[R0 + 1]), "s"(m0), "n"(R0 * STRIDE_B), "n"((R0 + 1) * STRIDE_B) : "memory", "m0");
     }
 };
 template <int STRIDE_B, int R0> struct ColWrite<STRIDE_B, R0, 3> {
     static __device__ __forceinline__ void run(unsigned m0, const float* v) {
         asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tds_write_addtid_b32 %0 offset:%4\n\tds_write_addtid_b32 %1 offset:%5\n\tds_write_addtid_b32 %2 offset:%6"
-                     :: "v"(v[R0]), "v"(v[R0 + 1]), "v"(v[R0 + 2]), "s"(m0), "n"(R0 * STRIDE_B), "n"((R0 + 1) * STRIDE_B), "n"((R0 + 2) * STRIDE_B) : "memory");
+                     :: "v"(v[R0]), "v"(v[R0 + 1]), "v"(v[R0 + 2]), "s"(m0), "n"(R0 * STRIDE_B), "n"((R0 + 1) * STRIDE_B), "n"((R0 + 2) * STRIDE_B) : "memory", "m0");
     }
 };
 template <int STRIDE_B, int R0> struct ColWrite<STRIDE_B, R0, 4> {
@@ -54,7 +54,7 @@ template <int STRIDE_B, int R0> struct ColWrite<STRIDE_B, R0, 4> {
         asm volatile("s_mov_b32 m0, %4\n\ts_nop 0\n\tds_write_addtid_b32 %0 offset:%5\n\tds_write_addtid_b32 %1 offset:%6\n\tds_write_addtid_b32 %2 offset:%7\n\t"
                      "ds_write_addtid_b32 %3 offset:%8"
                      :: "v"(v[R0]), "v"(v[R0 + 1]), "v"(v[R0 + 2]), "v"(v[R0 + 3]), "s"(m0), "n"(R0 * STRIDE_B), "n"((R0 + 1) * STRIDE_B),
-                        "n"((R0 + 2) * STRIDE_B), "n"((R0 + 3) * STRIDE_B) : "memory");
+                        "n"((R0 + 2) * STRIDE_B), "n"((R0 + 3) * STRIDE_B) : "memory", "m0");
     }
 };
 template <int STRIDE_B, int R0> struct ColWrite<STRIDE_B, R0, 5> {
@@ -62,7 +62,7 @@ template <int STRIDE_B, int R0> struct ColWrite<STRIDE_B, R0, 5> {
         asm volatile("s_mov_b32 m0, %5\n\ts_nop 0\n\tds_write_addtid_b32 %0 offset:%6\n\tds_write_addtid_b32 %1 offset:%7\n\tds_write_addtid_b32 %2 offset:%8\n\t"
                      "ds_write_addtid_b32 %3 offset:%9\n\tds_write_addtid_b32 %4 offset:%10"
                      :: "v"(v[R0]), "v"(v[R0 + 1]), "v"(v[R0 + 2]), "v"(v[R0 + 3]), "v"(v[R0 + 4]), "s"(m0), "n"(R0 * STRIDE_B),
-                        "n"((R0 + 1) * STRIDE_B), "n"((R0 + 2) * STRIDE_B), "n"((R0 + 3) * STRIDE_B), "n"((R0 + 4) * STRIDE_B) : "memory");
+                        "n"((R0 + 1) * STRIDE_B), "n"((R0 + 2) * STRIDE_B), "n"((R0 + 3) * STRIDE_B), "n"((R0 + 4) * STRIDE_B) : "memory", "m0");
     }
 };
 template <int STRIDE_B, int R0, int N> struct ColWrite {          // N > 5: five now, the rest recursively
@@ -327,69 +327,6 @@ blend_bwd_kernel(const BlendBwdArgs a)
                 }
                 reduce_row(mv, R.gid(q2));
     };
-#ifndef BWD_PAIR
-#define BWD_PAIR 0             // MEASURED AND LEFT OFF (round 2, same-box A/B, parity suite green with it on): blend_bwd 80.0 -> 106.6 us.
-#endif                         // The held candidate costs 22-34 more VGPRs (82 / 94: 5-6 waves per SIMD instead of 8) and the two masked reductions
-                               // eat what the shared arithmetic saves.
-    // BWD_PAIR (colour-only instances; VERDICT r1 #4c): two depth-adjacent rows of a quad whose contributing pixels are disjoint are
-    // worked as ONE row -- every lane takes the parameters of the splat it belongs to, the per-pair arithmetic runs once, and only the
-    // reduction is done twice (with the other splat's lanes zeroed).  Disjoint footprints commute exactly, so the values are those of
-    // the unpaired kernel.  A candidate's {alpha, validity} must exist before the decision, so one candidate is always held.
-    struct Cand { float4 q0, q1; float dx, dy, G, alpha; bool valid; int j; };
-    auto front = [&](const int j, const int eidx) {
-        Cand c; c.j = j;
-        c.q0 = chunk[j * NQ + 0]; c.q1 = chunk[j * NQ + 1];
-        c.dx = c.q0.x - pixfx; c.dy = c.q0.y - pixfy;
-        const float power = gauss_power(c.q0.z, c.q0.w, c.q1.x, c.dx, c.dy);
-        c.G = __expf(power);
-        c.alpha = fminf(0.99f, c.q1.y * c.G);
-        c.valid = (eidx < last_contributor) && !(power > 0.0f) && !(c.alpha < 1.0f / 255.0f);
-        return c;
-    };
-    auto pair_math = [&](const float G, const float alpha, const bool valid, const float dx, const float dy, const float opac,
-                         const float c0, const float c1, const float c2, const float cx, const float cy, const float cz, float (&mv)[NROWS]) {
-        const float inv_one_m = __builtin_amdgcn_rcpf(1.f - alpha);
-        T = valid ? T * inv_one_m : T;
-        const float w = valid ? alpha * T : 0.f;
-        const float D = c0 * gp0 + c1 * gp1 + c2 * gp2 + g_alpha;
-        const float Snew = last_alpha * Dprev + (1.f - last_alpha) * S;
-        float dL_dopa = (D - Snew) * T;
-        if (has_bg) dL_dopa += (-T_final * inv_one_m) * bg_dot;
-        S = valid ? Snew : S;
-        Dprev = valid ? D : Dprev;
-        last_alpha = valid ? alpha : last_alpha;
-        const float dL_dG = valid ? opac * dL_dopa : 0.f;
-        const float q = dL_dG * G;
-        const float qdx = q * dx, qdy = q * dy;
-        int r = 0;
-        mv[r++] = w * gp0; mv[r++] = w * gp1; mv[r++] = w * gp2;
-        mv[r++] = q; mv[r++] = qdx; mv[r++] = qdy;
-        mv[r++] = qdx * dx; mv[r++] = qdx * dy; mv[r++] = qdy * dy;
-        if constexpr (ABS) {
-            const float gxa = cx * qdx + cy * qdy;
-            const float gya = cz * qdy + cy * qdx;
-            mv[r++] = fabsf(gxa * halfW) + fabsf(gya * halfH);
-        }
-    };
-    auto finish_single = [&](const Cand& c) {
-        const float4 q2 = chunk[c.j * NQ + 2];
-        float mv[NROWS];
-        pair_math(c.G, c.alpha, c.valid, c.dx, c.dy, c.q1.y, c.q1.z, c.q1.w, q2.x, c.q0.z, c.q0.w, c.q1.x, mv);
-        reduce_row(mv, __float_as_uint(q2.y));
-    };
-    auto finish_pair = [&](const Cand& A, const Cand& B) {
-        const float4 qa = chunk[A.j * NQ + 2], qb = chunk[B.j * NQ + 2];
-        const bool sel = B.valid;                        // lanes of B; every other lane takes A's parameters (and contributes zeros if A skips it)
-        float mv[NROWS];
-        pair_math(sel ? B.G : A.G, sel ? B.alpha : A.alpha, A.valid || B.valid, sel ? B.dx : A.dx, sel ? B.dy : A.dy,
-                  sel ? B.q1.y : A.q1.y, sel ? B.q1.z : A.q1.z, sel ? B.q1.w : A.q1.w, sel ? qb.x : qa.x,
-                  sel ? B.q0.z : A.q0.z, sel ? B.q0.w : A.q0.w, sel ? B.q1.x : A.q1.x, mv);
-        float ma[NROWS], mb[NROWS];
-#pragma unroll
-        for (int r = 0; r < NROWS; r++) { ma[r] = sel ? 0.f : mv[r]; mb[r] = sel ? mv[r] : 0.f; }
-        reduce_row(ma, __float_as_uint(qa.y));
-        reduce_row(mb, __float_as_uint(qb.y));
-    };
     // the record of staged splat j, read back from LDS as wave-uniform (broadcast) ds_read_b128
     struct LdsRec {
         const float4* r; const uint32_t* idp;
@@ -429,26 +366,6 @@ blend_bwd_kernel(const BlendBwdArgs a)
             }
         }
         __syncthreads();
-        if constexpr (COMPACT && BWD_PAIR) {
-            Cand cur; bool have = false;
-            for (int sw = 0; sw < NSW; sw++) {
-                uint64_t bits = quad_bits[wid][sw];
-                bits = uniform64(bits);
-                while (bits != 0ull) {
-                    const int j = sw * 64 + __builtin_ctzll(bits);
-                    bits &= bits - 1;
-                    const int eidx = n - 1 - (i * BCHUNK + j);
-                    if (eidx >= my_wave_max) continue;
-                    const Cand nxt = front(j, eidx);
-                    const uint64_t vn = __ballot(nxt.valid);
-                    if (vn == 0ull) continue;                                   // no pixel of this quad takes it
-                    if (!have) { cur = nxt; have = true; continue; }
-                    if ((__ballot(cur.valid) & vn) == 0ull) { finish_pair(cur, nxt); have = false; }
-                    else { finish_single(cur); cur = nxt; }
-                }
-            }
-            if (have) finish_single(cur);
-        } else {
         for (int sw = 0; sw < NSW; sw++) {
             uint64_t bits = quad_bits[wid][sw];
             bits = uniform64(bits);
@@ -459,7 +376,6 @@ blend_bwd_kernel(const BlendBwdArgs a)
                 if (eidx >= my_wave_max) continue;              // (scalar test) behind every pixel of this quad: another quad's tail
                 process_row(j, eidx, LdsRec{ &chunk[j * NQ], &chunk_id[j] });
             }
-        }
         }
     }
 }

@@ -116,15 +116,28 @@ _POOL = _ScratchPool()
 
 
 class _Lease:
-    """Returns its scratch set to the pool when the owning autograd context is garbage-collected."""
-    __slots__ = ("key", "item")
+    """Returns its scratch set to the pool when the owning autograd context is garbage-collected.
+
+    Under stream capture (`torch.cuda.graph`) the pool is NOT used: the captured kernels bake the raw scratch pointers, so the set
+    must be memory the GRAPH owns -- it is allocated fresh while capturing (from the graph's private memory pool, which the
+    graph keeps reserved for as long as it lives) and never handed to `_POOL`, where an eager call with the same key would
+    share it and a pool eviction would let the allocator recycle it under later replays."""
+    __slots__ = ("key", "item", "pooled")
 
     def __init__(self, key):
-        self.key, self.item = key, _POOL.acquire(key)
+        self.key = key
+        self.pooled = not torch.cuda.is_current_stream_capturing()
+        if self.pooled:
+            self.item = _POOL.acquire(key)
+        else:
+            dev = key[3]
+            ws = torch.empty(_cabi.lib().igs_rast_backward_workspace_bytes(key[0]), dtype=torch.uint8, device=dev)
+            self.item = (_Scratch(dev, True), _Scratch(dev, True), _Scratch(dev, True), ws)
 
     def __del__(self):
         try:
-            _POOL.release(self.key, self.item)
+            if self.pooled:
+                _POOL.release(self.key, self.item)
         except Exception:  # noqa: BLE001  (interpreter shutdown)
             pass
 

@@ -121,7 +121,10 @@ int igs_rast_forward_finish(void);
  * allocated then) and the scratch callbacks do not allocate illegally (PyTorch's graph-pool allocations are fine).
  * Every replay posts {num_rendered, overflow, prefilter flag} into the thread's status slot; igs_rast_last_status() returns
  * them once the caller has synchronised the stream.  overflow != 0 means the per-tile instance slabs baked into the capture
- * were too small for that replay: its results are invalid, the slab hint has been raised, capture again. */
+ * were too small for that replay: its results are invalid, the slab hint has been raised, capture again.
+ * igs_rast_last_status() checks the slot's sequence word against the number baked into the calling thread's last
+ * igs_rast_forward_nowait: before the first replay has run (or when an eager forward has posted since) it returns
+ * IGS_RAST_E_RETRY instead of an older frame's numbers. */
 int igs_rast_forward_nowait(
     void* stream,
     igs_rast_alloc_fn geometry_buffer, void* geometry_user, igs_rast_alloc_fn binning_buffer, void* binning_user,
