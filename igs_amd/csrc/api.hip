@@ -162,6 +162,12 @@ struct FwdExtra {
     float* zero_loss2 = nullptr;
     bool scratch_clean = false;         // igs_refine_step_args::scratch_clean: the image buffer's binning counters are known clean
     bool skip_bwd_state = false;        // ... the loss is colour-only: blend_fwd need not store the geometry branches' backward state
+    // igs_refine_step with the L1 loss: run the colour-only blend backward inside the forward's tile kernel (blend_step.hip).  The
+    // caller fills everything of the backward's arguments that forward_impl does not know (bg, gacc, l1_*, want_absgrad); the
+    // list / record / geometry fields are set here.  *fused_ran reports whether that kernel was used (slab binning only).
+    BlendBwdArgs* fused_bwd = nullptr;
+    bool* fused_ran = nullptr;
+    int* fused_instance = nullptr;
 };
 // where the last slab-binned forward left its device-side validity words (refine step guards)
 struct LastFwd { const uint32_t* overflow = nullptr; const uint32_t* prefilter = nullptr; };
@@ -366,7 +372,18 @@ static int forward_impl(
     ba.host_seq = g_host_seq;
     if (slab_pending && ex.no_latch) g_nowait_seq = g_host_seq;
     g_status_stream = s;
-    HIP_TRY(launch_blend_fwd(s, ba, require_coord != 0, require_depth != 0), "blend_fwd launch");
+    const bool fuse_tiles = ex.fused_bwd && ex.skip_bwd_state && slab_pending && !colors_precomp && (require_coord != 0) == (require_depth != 0);
+    if (ex.fused_ran) *ex.fused_ran = fuse_tiles;
+    if (fuse_tiles) {
+        BlendBwdArgs& bb = *ex.fused_bwd;
+        bb.W = width; bb.H = height; bb.gx = gx; bb.gy = gy; bb.fx = fp.fx; bb.fy = fp.fy; bb.bg = background;
+        bb.ranges = ranges; bb.point_list = point_list; bb.rec = rec; bb.colors_precomp = nullptr;
+        bb.tile_order = nullptr;
+        ba.tile_order = nullptr;                 // (no separate backward kernel that could use a load order)
+        HIP_TRY(launch_blend_step(s, ba, bb, require_coord != 0, require_depth != 0, ex.fused_instance), "blend_step launch");
+    } else {
+        HIP_TRY(launch_blend_fwd(s, ba, require_coord != 0, require_depth != 0), "blend_fwd launch");
+    }
     DBG_SYNC("blend_fwd");
     prof_mark(s, ST_BLEND_FWD);
     if (slab_pending && ex.defer_status) {
@@ -559,6 +576,8 @@ static int backward_impl(
     if (!fuse && (!dL_dmean2D || !dL_dcolor || !dL_dopacity || !dL_dmean3D || !dL_dcov3D || !dL_dscale || !dL_drot || (M > 0 && !dL_dsh)))
         return fail(IGS_RAST_E_INVALID, "igs_rast_backward: NULL output");
 
+    if ((uint64_t)P * GACC_F * 4 >= (1ull << 32))      // (the blend backward addresses its accumulator rows with 32-bit byte offsets)
+        return fail(IGS_RAST_E_INVALID, "igs_rast_backward: more than 33 million Gaussians are not supported");
     const int gx = (width + TILE - 1) / TILE, gy = (height + TILE - 1) / TILE;
     const size_t Tn = (size_t)gx * gy, HW = (size_t)width * height;
     const GeomLayout GL(P);
@@ -596,7 +615,11 @@ static int backward_impl(
     ba.tile_order = (const uint32_t*)(ibase + IL.tile_order);    // the forward's blend kernel ordered the tiles heaviest-first
     bool gacc_compact = will_compact;
     int inst_bits = -1;
-    if (R > 0) {
+    if (fuse && fuse->blend_done) {
+        // the blend backward ran inside the forward's tile kernel (blend_step.hip): colour-only moments in compact rows
+        if (!will_compact) return fail(IGS_RAST_E_INVALID, "internal: fused tile kernel with a non-compact accumulator layout");
+        prof_mark(s, ST_BLEND_BWD);
+    } else if (R > 0) {
         HIP_TRY(launch_blend_bwd(s, ba, require_coord != 0, require_depth != 0, &gacc_compact, &inst_bits), "blend_bwd launch");
         if (gacc_compact != will_compact) return fail(IGS_RAST_E_INVALID, "internal: accumulator layout mismatch");
         __atomic_store_n(&g_last_bwd_instance, inst_bits, __ATOMIC_RELAXED);
@@ -727,12 +750,30 @@ extern "C" int igs_refine_step(const igs_refine_step_args* a)
         ex.raw_activations = true;
         ex.skip_bwd_state = !dn;                   // (colour-only backward instance: see BlendFwdArgs)
         ex.scratch_clean = a->scratch_clean != 0;
+        // L1 loss, colour-only backward: forward and backward blend of a tile in one kernel (blend_step.hip)
+        BlendBwdArgs fused_bwd;
+        bool fused_ran = false;
+        int fused_inst = -1;
+        static const bool no_fuse = getenv("IGS_NO_TILE_FUSION") != nullptr;      // (A/B switch for measurements)
+        if (!dssim && !dn && !no_fuse) {
+            fused_bwd.alphas = nullptr; fused_bwd.normalmap = nullptr; fused_bwd.accum_coord = nullptr; fused_bwd.accum_depth = nullptr;
+            fused_bwd.normal_length = nullptr; fused_bwd.n_contrib = nullptr;
+            fused_bwd.dL_dpix = nullptr; fused_bwd.dL_dcoord = nullptr; fused_bwd.dL_dmcoord = nullptr; fused_bwd.dL_ddepth = nullptr;
+            fused_bwd.dL_dmdepth = nullptr; fused_bwd.dL_dalpha = nullptr; fused_bwd.dL_dnormal = nullptr;
+            fused_bwd.gacc = ex.zero_gacc;
+            fused_bwd.l1_gt = a->gt; fused_bwd.l1_color = color; fused_bwd.l1_scale = l1_scale;
+            fused_bwd.l1_loss = (float*)((char*)ex.zero_gacc + ws_gacc_bytes(a->P));
+            fused_bwd.want_absgrad = a->dL_dmean2D ? 1 : 0;
+            ex.fused_bwd = &fused_bwd; ex.fused_ran = &fused_ran; ex.fused_instance = &fused_inst;
+        }
         const int R = forward_impl(a->stream, capture_alloc, &cg, capture_alloc, &cb, capture_alloc, &ci, a->P, a->D, a->M, a->background,
                                    a->width, a->height, xyz, shs, nullptr, opac, scal, 1.0f, rotn, nullptr, a->viewmatrix, a->projmatrix,
                                    a->cam_pos, a->tan_fovx, a->tan_fovy, 0.0f, 0, color, coord, mcoord, depth, mdepth, alpha, normal,
                                    a->radii, a->require_coord, a->require_depth, 0, false, 0, ex);
         if (R < 0) return R;
         f.guard_overflow = g_last_fwd.overflow; f.guard_prefilter = g_last_fwd.prefilter;
+        f.blend_done = fused_ran ? 1 : 0;
+        if (fused_ran) __atomic_store_n(&g_last_bwd_instance, fused_inst, __ATOMIC_RELAXED);
         if (dssim) {
             prof_mark((hipStream_t)a->stream, ST_GAP);
             if (launch_ssim_l1((hipStream_t)a->stream, a->width, a->height, color, a->gt, a->lambda_dssim, a->loss_weight, a->loss_scratch,

@@ -31,9 +31,11 @@ __device__ __forceinline__ uint32_t quad_reach_mask(float4 q0, float4 q1, float 
     if (!(det > 0.f) || !(cx > 0.f) || !(cz > 0.f) || !(det < 3.0e38f)) return 0xFu;
     const float two_tau = 2.0f * __logf(255.0f * o) * 1.002f + 1e-3f;
     if (!(two_tau < 3.0e38f)) return 0xFu;
-    const float inv = 1.0f / det;
-    const float ex = sqrtf(two_tau * cz * inv) * 1.001f + 0.02f;
-    const float ey = sqrtf(two_tau * cx * inv) * 1.001f + 0.02f;
+    // (v_rcp_f32 / v_sqrt_f32, 1 ulp each, instead of the IEEE sequences of `/` and sqrtf: the margins below are a thousand times wider,
+    //  and this test runs once per staged splat -- 11 % of the forward's instructions went here)
+    const float inv = __builtin_amdgcn_rcpf(det);
+    const float ex = __builtin_amdgcn_sqrtf(two_tau * cz * inv) * 1.001f + 0.02f;
+    const float ey = __builtin_amdgcn_sqrtf(two_tau * cx * inv) * 1.001f + 0.02f;
     if (!(ex < 3.0e38f) || !(ey < 3.0e38f)) return 0xFu;
     const float lx = q0.x - ex - tile_x0, hx = q0.x + ex - tile_x0;      // reach interval in tile-local pixel coordinates
     const float ly = q0.y - ey - tile_y0, hy = q0.y + ey - tile_y0;
@@ -42,7 +44,7 @@ __device__ __forceinline__ uint32_t quad_reach_mask(float4 q0, float4 q1, float 
     uint32_t m = (x0 && y0 ? 1u : 0u) | (x1 && y0 ? 2u : 0u) | (x0 && y1 ? 4u : 0u) | (x1 && y1 ? 8u : 0u);
     if (m == 0u) return 0u;
     // ---- test 2 (coordinates relative to the splat centre; rectangle inflated by 0.02 px)
-    const float nbc = -cy / cz, nba = -cy / cx;               // argmin of the form along a vertical / horizontal line
+    const float nbc = -cy * __builtin_amdgcn_rcpf(cz), nba = -cy * __builtin_amdgcn_rcpf(cx);      // argmin of the form along a vertical / horizontal line
     const float bx = (tile_x0 - 0.02f) - q0.x, by = (tile_y0 - 0.02f) - q0.y;
 #pragma unroll
     for (int q = 0; q < 4; q++) {

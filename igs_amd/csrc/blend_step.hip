@@ -1,0 +1,76 @@
+// blend_step.hip -- forward AND backward blend of a tile in ONE kernel, for the refine step with a per-pixel colour loss (L1).
+//
+// With `loss = mean |colour - gt|` (infer_batch.py:302 with lambda_dssim = 0, BASELINE configs[2]) the backward of a tile needs
+// nothing another tile produces: dL/dcolour of a pixel is a function of that pixel alone.  So the workgroup that has just blended
+// its tile front to back (blend_fwd_tile.h, the <coord, depth, normal> instance the reference's loop renders, images written as
+// always) turns round and walks the same list back to front (blend_bwd_tile.h, colour-only instance, L1 fused in) with what it
+// still holds in registers -- colour, final transmittance, alpha, last contributor -- instead of a second kernel that starts by
+// loading colour (3), ground truth (3), alpha and the contributor count of every pixel again.  What it saves (same-box ablation of the
+// stand-alone backward, round 3: empty grid 7 us, + per-pixel loads and the first barrier 16 us, + staging 25 us of its 78):
+// one kernel boundary, the 32 B per pixel of the backward's prologue (44 MB per view), the contributor-count image (never
+// written), and the records of the backward's first round come out of an L2 the forward has just pulled them through.
+// Results are bit-identical to the two-kernel path: the same device functions run on the same values.
+#include "blend_fwd_tile.h"
+#include "blend_fwd_blk.h"
+#include "blend_bwd_tile.h"
+#ifndef IGS_BLK_FWD
+#define IGS_BLK_FWD 0
+#endif
+
+template <bool COORD, bool DEPTH, bool NORMAL, bool ABS>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8)))
+blend_step_kernel(const BlendFwdArgs f, const BlendBwdArgs b)
+{
+    constexpr bool GEO = COORD || DEPTH || NORMAL;
+    using Cfg = BwdCfg<false, false, false, ABS>;
+#if IGS_BLK_FWD
+    constexpr size_t FWD_CHUNK_BYTES = (size_t)FWDB_CHUNK_F4(GEO) * 16;
+    constexpr size_t FWD_BYTES = FWD_CHUNK_BYTES + (size_t)FWDB_CHUNK * 4 + FWDB_LIST_BYTES;      // records | reach masks | block lists
+#else
+    constexpr size_t FWD_BYTES = (size_t)FWD_CHUNK * (GEO ? 6 : 3) * 16;
+#endif
+    constexpr size_t BWD_CHUNK_BYTES = (size_t)Cfg::BCHUNK * Cfg::NQ * 16;
+    constexpr size_t BWD_BYTES = BWD_CHUNK_BYTES + (size_t)Cfg::RED_FLOATS * 4;
+    // the two passes use the same LDS one after the other
+    __shared__ __attribute__((aligned(16))) char smem[FWD_BYTES > BWD_BYTES ? FWD_BYTES : BWD_BYTES];
+    __shared__ uint64_t quad_bits_f[4][FWD_NSW];
+    __shared__ uint64_t quad_bits_b[4][Cfg::NSW];
+    __shared__ int wave_done[4];
+    __shared__ int wave_max[4];
+
+    if (blockIdx.x == 0 && threadIdx.x == 0 && f.host_dst) {      // {R, overflow, prefilter flag} -> host-visible memory, as in blend_fwd_kernel
+        f.host_dst[0] = f.stats_src[0]; f.host_dst[1] = f.stats_src[1]; f.host_dst[2] = f.flag_src[0];
+        __threadfence_system();
+        __hip_atomic_store(&f.host_dst[3], f.host_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        __threadfence_system();
+    }
+    uint32_t tile;
+    if (!tile_for_block(blockIdx.x, f.gx, f.gy, tile)) return;
+    FwdPix px;
+#if IGS_BLK_FWD
+    blend_fwd_tile_blk<COORD, DEPTH, NORMAL, true, false>(f, tile, (float4*)smem, (uint32_t*)(smem + FWD_CHUNK_BYTES),
+                                                          (uint8_t*)(smem + FWD_CHUNK_BYTES + (size_t)FWDB_CHUNK * 4), wave_done, px);
+#else
+    blend_fwd_tile<COORD, DEPTH, NORMAL, true, false>(f, tile, (float4*)smem, quad_bits_f, wave_done, px);
+#endif
+    __syncthreads();          // every wave is done with the forward's staged records: the backward takes the LDS over
+    blend_bwd_tile<false, false, false, ABS, true>(b, tile, (float4*)smem, nullptr, quad_bits_b, wave_max, (float*)(smem + BWD_CHUNK_BYTES), &px);
+}
+
+// `f.skip_bwd_state` must be set (the lean forward); `b`: the colour-only backward with the L1 loss fused in (l1_gt set; l1_color,
+// alphas, n_contrib are not read).  instance_bits as launch_blend_bwd reports them.
+hipError_t launch_blend_step(hipStream_t s, const BlendFwdArgs& f, const BlendBwdArgs& b, bool coord, bool depth, int* instance_bits)
+{
+    if (!f.skip_bwd_state || !b.l1_gt || b.dL_dcoord || b.dL_dmcoord || b.dL_ddepth || b.dL_dmdepth || b.dL_dnormal || b.dL_dalpha || b.colors_precomp)
+        return hipErrorInvalidValue;
+    const dim3 grid(tile_grid_blocks(f.gx, f.gy)), block(256);
+    if (instance_bits) *instance_bits = b.want_absgrad ? 8 : 0;
+    if (coord && depth) {
+        if (b.want_absgrad) hipLaunchKernelGGL((blend_step_kernel<true, true, true, true>), grid, block, 0, s, f, b);
+        else hipLaunchKernelGGL((blend_step_kernel<true, true, true, false>), grid, block, 0, s, f, b);
+    } else if (!coord && !depth) {
+        if (b.want_absgrad) hipLaunchKernelGGL((blend_step_kernel<false, false, false, true>), grid, block, 0, s, f, b);
+        else hipLaunchKernelGGL((blend_step_kernel<false, false, false, false>), grid, block, 0, s, f, b);
+    } else return hipErrorInvalidValue;          // (the refine loop renders everything or nothing; mixed cases take the two-kernel path)
+    return hipGetLastError();
+}

@@ -170,6 +170,8 @@ struct BlendBwdArgs {
     const uint32_t* tile_order = nullptr;      // [T] tile ids, heaviest first (the forward's blend kernel wrote them); NULL: plain XCD-aware order
 };
 hipError_t launch_blend_bwd(hipStream_t s, const BlendBwdArgs& a, bool coord, bool depth, bool* compact_layout, int* instance_bits = nullptr);
+// forward + colour-only backward (L1 fused in) of every tile in one kernel (blend_step.hip): igs_refine_step with the L1 loss
+hipError_t launch_blend_step(hipStream_t s, const BlendFwdArgs& f, const BlendBwdArgs& b, bool coord, bool depth, int* instance_bits = nullptr);
 
 struct GeomBwdArgs {
     int P, D, M, W, H;
@@ -197,6 +199,7 @@ struct RefineFuse {
     const float* loss_shards; const float* loss_shards2; const float* loss_shards3; float* loss_out;
     float loss_scale, loss_scale2, loss_scale3, loss_bias;
     int prezeroed;                                                         // the accumulators were zero-filled by the forward
+    int blend_done = 0;                                                    // the blend backward already ran inside the forward's tile kernel (blend_step.hip)
     float* color_out = nullptr;                                            // [P][3] non-NULL: also write dL/d(colour) of this view (clamped channels and
                                                                            // invisible Gaussians zero): what the N > 1 exchange gathers instead of dL/dSH
 };

@@ -104,9 +104,11 @@ def image_bound(k, rng):
     return max(1e-4, 24.0 * float(np.spacing(np.float32(max(rng, 1e-30)))))
 
 
-def check_images(out, oo, flips=2e-4, label=""):
+def check_images(out, oo, flips=None, label=""):
     """Every pixel of the seven images within `image_bound` of the oracle, in absolute units, except for at most a fraction `flips`
-    of the pixels, where a hard threshold of the blend (`power > 0`, `alpha < 1/255`, `T (1 - alpha) < 1e-4`: forward.cu:556-573;
+    of the pixels (default: 1e-5 of the image, but two pixels at least -- measured at full size, ten cameras, round 3: at most ONE
+    pixel of 1.37 million per output, and the largest error off those pixels 7.5e-5 colour / 7.4e-5 normal / 9.5e-6 depth at range
+    38.5 / 7.6e-6 coord / 4.2e-7 alpha), where a hard threshold of the blend (`power > 0`, `alpha < 1/255`, `T (1 - alpha) < 1e-4`: forward.cu:556-573;
     `T > 0.5` for the median outputs: forward.cu:640) falls on the other side because expf / the per-Gaussian conic differ in the
     last bits -- just as between the reference's CUDA build and this oracle.  What a flip can do is bounded too: dropping or adding
     one splat at the `alpha < 1/255` threshold moves an accumulated output by alpha T <= 1/255 of its range, stopping one splat
@@ -116,6 +118,10 @@ def check_images(out, oo, flips=2e-4, label=""):
     nr, color, coord, mcoord, alpha, normal, depth, mdepth = out[:8]
     for k, v in [("color", color), ("coord", coord), ("mcoord", mcoord), ("depth", depth), ("mdepth", mdepth), ("alpha", alpha), ("normal", normal)]:
         o = oo[k]
+        if flips is None:
+            flips_k = max(1e-5, 2.0 / max(1, o.shape[-1] * o.shape[-2]))
+        else:
+            flips_k = flips
         d = np.abs(np.asarray(v.cpu().numpy(), np.float64) - o)
         rng = float(np.abs(o).max()) if o.size else 0.0
         bound = image_bound(k, rng)
@@ -126,7 +132,7 @@ def check_images(out, oo, flips=2e-4, label=""):
         IMAGE_REPORT.append((label, k, good_max, bound, frac, flip_max / max(rng, 1.0)))
         print("images %s %-6s: max abs err %.3e (bound %.3e, range %.3g); flipped pixels %.2e of all, largest %.3e of range"
               % (label, k, good_max, bound, rng, frac, flip_max / max(rng, 1.0)))
-        assert frac <= flips, (k, frac, flip_max)
+        assert frac <= flips_k, (k, frac, flip_max)
         if k not in ("mcoord", "mdepth"):
             assert flip_max <= 0.01 * max(rng, 1.0), (k, flip_max, rng)
 
