@@ -11,24 +11,14 @@
 // Tiles are handed to workgroups through an XCD-aware remap so that the tiles sharing an L2 are neighbours.
 // The per-tile work itself lives in blend_fwd_tile.h (shared with the fused tile kernel of the refine step, blend_step.hip).
 #include "blend_fwd_tile.h"
-#include "blend_fwd_blk.h"
-#ifndef IGS_BLK_FWD
-#define IGS_BLK_FWD 0          // 1: block-list form (blend_fwd_blk.h: measured SLOWER); 0: quad form (blend_fwd_tile.h)
-#endif
 
 template <bool COORD, bool DEPTH, bool NORMAL, bool LEAN = false>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8)))
 blend_fwd_kernel(const BlendFwdArgs a)
 {
     constexpr bool GEO = COORD || DEPTH || NORMAL;
-#if IGS_BLK_FWD
-    __shared__ float4 chunk[FWDB_CHUNK_F4(GEO)];
-    __shared__ uint32_t reach[FWDB_CHUNK];
-    __shared__ __attribute__((aligned(4))) uint8_t lists[FWDB_LIST_BYTES];
-#else
     __shared__ float4 chunk[FWD_CHUNK * (GEO ? 6 : 3)];
     __shared__ uint64_t quad_bits[4][FWD_NSW];              // [quad][staging wave]
-#endif
     __shared__ int wave_done[4];
     __shared__ uint32_t order_hist[2 * LOAD_CLASSES];
 
@@ -43,11 +33,7 @@ blend_fwd_kernel(const BlendFwdArgs a)
     uint32_t tile;
     if (!tile_for_block(blockIdx.x, a.gx, a.gy, tile)) return;
     FwdPix px;
-#if IGS_BLK_FWD
-    blend_fwd_tile_blk<COORD, DEPTH, NORMAL, LEAN, true>(a, tile, chunk, reach, lists, wave_done, px);
-#else
     blend_fwd_tile<COORD, DEPTH, NORMAL, LEAN, true>(a, tile, chunk, quad_bits, wave_done, px);
-#endif
 }
 
 hipError_t launch_blend_fwd(hipStream_t s, const BlendFwdArgs& a, bool coord, bool depth)

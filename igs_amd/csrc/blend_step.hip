@@ -11,11 +11,7 @@
 // written), and the records of the backward's first round come out of an L2 the forward has just pulled them through.
 // Results are bit-identical to the two-kernel path: the same device functions run on the same values.
 #include "blend_fwd_tile.h"
-#include "blend_fwd_blk.h"
 #include "blend_bwd_tile.h"
-#ifndef IGS_BLK_FWD
-#define IGS_BLK_FWD 0
-#endif
 
 template <bool COORD, bool DEPTH, bool NORMAL, bool ABS>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8)))
@@ -23,12 +19,7 @@ blend_step_kernel(const BlendFwdArgs f, const BlendBwdArgs b)
 {
     constexpr bool GEO = COORD || DEPTH || NORMAL;
     using Cfg = BwdCfg<false, false, false, ABS>;
-#if IGS_BLK_FWD
-    constexpr size_t FWD_CHUNK_BYTES = (size_t)FWDB_CHUNK_F4(GEO) * 16;
-    constexpr size_t FWD_BYTES = FWD_CHUNK_BYTES + (size_t)FWDB_CHUNK * 4 + FWDB_LIST_BYTES;      // records | reach masks | block lists
-#else
     constexpr size_t FWD_BYTES = (size_t)FWD_CHUNK * (GEO ? 6 : 3) * 16;
-#endif
     constexpr size_t BWD_CHUNK_BYTES = (size_t)Cfg::BCHUNK * Cfg::NQ * 16;
     constexpr size_t BWD_BYTES = BWD_CHUNK_BYTES + (size_t)Cfg::RED_FLOATS * 4;
     // the two passes use the same LDS one after the other
@@ -47,12 +38,7 @@ blend_step_kernel(const BlendFwdArgs f, const BlendBwdArgs b)
     uint32_t tile;
     if (!tile_for_block(blockIdx.x, f.gx, f.gy, tile)) return;
     FwdPix px;
-#if IGS_BLK_FWD
-    blend_fwd_tile_blk<COORD, DEPTH, NORMAL, true, false>(f, tile, (float4*)smem, (uint32_t*)(smem + FWD_CHUNK_BYTES),
-                                                          (uint8_t*)(smem + FWD_CHUNK_BYTES + (size_t)FWDB_CHUNK * 4), wave_done, px);
-#else
     blend_fwd_tile<COORD, DEPTH, NORMAL, true, false>(f, tile, (float4*)smem, quad_bits_f, wave_done, px);
-#endif
     __syncthreads();          // every wave is done with the forward's staged records: the backward takes the LDS over
     blend_bwd_tile<false, false, false, ABS, true>(b, tile, (float4*)smem, nullptr, quad_bits_b, wave_max, (float*)(smem + BWD_CHUNK_BYTES), &px);
 }
