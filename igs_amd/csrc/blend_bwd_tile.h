@@ -304,24 +304,37 @@ __device__ __forceinline__ void blend_bwd_tile(const BlendBwdArgs& a, const uint
     // `j`: staged slot (wave-uniform); a pixel takes part iff the slot lies in front of its last contributor: j > j_first (per
     // lane, per round -- no per-row scalar arithmetic on list positions); j_med: the slot of the pixel's median splat
     int j_first = 0, j_med = -1;
+    // background term of dL/dalpha (backward.cu:  dL_dalpha += (-T_final / (1 - alpha)) * bg_dot): zero when the background is black
+    const float bg_dot_e = has_bg ? bg_dot : 0.f;
     auto process_row = [&](const int j, auto R) {
+                // colour-only instances stage the record as { x, y, conic.x, conic.y | conic.z, opacity, -, - | r, g, b, id }: three
+                // ALIGNED broadcast reads (b128, b64, b128) with immediate offsets; the instances with geometry keep the 96-byte record
                 const float4 q0 = R.q0();
-                const float4 q1 = R.q1();
+                float cz, op, col0, col1, col2;
+                float4 q1, q2;
+                if constexpr (GEO) { q1 = R.q1(); cz = q1.x; op = q1.y; }
+                else { const float2 t2 = *(const float2*)&R.r[1]; cz = t2.x; op = t2.y; }
                 const float dx = q0.x - pixfx, dy = q0.y - pixfy;
-                const float power = gauss_power(q0.z, q0.w, q1.x, dx, dy);
+                const float power = gauss_power(q0.z, q0.w, cz, dx, dy);
                 const float G = __expf(power);
-                const float alpha = fminf(0.99f, q1.y * G);
-                const bool valid = (j > j_first) && !(power > 0.0f) && !(alpha < 1.0f / 255.0f);
+                const float alpha0 = fminf(0.99f, op * G);
+                const bool valid = (j > j_first) && !(power > 0.0f) && !(alpha0 < 1.0f / 255.0f);
                 if (__ballot(valid) == 0ull) return;
 
-                const float4 q2 = R.q2();
+                uint32_t gid;
+                if constexpr (GEO) { q2 = R.q2(); col0 = q1.z; col1 = q1.w; col2 = q2.x; gid = chunk_id[j]; }
+                else { const float4 c4 = R.r[2]; col0 = c4.x; col1 = c4.y; col2 = c4.z; gid = __float_as_uint(c4.w); }
+                // A pixel the splat does not contribute to takes part with alpha 0: then 1/(1-alpha) = 1 and T stays, w = 0, and the
+                // suffix recurrence below may be advanced unconditionally -- with last_alpha = 0 its next step reproduces S bit for
+                // bit (0 * D + 1 * S) -- so the row needs two selects instead of six (issue slots: DESIGN.md 5).
+                const float alpha = valid ? alpha0 : 0.f;
                 // 1/(1-alpha) once (v_rcp_f32, 1 ulp) instead of two IEEE divisions; 1-alpha >= 0.01
                 const float inv_one_m = __builtin_amdgcn_rcpf(1.f - alpha);
-                T = valid ? T * inv_one_m : T;
-                const float w = valid ? alpha * T : 0.f;
+                T = T * inv_one_m;
+                const float w = alpha * T;
                 const bool is_med = valid && (j == j_med);
 
-                float D = q1.z * gp0 + q1.w * gp1 + q2.x * gp2 + g_alpha;
+                float D = col0 * gp0 + col1 * gp1 + col2 * gp2 + g_alpha;
                 float dLc0 = 0, dLc1 = 0, dLc2 = 0, dLt = 0;
                 float4 q3, q4, q5;
                 if constexpr (GEO) { q3 = R.r[3]; q5 = R.r[5]; }
@@ -343,13 +356,9 @@ __device__ __forceinline__ void blend_bwd_tile(const BlendBwdArgs& a, const uint
                 if constexpr (NORMAL) D += q3.w * gn0 + q5.z * gn1 + q5.w * gn2;
 
                 const float Snew = last_alpha * Dprev + (1.f - last_alpha) * S;
-                float dL_dopa = (D - Snew) * T;
-                if (has_bg) dL_dopa += (-T_final * inv_one_m) * bg_dot;
-                S = valid ? Snew : S;
-                Dprev = valid ? D : Dprev;
-                last_alpha = valid ? alpha : last_alpha;
-                const float dL_dG = valid ? q1.y * dL_dopa : 0.f;
-                const float q = dL_dG * G;
+                const float dL_dopa = (D - Snew) * T + (-T_final * inv_one_m) * bg_dot_e;
+                S = Snew; Dprev = D; last_alpha = alpha;
+                const float q = valid ? (op * dL_dopa) * G : 0.f;
                 const float qdx = q * dx, qdy = q * dy;
 
                 // ---- transpose-reduce over the 64 pixels of the wave: row r of `myred` = the 64 per-lane values of one LIVE
@@ -368,10 +377,10 @@ __device__ __forceinline__ void blend_bwd_tile(const BlendBwdArgs& a, const uint
                 mv[r++] = qdx * dx; mv[r++] = qdx * dy; mv[r++] = qdy * dy;
                 if constexpr (ABS) {
                     const float gxa = q0.z * qdx + q0.w * qdy;      // -dL/d(delx) of the Gaussian term
-                    const float gya = q1.x * qdy + q0.w * qdx;
+                    const float gya = cz * qdy + q0.w * qdx;
                     mv[r++] = fabsf(gxa * halfW) + fabsf(gya * halfH);
                 }
-                reduce_row(mv, GEO ? chunk_id[j] : __float_as_uint(q2.y));      // (colour-only: the id rides in the record's unused ts slot)
+                reduce_row(mv, gid);
     };
     // the record of staged splat j, read back from LDS as wave-uniform (broadcast) ds_read_b128
     struct LdsRec {
@@ -397,9 +406,13 @@ __device__ __forceinline__ void blend_bwd_tile(const BlendBwdArgs& a, const uint
                     q1.z = a.colors_precomp[3 * (size_t)id]; q1.w = a.colors_precomp[3 * (size_t)id + 1];
                     q2.x = a.colors_precomp[3 * (size_t)id + 2];
                 }
-                if constexpr (!GEO) q2.y = __uint_as_float(id);      // the colour-only row never reads ts: the id rides in its slot
-                chunk[tid * NQ + 0] = q0; chunk[tid * NQ + 1] = q1; chunk[tid * NQ + 2] = q2;
-                if constexpr (GEO) { chunk[tid * NQ + 3] = src[3]; chunk[tid * NQ + 4] = src[4]; chunk[tid * NQ + 5] = src[5]; chunk_id[tid] = id; }
+                if constexpr (GEO) {
+                    chunk[tid * NQ + 0] = q0; chunk[tid * NQ + 1] = q1; chunk[tid * NQ + 2] = q2;
+                    chunk[tid * NQ + 3] = src[3]; chunk[tid * NQ + 4] = src[4]; chunk[tid * NQ + 5] = src[5]; chunk_id[tid] = id;
+                } else {      // (see process_row: aligned reads, the id in the colour quad)
+                    chunk[tid * NQ + 0] = q0; chunk[tid * NQ + 1] = make_float4(q1.x, q1.y, 0.f, 0.f);
+                    chunk[tid * NQ + 2] = make_float4(q1.z, q1.w, q2.x, __uint_as_float(id));
+                }
                 qmask = quad_reach_mask(q0, q1, tile_x0, tile_y0);
             }
         }
