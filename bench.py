@@ -558,24 +558,52 @@ def main():
             per = {k: (ms / cnt if cnt else 0.0) for k, (ms, cnt) in stages.items()}
             nsamp = {k: cnt for k, (ms, cnt) in stages.items() if cnt}
             per_t = {k: (ms / cnt if cnt else 0.0) for k, (ms, cnt) in stages_timed.items()}
-            dom = "blend_bwd" if per.get("blend_bwd", 0) >= per.get("blend_fwd", 0) else "blend_fwd"
-            oth = "blend_fwd" if dom == "blend_bwd" else "blend_bwd"
+            # igs_refine_step with the L1 loss blends forward AND backward in one kernel per tile (blend_step.hip): the "blend_fwd" stage is
+            # then that launch and the "blend_bwd" stage the empty interval between two event marks
+            tile_fusion = fused and stream is False and os.environ.get("IGS_NO_TILE_FUSION") is None and \
+                per.get("blend_fwd", 0) > 0 and per.get("blend_bwd", 0) < 0.25 * per.get("blend_fwd", 0)
+            T_tiles = ((args.width + 15) // 16) * ((args.height + 15) // 16)
+            if tile_fusion:
+                per["blend_step"] = per["blend_fwd"]
+                nsamp["blend_step"] = nsamp.get("blend_fwd", 0)
+                per_t["blend_step"] = per_t.get("blend_fwd")
+                ab["blend_step"] = ab["blend_fwd"] + ab["blend_bwd"]
+                dom, oth = "blend_step", None
+            else:
+                dom = "blend_bwd" if per.get("blend_bwd", 0) >= per.get("blend_fwd", 0) else "blend_fwd"
+                oth = "blend_fwd" if dom == "blend_bwd" else "blend_bwd"
+            # the bytes the launched instance cannot avoid (SURVEY's R*100 write term counts 25 moments, the colour-only
+            # instance accumulates 10; the lean forward stores no backward state; the fused kernel re-reads nothing per pixel)
+            HWp = args.width * args.height
+            strict = {"blend_fwd": R_avg * (100 if geo_fwd else 40) + HWp * ((60 if geo_fwd else 16) + (8 if not fused else 4)) + 8 * T_tiles,
+                      "blend_bwd": R_avg * (64 if dn else 40) + HWp * ((68 if fused else 56) if dn else (40 if fused else 28)) + R_avg * (64 if dn else 40),
+                      "blend_step": R_avg * ((100 if geo_fwd else 40) + 40 + 40) + HWp * ((60 if geo_fwd else 16) + 12) + 8 * T_tiles}
             ach = ab[dom] / (per[dom] * 1e-3) / 1e9 if per[dom] > 0 else 0.0
             roof = {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                     "traffic": None,
-                    "traffic_note": "HBM bytes are not measured in this process; rocprofv3 PMC passes of the same command: profiles/r02_pmc.json",
+                    "traffic_note": "HBM bytes are not measured in this process; rocprofv3 PMC passes of the same command: profiles/r03_pmc.json",
                     "algorithmic_bytes_per_launch": ab[dom], "avg_launch_ms": per[dom], "avg_launch_samples": nsamp.get(dom, 0),
                     "avg_launch_ms_sampled_in_timed_region": per_t.get(dom),
                     "stage_timing": ("HIP events on the kernels' own stream, every step of a separate %d-step pass right after the timed region"
                                      % args.profile_steps) if (cfg in ("cfg2", "cfg3") and args.profile_steps > 0) else
                                     "HIP events on the kernels' own stream, every %d-th step of the timed region" % max(1, args.profile_every),
-                    "instance": (("blend_bwd<depth, normal gradients%s>: R*64 + H*W*%d + R*100 bytes" % ((", L1 fused", 68) if fused else ("", 56)) if dn else
-                                  "blend_bwd<colour-only gradients%s>: R*40 + H*W*%d + R*100 bytes" % ((", L1 fused", 40) if fused else ("", 28))) if dom == "blend_bwd"
-                                 else "blend_fwd<coord,depth,normal>: R*100 + H*W*88 + 8*T bytes"),
+                    "instance": ("blend_step<coord,depth,normal | colour-only gradients, L1 fused>: one kernel per tile does the forward "
+                                 "(R*100 + H*W*88 + 8*T) and the backward (R*40 + H*W*40 + R*100) -- SURVEY 8(d)'s bytes of the two kernels it replaces"
+                                 if dom == "blend_step" else
+                                 (("blend_bwd<depth, normal gradients%s>: R*64 + H*W*%d + R*100 bytes" % ((", L1 fused", 68) if fused else ("", 56)) if dn else
+                                   "blend_bwd<colour-only gradients%s>: R*40 + H*W*%d + R*100 bytes" % ((", L1 fused", 40) if fused else ("", 28))) if dom == "blend_bwd"
+                                  else "blend_fwd<coord,depth,normal>: R*100 + H*W*88 + 8*T bytes")),
+                    "strict": {"bytes_per_launch": strict[dom], "achieved": strict[dom] / (per[dom] * 1e-3) / 1e9 if per[dom] > 0 else 0.0,
+                               "frac": strict[dom] / (per[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS if per[dom] > 0 else 0.0,
+                               "note": "bytes this instance cannot avoid: gathers R*g, the images it writes, gt, and the accumulator rows it "
+                                       "actually adds to (10 moments = 40 B for the colour-only backward, not SURVEY's 25 = 100 B); the lean forward "
+                                       "stores no backward state and the fused kernel re-reads no per-pixel results"},
                     "num_rendered_avg": R_avg,
-                    "other": {oth: {"achieved": (ab[oth] / (per[oth] * 1e-3) / 1e9) if per.get(oth, 0) > 0 else 0.0,
-                                    "frac": (ab[oth] / (per[oth] * 1e-3) / 1e9 / HBM_PEAK_GBS) if per.get(oth, 0) > 0 else 0.0,
-                                    "algorithmic_bytes_per_launch": ab[oth], "avg_launch_ms": per.get(oth)}},
+                    "other": ({oth: {"achieved": (ab[oth] / (per[oth] * 1e-3) / 1e9) if per.get(oth, 0) > 0 else 0.0,
+                                     "frac": (ab[oth] / (per[oth] * 1e-3) / 1e9 / HBM_PEAK_GBS) if per.get(oth, 0) > 0 else 0.0,
+                                     "algorithmic_bytes_per_launch": ab[oth], "avg_launch_ms": per.get(oth)}} if oth else
+                              {"note": "forward and backward blend are one launch; IGS_NO_TILE_FUSION=1 python bench.py times them separately "
+                                       "(round 3, same box: blend_fwd 55 us, blend_bwd 73 us, fused 122 us)"}),
                     "stage_ms": {k: round(v, 4) for k, v in per.items()}}
             # ALU-side figure (SURVEY.md 8d / hard part 3): pixel-Gaussian pairs = sum over pixels of the contributor count
             try:
@@ -593,27 +621,29 @@ def main():
                         tot_pairs += int(d["n_contrib"][0].to(torch.int64).sum().item())
                     pairs = tot_pairs / ncam
                     roof["pairs_per_view"] = pairs
-                    roof["pairs_per_s"] = {k: (pairs / (per[k] * 1e-3) if per.get(k, 0) > 0 else None) for k in ("blend_fwd", "blend_bwd")}
+                    roof["pairs_per_s"] = ({"blend_step (every pair once forward, once backward)": 2.0 * pairs / (per["blend_step"] * 1e-3)} if tile_fusion else
+                                           {k: (pairs / (per[k] * 1e-3) if per.get(k, 0) > 0 else None) for k in ("blend_fwd", "blend_bwd")})
                     roof["pairs_note"] = ("pixel-Gaussian pairs examined per view (sum over pixels of the reference's `contributor` count, "
                                           "forward.cu:556-573), mean over %d cameras; VALU issue fraction of the blend kernels: DESIGN.md section 5 "
                                           "(rocprofv3 SQ_INSTS_VALU x measured cycles per wave64 op, tools/ubench/valu_rate)" % ncam)
             except Exception as e:  # noqa: BLE001
                 roof["pairs_per_view"] = None
                 roof["pairs_note"] = "failed: %s" % e
-            # VALU-issue side (SURVEY 8d hard part 3): wave-instruction counts per launch are a property of binary + workload and come
-            # from the committed rocprofv3 PMC pass of this same workload; the launch time is this run's
+            # issue side: wave-instruction counts per launch are a property of binary + workload and come from the committed rocprofv3 PMC
+            # pass of this same workload (profiles/r03_pmc.json); the launch time is this run's
             try:
                 if cfg == "cfg3" and args.scene == "bench" and P == 200000 and (args.width, args.height) == (1352, 1014) and loss == "l1" and not dn:
-                    pm = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc.json")))
+                    pm = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc.json")))
                     vi = {}
-                    for k in ("blend_fwd", "blend_bwd"):
-                        if k in pm and per.get(k, 0) > 0:
-                            insts = pm[k]["SQ_INSTS_VALU"]
-                            vi[k] = {"valu_wave_insts_per_launch": insts,
-                                     "issue_frac": insts * 2.6 / 1024.0 / (per[k] * 1e-3 * 2.4e9)}
-                    roof["valu_issue"] = dict(vi, note="SQ_INSTS_VALU per launch from profiles/r02_pmc.json (not counted in this process) x 2.6 cycles per "
-                                              "wave64 instruction and SIMD (tools/ubench/valu_rate, profiles/r02_ubench_valu_rate.txt) / 1024 SIMDs / "
-                                              "(this run's launch time x 2.4 GHz peak clock)")
+                    for k in ("blend_step", "blend_fwd", "blend_bwd"):
+                        if k in pm and per.get(k, 0) > 0 and "SQ_INSTS_VALU" in pm[k]:
+                            insts = sum(pm[k].get(c, 0.0) for c in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS"))
+                            vi[k] = {"wave_insts_per_launch": insts, "valu": pm[k]["SQ_INSTS_VALU"], "salu": pm[k].get("SQ_INSTS_SALU"),
+                                     "lds": pm[k].get("SQ_INSTS_LDS"), "issue_frac": insts * 2.5 / 1024.0 / (per[k] * 1e-3 * 2.4e9)}
+                    roof["issue"] = dict(vi, note="vector + scalar + LDS wave-instructions per launch from profiles/r03_pmc.json (NOT counted in this "
+                                         "process) x 2.5 cycles per instruction and SIMD -- scalar instructions cost an issue slot like vector ones "
+                                         "(tools/ubench/scalar_cost, profiles/r03_ubench_scalar_cost.txt) -- / 1024 SIMDs / (this run's launch time x "
+                                         "2.4 GHz peak clock)")
             except Exception:  # noqa: BLE001
                 pass
             out["roofline"] = roof

@@ -34,15 +34,16 @@ class RefineStepArgs(C.Structure):
                 ("loss_scratch", C.c_void_p),
                 ("out_images", C.c_void_p), ("radii", C.c_void_p), ("dL_dmean2D", C.c_void_p), ("loss_out", C.c_void_p),
                 ("require_coord", C.c_int), ("require_depth", C.c_int), ("clamp_grads", C.c_float),
-                ("color_grad_out", C.c_void_p), ("scratch_clean", C.c_int)]
+                ("color_grad_out", C.c_void_p), ("scratch_clean", C.c_int),
+                ("gt_stats", C.c_void_p), ("gt_stats_valid", C.c_int), ("color_ready_event", C.c_void_p)]
 
 
 EXPORTS = ["igs_rast_version", "igs_rast_last_error", "igs_rast_forward", "igs_rast_backward_workspace_bytes",
            "igs_rast_forward_async", "igs_rast_forward_finish", "igs_rast_forward_nowait", "igs_rast_last_status", "igs_rast_hint_scratch_clean", "igs_rast_set_slab_hint", "igs_rast_get_slab_hint", "igs_rast_backward", "igs_rast_mark_visible", "igs_rast_debug_dump",
-           "igs_rast_profile_enable", "igs_rast_profile_read", "igs_adam_step", "igs_adam_step_groups", "igs_densify_stats", "igs_densify_remap", "igs_refine_step", "igs_refine_loss_scratch_bytes", "igs_ssim_l1_scratch_bytes", "igs_ssim_l1_loss_fwd_bwd", "igs_depth_normal_loss_fwd_bwd", "igs_l1_loss_fwd_bwd", "igs_activate_fwd", "igs_activate_bwd",
-           "igs_sh_grad_from_view_colors", "igs_adam_sh_from_view_colors", "igs_rast_last_backward_instance", "igs_refine_step_args_size", "igs_rast_debug_poison_lds", "igs_adam_exchange_step"]
+           "igs_rast_profile_enable", "igs_rast_profile_read", "igs_adam_step", "igs_adam_step_groups", "igs_densify_stats", "igs_densify_remap", "igs_refine_step", "igs_refine_loss_scratch_bytes", "igs_ssim_l1_scratch_bytes", "igs_ssim_l1_loss_fwd_bwd", "igs_ssim_l1_loss_fwd_bwd_cached", "igs_ssim_gt_stats_bytes", "igs_depth_normal_loss_fwd_bwd", "igs_l1_loss_fwd_bwd", "igs_activate_fwd", "igs_activate_bwd",
+           "igs_sh_grad_from_view_colors", "igs_adam_sh_from_view_colors", "igs_rast_last_backward_instance", "igs_refine_step_args_size", "igs_rast_debug_poison_lds", "igs_adam_exchange_step", "igs_morton_order", "igs_morton_order_scratch_bytes"]
 
-VERSION = 3       # IGS_RAST_VERSION this binding was written against (include/igs_rast.h)
+VERSION = 4       # IGS_RAST_VERSION this binding was written against (include/igs_rast.h)
 
 STAGES = ["preprocess", "depth_sort", "scan", "emit", "tile_sort", "ranges", "blend_fwd", "memset", "blend_bwd", "geom_bwd"]
 
@@ -128,6 +129,14 @@ def lib():
         L.igs_ssim_l1_scratch_bytes.argtypes = [_i, _i]
         L.igs_ssim_l1_loss_fwd_bwd.restype = _i
         L.igs_ssim_l1_loss_fwd_bwd.argtypes = [_vp, _i, _i, _vp, _vp, _f, _f, _vp, _vp, _vp]
+        L.igs_ssim_l1_loss_fwd_bwd_cached.restype = _i
+        L.igs_ssim_l1_loss_fwd_bwd_cached.argtypes = [_vp, _i, _i, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _i]
+        L.igs_ssim_gt_stats_bytes.restype = C.c_size_t
+        L.igs_ssim_gt_stats_bytes.argtypes = [_i, _i]
+        L.igs_morton_order_scratch_bytes.restype = C.c_size_t
+        L.igs_morton_order_scratch_bytes.argtypes = [_i]
+        L.igs_morton_order.restype = _i
+        L.igs_morton_order.argtypes = [_vp, _i, _vp, _vp, _i, _vp, _vp]
         L.igs_depth_normal_loss_fwd_bwd.restype = _i
         L.igs_depth_normal_loss_fwd_bwd.argtypes = [_vp, _i, _i, _f, _f, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp]
         L.igs_l1_loss_fwd_bwd.restype = _i

@@ -638,6 +638,12 @@ static int backward_impl(
     if (fuse) {
         RefineFuse f = *fuse;
         if (!f.loss_shards) f.loss_shards = loss_shards;
+        if (f.color_event && f.color_out && f.grad_out) {
+            // N > 1: this view's colour gradients leave one kernel early, the all-gather runs underneath the per-Gaussian kernel
+            HIP_TRY(launch_extract_view_colors(s, P, radii, ba.rec, gacc, gacc_compact ? 1 : 0, shs != nullptr && M > 0, f.color_out), "extract_view_colors launch");
+            HIP_TRY(hipEventRecord((hipEvent_t)f.color_event, s), "record colour event");
+            f.color_out = nullptr; f.colors_extracted = 1;
+        }
         HIP_TRY(launch_geom_bwd_adam(s, ga, f), "geom_bwd_adam launch");
     } else {
         HIP_TRY(launch_geom_bwd(s, ga), "geom_bwd launch");
@@ -708,6 +714,7 @@ extern "C" int igs_refine_step(const igs_refine_step_args* a)
     f.lr_opacity = (float)(a->lr_opacity / bc1); f.lr_scale = (float)(a->lr_scale / bc1);
     f.clamp = a->clamp_grads;
     f.color_out = a->color_grad_out;
+    f.color_event = a->color_ready_event;
     f.b1 = a->beta1; f.b2 = a->beta2; f.eps = a->eps; f.inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
     const float inv_n = 1.0f / (float)(3 * HW);
     const bool dssim = a->lambda_dssim > 0.f;
@@ -777,7 +784,7 @@ extern "C" int igs_refine_step(const igs_refine_step_args* a)
         if (dssim) {
             prof_mark((hipStream_t)a->stream, ST_GAP);
             if (launch_ssim_l1((hipStream_t)a->stream, a->width, a->height, color, a->gt, a->lambda_dssim, a->loss_weight, a->loss_scratch,
-                               grad_img, false) != hipSuccess)
+                               grad_img, false, a->gt_stats, a->gt_stats_valid != 0) != hipSuccess)
                 return fail(IGS_RAST_E_HIP, "ssim loss launch");
             prof_mark((hipStream_t)a->stream, ST_MEMSET);          // (the stage slot the fused step does not otherwise use: "loss")
         }
@@ -802,6 +809,18 @@ extern "C" int igs_refine_step(const igs_refine_step_args* a)
         // a tile overflowed its slab: the guarded update kernel has done nothing; go again with the enlarged slabs
     }
     return fail(IGS_RAST_E_INVALID, "igs_refine_step: internal retry failure");
+}
+
+// Morton order of the Gaussians' positions (sort.hip): perm[i] = index of the Gaussian that comes i-th along the Z-order curve of
+// xyz quantised to `bits` bits per axis inside the box lohi = {lo.x, lo.y, lo.z, hi.x, hi.y, hi.z} (device memory).
+extern "C" size_t igs_morton_order_scratch_bytes(int P) { return morton_scratch_bytes(P) + 256; }
+extern "C" int igs_morton_order(void* stream, int P, const float* xyz, const float* lohi, int bits, void* scratch, int* perm)
+{
+    if (P < 0 || bits < 1 || bits > 10) return fail(IGS_RAST_E_INVALID, "igs_morton_order: bad sizes (1..10 bits per axis)");
+    if (P == 0) return 0;
+    if (!xyz || !lohi || !scratch || !perm) return fail(IGS_RAST_E_INVALID, "igs_morton_order: NULL pointer");
+    HIP_TRY(launch_morton_order((hipStream_t)stream, P, xyz, lohi, bits, scratch, perm), "morton order launch");
+    return 0;
 }
 
 extern "C" int igs_rast_mark_visible(void* stream, int P, const float* means3D, const float* viewmatrix,

@@ -134,6 +134,8 @@ hipError_t launch_mark_visible(hipStream_t s, int P, const float* means3D, const
 // except table 0, which the producer of keys_a filled with the first pass's per-block digit counts.
 hipError_t radix_sort_pairs(hipStream_t s, uint32_t n, uint32_t* keys_a, uint32_t* keys_b, uint32_t* vals_a, uint32_t* vals_b,
                             uint32_t* hist, int bit_lo, int bit_hi, uint32_t** out_keys, uint32_t** out_vals);
+size_t morton_scratch_bytes(int P);
+hipError_t launch_morton_order(hipStream_t s, int P, const float* xyz, const float* lohi, int bits, void* scratch, int* perm);
 hipError_t launch_count_sorted(hipStream_t s, int P, const uint32_t* order, const uint32_t* tiles, uint32_t* blocksum);
 hipError_t launch_scan_blocksums(hipStream_t s, int nblocks, uint32_t* blocksum);
 hipError_t launch_emit_instances(hipStream_t s, int P, int gx, int gy, const uint32_t* order, const uint32_t* tiles,
@@ -200,10 +202,15 @@ struct RefineFuse {
     float loss_scale, loss_scale2, loss_scale3, loss_bias;
     int prezeroed;                                                         // the accumulators were zero-filled by the forward
     int blend_done = 0;                                                    // the blend backward already ran inside the forward's tile kernel (blend_step.hip)
+    // N > 1: the view's colour gradients are final as soon as the blend backward is done -- backward_impl extracts them into color_out
+    // right there and records `color_event` on the stream, so that the ranks' all-gather can run underneath the per-Gaussian kernel
+    void* color_event = nullptr;
+    int colors_extracted = 0;                                              // (set by backward_impl for the per-Gaussian kernel: color_out is already written)
     float* color_out = nullptr;                                            // [P][3] non-NULL: also write dL/d(colour) of this view (clamped channels and
                                                                            // invisible Gaussians zero): what the N > 1 exchange gathers instead of dL/dSH
 };
 hipError_t launch_geom_bwd_adam(hipStream_t s, const GeomBwdArgs& a, const RefineFuse& f);
+hipError_t launch_extract_view_colors(hipStream_t s, int P, const int* radii, const float* rec, const float* gacc, int gacc_compact, bool have_sh, float* color_out);
 #define IGS_MAX_EXCHANGE_VIEWS 64
 hipError_t launch_sh_grad_views(hipStream_t s, int P, int D, int M, int V, const float* means3D, const float* campos_host, const float* gc,
                                 float clamp, float* dsh_out);
@@ -216,7 +223,7 @@ hipError_t launch_depth_normal(hipStream_t s, int W, int H, float fx, float fy, 
                                float weight, float depth_ratio, float* g_depth, float* g_mdepth, float* g_normal, float* loss_shards);
 // 0.8 L1 + 0.2 (1 - SSIM)-style loss, forward + backward (loss_ops.hip); scratch: igs_ssim_l1_scratch_bytes
 hipError_t launch_ssim_l1(hipStream_t s, int W, int H, const float* pred, const float* gt, float lambda_dssim, float weight,
-                          void* scratch, float* grad, bool zero_shards);
+                          void* scratch, float* grad, bool zero_shards, float* gt_stats = nullptr, bool gt_stats_valid = false);
 
 // ---------------------------------------------------------------------------------------------
 // device helpers

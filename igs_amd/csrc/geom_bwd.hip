@@ -727,7 +727,7 @@ geom_bwd_kernel(const GBArgs args)
             small_group(fz.off_scale, 3, 8, fz.lr_scale);
         }
         // N > 1 colour exchange: the SH gradient of the step is rebuilt from the gathered colour gradients, this view's is not needed
-        const bool skip_sh = FUSED && fz.grad_out && fz.color_out;
+        const bool skip_sh = FUSED && fz.grad_out && (fz.color_out || fz.colors_extracted);
         if (!skip_sh) {
         const int total = ng * F;
         float* dst = FUSED ? fz.param + fz.off_sh + (size_t)g0 * F : a.dL_dsh + (size_t)g0 * F;
@@ -808,5 +808,30 @@ hipError_t launch_geom_bwd_adam(hipStream_t s, const GeomBwdArgs& a, const Refin
     const int cap = GEOM_ADAM_BLOCKS;
     if (blocks > cap) blocks = cap;
     hipLaunchKernelGGL((geom_bwd_kernel<true, NT>), dim3(blocks), dim3(NT), lds, s, g);
+    return hipGetLastError();
+}
+
+// dL/d(colour) of this view per Gaussian, straight from the blend backward's accumulator rows (moments 0..2), with the semantics of the
+// per-Gaussian kernel's `color_out`: channels the SH evaluation clamped at zero (forward.cu:71-73 -> backward.cu:36-40) and
+// Gaussians the view does not see give zero.  Lets the N > 1 exchange start one kernel earlier (RefineFuse::color_event).
+__global__ void __launch_bounds__(256)
+extract_view_colors_kernel(int P, const int* __restrict__ radii, const float* __restrict__ rec, const float* __restrict__ gacc,
+                           int stride, int have_sh, float* __restrict__ color_out)
+{
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= P) return;
+    float3 c = make_float3(0.f, 0.f, 0.f);
+    if (have_sh && radii[idx] > 0) {
+        const float4 g = *(const float4*)(gacc + (size_t)idx * stride);
+        const uint32_t clamped = __float_as_uint(rec[(size_t)idx * REC_F + 30]);      // record word 7.z (preprocess.hip)
+        c = make_float3((clamped & 1u) ? 0.f : g.x, (clamped & 2u) ? 0.f : g.y, (clamped & 4u) ? 0.f : g.z);
+    }
+    color_out[3 * (size_t)idx] = c.x; color_out[3 * (size_t)idx + 1] = c.y; color_out[3 * (size_t)idx + 2] = c.z;
+}
+hipError_t launch_extract_view_colors(hipStream_t s, int P, const int* radii, const float* rec, const float* gacc, int gacc_compact, bool have_sh,
+                                      float* color_out)
+{
+    hipLaunchKernelGGL(extract_view_colors_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, radii, rec, gacc,
+                       gacc_compact ? GACC_COMPACT_F : GACC_F, have_sh ? 1 : 0, color_out);
     return hipGetLastError();
 }

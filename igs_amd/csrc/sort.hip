@@ -573,3 +573,57 @@ hipError_t launch_compact_lists(hipStream_t s, uint32_t T, const uint32_t* range
         hipLaunchKernelGGL(compact_lists_kernel, dim3(T), dim3(256), 0, s, ranges_in, ranges_out, list_in, list_out, out_capacity);
     return hipGetLastError();
 }
+
+// ---- Morton (Z-order) ordering of the Gaussians' positions (GaussianParams.spatial_sort; no reference counterpart: the binning
+// stage reserves its slots per (workgroup, tile), which pays when consecutive Gaussians project to neighbouring tiles) ----------
+// key = 3 x `bits` interleaved bits of the position quantised inside the bounding box lohi = {lo.xyz, hi.xyz} (device memory: no
+// host read-back); written with the identity permutation and the first radix pass's per-block histogram, then sorted by the
+// library's own stable LSD radix sort -- the order torch.argsort(code, stable=True) gives.
+__device__ __forceinline__ uint32_t spread3(uint32_t v)
+{
+    v = (v | (v << 16)) & 0x30000FFu;
+    v = (v | (v << 8)) & 0x300F00Fu;
+    v = (v | (v << 4)) & 0x30C30C3u;
+    return (v | (v << 2)) & 0x9249249u;
+}
+__global__ void __launch_bounds__(256)
+morton_keys_kernel(int P, const float* __restrict__ xyz, const float* __restrict__ lohi, int bits, uint32_t* __restrict__ keys,
+                   uint32_t* __restrict__ vals, uint32_t* __restrict__ hist0, uint32_t per_block)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= P) return;
+    const float top = (float)((1u << bits) - 1u);
+    uint32_t q[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const float lo = lohi[k], ext = fmaxf(lohi[3 + k] - lo, 1e-12f);
+        const float t = (xyz[3 * (size_t)i + k] - lo) / ext * top;          // (same expression, same order as the PyTorch form it replaces)
+        const long long v = (long long)t;                                     // truncation towards zero, as .long()
+        q[k] = (uint32_t)(v < 0 ? 0 : (v > (long long)top ? (long long)top : v));
+    }
+    const uint32_t code = spread3(q[0]) | (spread3(q[1]) << 1) | (spread3(q[2]) << 2);
+    keys[i] = code; vals[i] = (uint32_t)i;
+    atomicAdd(&hist0[((uint32_t)i / per_block) * RADIX + (code & 255u)], 1u);
+}
+size_t morton_scratch_bytes(int P)
+{
+    const size_t n = (size_t)(P > 0 ? P : 0);
+    return 4 * ((n * 4 + 255) & ~(size_t)255) + (size_t)SORT_MAX_PASSES * RADIX * SORT_MAX_BLOCKS * 4 + 256;
+}
+hipError_t launch_morton_order(hipStream_t s, int P, const float* xyz, const float* lohi, int bits, void* scratch, int* perm)
+{
+    if (P <= 0) return hipSuccess;
+    const size_t seg = ((size_t)P * 4 + 255) & ~(size_t)255;
+    char* b = (char*)(((uintptr_t)scratch + 255) & ~(uintptr_t)255);
+    uint32_t *ka = (uint32_t*)b, *kb = (uint32_t*)(b + seg), *va = (uint32_t*)(b + 2 * seg), *vb = (uint32_t*)(b + 3 * seg);
+    uint32_t* hist = (uint32_t*)(b + 4 * seg);
+    hipError_t e = zero_fill_async(s, hist, (size_t)SORT_MAX_PASSES * RADIX * SORT_MAX_BLOCKS * 4);
+    if (e != hipSuccess) return e;
+    uint32_t nb, per;
+    sort_geometry((uint32_t)P, &nb, &per);
+    hipLaunchKernelGGL(morton_keys_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, xyz, lohi, bits, ka, va, hist, per);
+    uint32_t *sk = nullptr, *sv = nullptr;
+    e = radix_sort_pairs(s, (uint32_t)P, ka, kb, va, vb, hist, 0, 3 * bits, &sk, &sv);
+    if (e != hipSuccess) return e;
+    return hipMemcpyAsync(perm, sv, (size_t)P * 4, hipMemcpyDeviceToDevice, s);
+}

@@ -73,17 +73,19 @@ class GaussianParams:
         the order (apart from which of two splats at EXACTLY the same depth comes first); `self.order[i]` is the index Gaussian i
         had when the store was created -- `original_order()` undoes every sort so far."""
         import ctypes as C
-        xyz = self.leaves["xyz"].detach()
-        lo, hi = xyz.min(dim=0).values, xyz.max(dim=0).values
-        q = ((xyz - lo) / (hi - lo).clamp(min=1e-12) * (2 ** bits - 1)).long().clamp(0, 2 ** bits - 1)
-
-        def spread(v):
-            v = (v | (v << 16)) & 0x30000FF
-            v = (v | (v << 8)) & 0x300F00F
-            v = (v | (v << 4)) & 0x30C30C3
-            return (v | (v << 2)) & 0x9249249
-        code = spread(q[:, 0]) | (spread(q[:, 1]) << 1) | (spread(q[:, 2]) << 2)
-        perm = torch.argsort(code, stable=True).to(torch.int32).contiguous()
+        xyz = self.leaves["xyz"].detach().contiguous()
+        lohi = torch.cat([xyz.min(dim=0).values, xyz.max(dim=0).values]).contiguous()      # stays on the device: no host read-back
+        Lb = _cabi.lib()
+        perm = torch.empty(self.P, dtype=torch.int32, device=self.device)
+        need = Lb.igs_morton_order_scratch_bytes(self.P)
+        if getattr(self, "_morton_scratch", None) is None or self._morton_scratch.numel() < need:
+            self._morton_scratch = torch.empty(need, dtype=torch.uint8, device=self.device)
+        with torch.cuda.device(self.device):
+            # keys, identity and the stable radix sort are the library's own (sort.hip); same order as torch.argsort(code, stable=True)
+            rc = Lb.igs_morton_order(torch.cuda.current_stream(self.device).cuda_stream, self.P, xyz.data_ptr(), lohi.data_ptr(), bits,
+                                     self._morton_scratch.data_ptr(), perm.data_ptr())
+        if rc != 0:
+            raise RuntimeError("igs_morton_order failed: %d" % rc)
         P = self.P
         new = [torch.empty_like(self.flat) for _ in range(3)]
         off = (C.c_size_t * 5)(*[self.spans[n][0] for n in ("xyz", "rotation", "shs", "opacity", "scaling")])
@@ -210,6 +212,49 @@ class L1Fused:
         return self.loss_sum        # 64 partial sums of |pred - gt| at [::16] (call .sum() when the value is needed)
 
 
+class GtStatsCache:
+    """blur(gt), blur(gt^2) of the SSIM loss per ground-truth image (`gt_stats` of include/igs_rast.h): the reference recomputes them in
+    every iteration (loss_utils.py:34-63) although a view's ground truth does not change while a frame is refined (50 iterations
+    over 10 views: every view comes back five times).  One buffer per view, recycled from frame to frame through a pool per
+    (H, W, device).  `get(view, gt)` returns (pointer, valid): valid is 0 on the first visit of this ground-truth tensor -- the
+    call that then FILLS the buffer -- and 1 afterwards."""
+    _pool = {}          # (H, W, device) -> free buffers
+    KEEP = 32
+
+    def __init__(self, device):
+        self.device = device
+        self.entries = {}          # view -> [buffer, identity of the gt it holds, pool key]
+
+    def get(self, view, gt):
+        H, W = int(gt.shape[-2]), int(gt.shape[-1])
+        ident = (gt.data_ptr(), gt._version, H, W)
+        e = self.entries.get(view)
+        if e is not None and e[1] == ident:
+            return e[0].data_ptr(), 1
+        if e is None or e[2] != (H, W, str(self.device)):
+            if e is not None:
+                self._give_back(e)
+            pk = (H, W, str(self.device))
+            free = GtStatsCache._pool.setdefault(pk, [])
+            buf = free.pop() if free else torch.empty(_cabi.lib().igs_ssim_gt_stats_bytes(W, H) // 4, dtype=torch.float32, device=self.device)
+            e = self.entries[view] = [buf, None, pk]
+        e[1] = ident
+        return e[0].data_ptr(), 0
+
+    @staticmethod
+    def _give_back(e):
+        free = GtStatsCache._pool.setdefault(e[2], [])
+        if len(free) < GtStatsCache.KEEP:
+            free.append(e[0])
+
+    def __del__(self):
+        try:
+            for e in self.entries.values():
+                self._give_back(e)
+        except Exception:  # noqa: BLE001  (interpreter shutdown)
+            pass
+
+
 class L1SsimFused:
     """(1 - lambda) L1 + lambda (1 - SSIM), forward + backward in two HIP launches (igs_ssim_l1_loss_fwd_bwd)."""
 
@@ -218,15 +263,17 @@ class L1SsimFused:
         self.scratch, self.key = None, None
         self.sums = torch.zeros(2048, dtype=torch.float32, device=device)
 
-    def __call__(self, pred, gt, grad_out, weight=1.0):
+    def __call__(self, pred, gt, grad_out, weight=1.0, gt_stats=None):
+        """`gt_stats`: (pointer, valid) from a GtStatsCache -- the ground truth's own SSIM statistics are then cached / reused."""
         L = _cabi.lib()
         H, W = int(pred.shape[-2]), int(pred.shape[-1])
         if self.key != (H, W):
             self.key = (H, W)
             self.scratch = torch.empty(L.igs_ssim_l1_scratch_bytes(W, H), dtype=torch.uint8, device=self.device)
-        rc = L.igs_ssim_l1_loss_fwd_bwd(torch.cuda.current_stream(self.device).cuda_stream, W, H, pred.data_ptr(), gt.data_ptr(),
-                                        self.lambda_dssim, float(weight), self.scratch.data_ptr(), grad_out.data_ptr(),
-                                        self.sums.data_ptr())
+        ptr, valid = gt_stats if gt_stats is not None else (None, 0)
+        rc = L.igs_ssim_l1_loss_fwd_bwd_cached(torch.cuda.current_stream(self.device).cuda_stream, W, H, pred.data_ptr(), gt.data_ptr(),
+                                               self.lambda_dssim, float(weight), self.scratch.data_ptr(), grad_out.data_ptr(),
+                                               self.sums.data_ptr(), ptr, valid)
         if rc != 0:
             raise RuntimeError("igs_ssim_l1_loss_fwd_bwd failed: %d" % rc)
         return self.sums
@@ -251,6 +298,8 @@ class Refiner:
         self.render_fn = render if render_fn is None else render_fn
         self.adam_fn = params.adam_step if adam_fn is None else adam_fn
         self.l1 = L1Fused(params.device) if loss == "l1" else L1SsimFused(params.device, 1.0 - lambda_l1)
+        self.gt_stats = GtStatsCache(params.device) if loss != "l1" else None      # the ground truth's SSIM statistics, per view (GtStatsCache)
+        self.cache_gt_stats = True
         # RaDe-GS depth-normal regulariser (train.py:143-164; BASELINE cfg-5 uses 0.05): needs dL/d depth, mdepth, normal -- the
         # fused step evaluates it in one HIP launch and runs the <depth, normal> backward instance; the unfused native path does
         # not implement it (the autograd path does, through igs_amd/regularizers.py)
@@ -309,7 +358,13 @@ class Refiner:
         picks = []
         for _ in range(self.world_size):
             if not self.order:
-                self.order = torch.randperm(len(self.cams), generator=self.gen).tolist()
+                order = torch.randperm(len(self.cams), generator=self.gen).tolist()
+                # a step that straddles two passes over the views (10 views on 8 ranks: the second step takes the 2 left over and 6 of
+                # the next pass) must not hold a view twice while there are enough views: the ones this step already has are drawn
+                # LAST from the new pass (pop() takes from the end).  Same generator on every rank -> same order everywhere.
+                if picks and len(self.cams) >= self.world_size:
+                    order = [v for v in order if v in picks] + [v for v in order if v not in picks]
+                self.order = order
             picks.append(self.order.pop())
         self.last_picks = picks          # the views of every rank this step (same permutation everywhere)
         return picks[self.rank]
@@ -343,7 +398,10 @@ class Refiner:
             nr, color, coord, mcoord, alpha, normal, depth, mdepth, radii, gb, bb, ib = out
             if self.grad_img is None or self.grad_img.shape != color.shape:
                 self.grad_img = torch.empty_like(color)
-            self.l1(color, gt, self.grad_img, weight=1.0 / self.world_size)      # L1 or L1 + D-SSIM, fused fwd + bwd
+            if self.gt_stats is not None and self.cache_gt_stats and getattr(self, "_view", None) is not None:
+                self.l1(color, gt, self.grad_img, weight=1.0 / self.world_size, gt_stats=self.gt_stats.get(self._view, gt))
+            else:
+                self.l1(color, gt, self.grad_img, weight=1.0 / self.world_size)      # L1 or L1 + D-SSIM, fused fwd + bwd
             G = p.grad
             def span(name, shape):
                 o, n = p.spans[name]
@@ -370,7 +428,7 @@ class Refiner:
         return dict(images_pred=color, radii=radii, visibility_filter=None, viewspace_points=outs["means2D"], alpha=alpha,
                     depth_pred=depth, normal=normal)
 
-    def _fused_step(self, cam, gt, grads_only=False, color_out=None):
+    def _fused_step(self, cam, gt, grads_only=False, color_out=None, color_event=None):
         """Single-GPU step entirely inside the library: `igs_refine_step` (include/igs_rast.h) -- activations, render, L1,
         backward and the Adam update in 5 launches; no gradient array is materialised."""
         import ctypes as C
@@ -409,6 +467,8 @@ class Refiner:
                 self._loss_scratch = torch.empty(L.igs_refine_loss_scratch_bytes(W, H), dtype=torch.uint8, device=dev)
             a.lambda_dssim = (1.0 - self.lambda_l1) if self.loss == "l1_ssim" else 0.0
             a.loss_scratch = self._loss_scratch.data_ptr()
+            if self.loss == "l1_ssim" and self.gt_stats is not None and self.cache_gt_stats and getattr(self, "_view", None) is not None:
+                a.gt_stats, a.gt_stats_valid = self.gt_stats.get(self._view, gt)
         else:
             a.lambda_dssim, a.loss_scratch = 0.0, None
         a.out_images, a.radii = imgs.data_ptr(), radii.data_ptr()
@@ -417,6 +477,11 @@ class Refiner:
         a.require_coord, a.require_depth = rq, rq
         a.clamp_grads = 15.0 if getattr(self, "clamp", False) else 0.0
         a.color_grad_out = color_out.data_ptr() if color_out is not None else None
+        if color_event is not None:
+            h = color_event.cuda_event                         # ctypes.c_void_p of the hipEvent_t
+            a.color_ready_event = getattr(h, "value", h)
+        else:
+            a.color_ready_event = None
         a.scratch_clean = 0 if os.environ.get("IGS_SCRATCH_CLEAN") == "0" else 1      # (RasterBuffers: zero-filled at allocation, touched by this library only)
         with torch.cuda.device(dev):
             nr = L.igs_refine_step(C.byref(a))
@@ -476,12 +541,31 @@ class Refiner:
             self._gc = torch.zeros((N, P, 3), dtype=torch.float32, device=dev)
             self._gc_mine = torch.zeros((P, 3), dtype=torch.float32, device=dev)
             self._campos_host = {}
-        pkg = self._fused_step(cam, gt, grads_only=True, color_out=self._gc_mine)
-        with self._Timed(self):
+        # The view's colour gradients are final right after the blend backward, one kernel before the step ends: the library writes them
+        # there and records an event (igs_refine_step_args::color_ready_event); the all-gather waits for THAT on a side stream and runs
+        # underneath the per-Gaussian kernel (geom_bwd, ~70 us) instead of behind it.  `overlap_exchange = False`: gather after the step.
+        overlap = getattr(self, "overlap_exchange", True) and dev.type == "cuda"
+        if overlap and getattr(self, "_color_event", None) is None:
+            self._color_event = torch.cuda.Event()
+            self._color_event.record(torch.cuda.current_stream(dev))       # (creates the hipEvent_t the library will record)
+            self._comm_stream = torch.cuda.Stream(device=dev)
+        pkg = self._fused_step(cam, gt, grads_only=True, color_out=self._gc_mine, color_event=self._color_event if overlap else None)
+
+        def gather():
             if dist.get_backend() == "nccl":
                 dist.all_gather_into_tensor(self._gc.view(-1), self._gc_mine.view(-1))      # RCCL: straight into the [N,P,3] buffer
             else:
                 dist.all_gather(list(self._gc.unbind(0)), self._gc_mine)
+        if overlap:
+            main = torch.cuda.current_stream(dev)
+            self._comm_stream.wait_event(self._color_event)
+            with torch.cuda.stream(self._comm_stream):
+                gather()
+            with self._Timed(self):
+                main.wait_stream(self._comm_stream)                    # (what is left of the gather once geom_bwd is done)
+        else:
+            with self._Timed(self):
+                gather()
         import ctypes as C
         for v in picks:
             if v not in self._campos_host:          # (one device read per camera, the first time it is used)
@@ -543,6 +627,7 @@ class Refiner:
         if view is None:
             view = self._next_view()
         cam, gt = self.cams[view], self.gt[view]
+        self._view = view
         native_ok = self.native and self.render_fn is render and (self.fused or self.lambda_depth_normal == 0.0)
         if self.densify is not None and not (native_ok and self.adam_fn == p.adam_step):
             raise NotImplementedError("densify-and-prune is implemented for the native path with the library's optimiser only "

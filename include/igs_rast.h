@@ -45,7 +45,7 @@
 extern "C" {
 #endif
 
-#define IGS_RAST_VERSION 3
+#define IGS_RAST_VERSION 4
 
 #define IGS_RAST_E_INVALID   (-1)   /* bad argument (NULL required pointer, negative size, ...) */
 #define IGS_RAST_E_HIP       (-2)   /* a HIP runtime call or kernel launch failed */
@@ -293,6 +293,15 @@ typedef struct igs_refine_step_args {
                                                  it was allocated and has since been used by this library only (every slab-binned forward
                                                  leaves the binning counters in it zeroed again): the per-frame zero-fill launch is skipped.
                                                  0: no assumption (a fresh, uninitialised buffer is fine) */
+    float* gt_stats;                          /* lambda_dssim > 0, optional (NULL = off): igs_ssim_gt_stats_bytes(width, height) bytes that belong to
+                                                 THIS ground-truth image.  loss_utils.py:34-63 blurs gt and gt^2 again in every iteration; with a
+                                                 buffer the step that finds gt_stats_valid == 0 stores the two maps in it and every later step on the
+                                                 same gt (gt_stats_valid != 0) reads them instead of recomputing them -- same values, 3 blurs for 5 */
+    int gt_stats_valid;
+    void* color_ready_event;                  /* optional hipEvent_t (with grad_out and color_grad_out, multi-GPU): color_grad_out is then written
+                                                 right after the blend backward -- one kernel before the step ends -- and this event is recorded on
+                                                 `stream` behind it, so that the caller can start the all-gather of the colour gradients on another
+                                                 stream underneath the per-Gaussian kernel.  NULL: written by the last kernel of the step */
 } igs_refine_step_args;
 int igs_refine_step(const igs_refine_step_args* args);
 size_t igs_refine_step_args_size(void);       /* sizeof(igs_refine_step_args) of the loaded library: bindings check it before the first call */
@@ -329,6 +338,13 @@ size_t igs_refine_loss_scratch_bytes(int width, int height);
 size_t igs_ssim_l1_scratch_bytes(int width, int height);
 int igs_ssim_l1_loss_fwd_bwd(void* stream, int width, int height, const float* pred, const float* gt, float lambda_dssim, float weight,
                              void* scratch, float* grad, float* sums);
+/* The same with a cache of the two statistics that depend on the ground truth alone, blur(gt) and blur(gt^2) (the reference blurs them
+ * again in every iteration; gt does not change while a frame is refined): `gt_stats` = igs_ssim_gt_stats_bytes(width, height) bytes
+ * owned by the caller, one buffer per ground-truth image.  gt_stats_valid == 0: computed as usual AND stored; != 0: read (3 blurs
+ * instead of 5).  Same values either way.  gt_stats == NULL: igs_ssim_l1_loss_fwd_bwd. */
+size_t igs_ssim_gt_stats_bytes(int width, int height);
+int igs_ssim_l1_loss_fwd_bwd_cached(void* stream, int width, int height, const float* pred, const float* gt, float lambda_dssim, float weight,
+                                    void* scratch, float* grad, float* sums, float* gt_stats, int gt_stats_valid);
 
 /* RaDe-GS depth-normal consistency regulariser, value and gradients in one launch
  * (submodules/RaDe-GS/utils/graphics_utils.py:97-126, train.py:143-160):
@@ -344,6 +360,14 @@ int igs_depth_normal_loss_fwd_bwd(void* stream, int width, int height, float tan
  * sum |pred - gt| is accumulated into 64 shards loss_sum[16*s], s = 0..63 (1024 floats, zeroed by the caller, summed by
  * the caller: same-address atomics would serialise). */
 int igs_l1_loss_fwd_bwd(void* stream, size_t n, const float* pred, const float* gt, float* grad, float* loss_sum, float scale);
+
+/* Morton (Z-order) permutation of the Gaussians' positions (extension, no reference counterpart; used by the refine loop's store so
+ * that consecutive Gaussians project to neighbouring tiles -- the binning stage then reserves instance slots once per (workgroup,
+ * tile) instead of once per instance).  perm[i] = index of the Gaussian that comes i-th; ties keep their order (stable radix sort
+ * of the library itself, no PyTorch / rocPRIM sort on the stream path).  lohi: {lo.xyz, hi.xyz} of the positions, 6 floats in
+ * DEVICE memory; bits: 1..10 per axis; scratch: igs_morton_order_scratch_bytes(P) bytes. */
+size_t igs_morton_order_scratch_bytes(int P);
+int igs_morton_order(void* stream, int P, const float* xyz, const float* lohi, int bits, void* scratch, int* perm);
 
 /* Densification support (igs/models/gaussian_model.py:586-663,865-868; driven by infer_batch.py:308-321).
  * igs_densify_stats: per-step statistics of add_densification_stats + the max_radii2D update, for Gaussians with radii > 0:

@@ -866,6 +866,33 @@ def test_fused_gradient_only_step_equals_unfused_native_step(dev):
             assert np.quantile(r, 0.999) < 2e-3 and np.median(r) < 1e-5, (loss, k, np.quantile(r, 0.999), np.median(r))
 
 
+def test_morton_order_equals_stable_argsort_of_the_codes(dev):
+    """igs_morton_order (the library's own keys + stable LSD radix sort: no PyTorch / rocPRIM sort on the stream path) against
+    torch.argsort(code, stable=True) of the same 30-bit Morton codes, incl. many equal keys (4 bits per axis) and P not a multiple of
+    anything."""
+    from igs_amd import _cabi
+    L = _cabi.lib()
+    gen = torch.Generator().manual_seed(5)
+    for P, bits in ((1, 10), (777, 10), (200003, 10), (50000, 4)):
+        xyz = (torch.randn(P, 3, generator=gen) * 3.0).to(dev).contiguous()
+        lo, hi = xyz.min(dim=0).values, xyz.max(dim=0).values
+        q = ((xyz - lo) / (hi - lo).clamp(min=1e-12) * (2 ** bits - 1)).long().clamp(0, 2 ** bits - 1)
+
+        def spread(v):
+            v = (v | (v << 16)) & 0x30000FF
+            v = (v | (v << 8)) & 0x300F00F
+            v = (v | (v << 4)) & 0x30C30C3
+            return (v | (v << 2)) & 0x9249249
+        code = spread(q[:, 0]) | (spread(q[:, 1]) << 1) | (spread(q[:, 2]) << 2)
+        want = torch.argsort(code, stable=True).to(torch.int32)
+        perm = torch.empty(P, dtype=torch.int32, device=dev)
+        scratch = torch.empty(L.igs_morton_order_scratch_bytes(P), dtype=torch.uint8, device=dev)
+        lohi = torch.cat([lo, hi]).contiguous()
+        assert L.igs_morton_order(torch.cuda.current_stream(dev).cuda_stream, P, xyz.data_ptr(), lohi.data_ptr(), bits, scratch.data_ptr(),
+                                  perm.data_ptr()) == 0
+        assert torch.equal(perm, want), (P, bits)
+
+
 def test_spatial_sort_keeps_results_and_aggregated_binning_is_exact(dev):
     """Morton reordering of the parameter store (one gather pass, Adam moments included): images are unchanged up to float
     summation order... in fact identical, because per pixel the splats are still blended in depth order; original_order()
@@ -1269,15 +1296,18 @@ def test_colour_gradient_exchange_rebuilds_the_sh_gradient_of_all_views(dev, cla
     torch.testing.assert_close(p.flat[sh0:sh0 + shn], w1, rtol=1e-5, atol=1e-6)
 
 
-def test_two_rank_colour_exchange_equals_flat_allreduce(dev):
-    """Two ranks (gloo, both on this GPU) through Refiner.step(): the colour-gradient exchange and the flat all-reduce leave the
-    same gradient and parameters, and the replicas stay bit-identical (tools/check_exchange.py; with RCCL the driver's run)."""
+@pytest.mark.parametrize("ranks", [2, 4])
+def test_two_rank_colour_exchange_equals_flat_allreduce(dev, ranks):
+    """Two / four ranks (gloo, all on this GPU) through Refiner.step(): the colour-gradient exchange and the flat all-reduce leave the
+    same gradient and parameters, the replicas stay bit-identical, and the exchange whose all-gather starts from the event recorded
+    right after the blend backward (side stream, underneath geom_bwd) equals the serial one (tools/check_exchange.py; with
+    RCCL the driver's run)."""
     import os, socket, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
-    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ranks), "--master-addr", "127.0.0.1",
                         "--master-port", str(port), os.path.join(root, "tools", "check_exchange.py"), "--backend", "gloo"],
                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300, env=env, cwd=root)
     assert r.returncode == 0 and "EXCHANGE_CHECK_OK" in r.stdout, r.stdout[-2000:]
@@ -1378,6 +1408,17 @@ def test_loss_kernels_match_reference_loss_utils_fixture(dev, golden_torch_only,
     np.testing.assert_allclose(0.8 * l1_mean + 0.2 * (1.0 - ssim_mean), g["loss_%s_total" % tag].item(), rtol=2e-5)
     G = g["loss_%s_grad" % tag]
     assert np.abs(grad.cpu().numpy() - G).max() <= 1e-4 * np.abs(G).max()
+    # the same with the ground truth's own statistics cached (igs_ssim_l1_loss_fwd_bwd_cached): the call that FILLS the buffer and the
+    # calls that READ it give what the uncached call gives (the same code computes blur(gt), blur(gt^2) in all three)
+    stats = torch.full((L.igs_ssim_gt_stats_bytes(W, H) // 4,), float("nan"), device=dev)
+    for valid in (0, 1, 1):
+        grad_c, sums_c = torch.empty_like(img), torch.empty(2048, device=dev)
+        rc = L.igs_ssim_l1_loss_fwd_bwd_cached(torch.cuda.current_stream(dev).cuda_stream, W, H, img.data_ptr(), gt.data_ptr(), 0.2, 1.0,
+                                               scratch.data_ptr(), grad_c.data_ptr(), sums_c.data_ptr(), stats.data_ptr(), valid)
+        assert rc == 0
+        # (to rounding: the three instances of the kernel are compiled separately, with the SLP vectoriser pairing their multiply-adds)
+        assert float((grad_c - grad).abs().max()) <= 2e-6 * float(grad.abs().max()) and not torch.isnan(stats).any()
+        assert abs(float(sums_c[:1024].sum()) - float(sums[:1024].sum())) <= 1e-6 * abs(float(sums[:1024].sum()))      # (shard order of the atomics)
     # the drop-in function with the reference's call shape, value and gradient of the SSIM part alone
     x = img.clone().requires_grad_(True)
     v = fused_ssim(x, gt.unsqueeze(0), size_average=False)

@@ -20,7 +20,7 @@ def test_cabi_library_exports_every_declared_symbol():
     assert {"igs_rast_forward", "igs_rast_backward", "igs_rast_mark_visible", "igs_rast_backward_workspace_bytes"} <= names
     for n in sorted(names):
         assert hasattr(L, n), "libigs_rast.so does not export %s" % n
-    assert L.igs_rast_version() == _cabi.VERSION == 3
+    assert L.igs_rast_version() == _cabi.VERSION == 4
     assert L.igs_refine_step_args_size() > 0
     assert L.igs_rast_backward_workspace_bytes(1000) >= 1000 * 25 * 4
     assert set(_cabi.EXPORTS) <= names | {"igs_rast_last_error", "igs_rast_version"}
@@ -112,12 +112,12 @@ def _torch_adam_on_flat(params):
     return step
 
 
-def _make_scene(P=64):
+def _make_scene(P=64, ncams=6):
     from igs_amd.scenes import cfg1_scene
     raw, _, _ = cfg1_scene(P=P, size=16)
     gen = torch.Generator().manual_seed(7)
-    cams = [dict(w=torch.randn(5, generator=gen)) for _ in range(6)]
-    gts = [torch.randn(1, P, 1, generator=gen) for _ in range(6)]
+    cams = [dict(w=torch.randn(5, generator=gen)) for _ in range(ncams)]
+    gts = [torch.randn(1, P, 1, generator=gen) for _ in range(ncams)]
     return raw, cams, gts
 
 
@@ -137,14 +137,15 @@ def test_flat_parameter_store_aliases_gradients():
     assert float(p.grad.abs().sum()) == 0.0 and float(p.leaves["xyz"].grad.abs().sum()) == 0.0
 
 
-def _rank_main(rank, world, port, q):
+def _rank_main(rank, world, port, q, ncams=6, steps=4):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     import torch.distributed as dist
+    torch.set_num_threads(1)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     sys.path.insert(0, ROOT)
     from igs_amd.refine import GaussianParams, Refiner
-    raw, cams, gts = _make_scene()
+    raw, cams, gts = _make_scene(ncams=ncams)
     p = GaussianParams(raw, torch.device("cpu"))
     r = Refiner(p, cams, gts, None, loss="l1_ssim_off", world_size=world, rank=rank, seed=3,
                 render_fn=_fake_render, adam_fn=_torch_adam_on_flat(p))
@@ -165,7 +166,7 @@ def _rank_main(rank, world, port, q):
         self.adam_fn()
         return view
     r.step = types.MethodType(step, r)
-    for _ in range(4):
+    for _ in range(steps):
         views.append(r.step())
     q.put((rank, views, p.flat.clone().numpy()))
     dist.barrier()
@@ -203,6 +204,44 @@ def test_view_sharding_and_gradient_allreduce_gloo_world2():
     np.testing.assert_allclose(p.flat.numpy(), f0, rtol=1e-5, atol=1e-7)
     # without-replacement sampling: the first 3 steps (6 draws) cover all 6 views once
     assert sorted(v0[:3] + v1[:3]) == list(range(6))
+
+
+def test_view_sharding_world8_with_10_views_refills_mid_step_gloo():
+    """N = 8 ranks over gloo with TEN views (BASELINE configs[3]'s shape: the permutation of the views runs out in the middle of every
+    other step): no step holds a view twice, every pass over the views uses each view once, the replicas stay bit-identical, and
+    they equal ONE process that applies the averaged gradient of the same eight views per step."""
+    import torch.multiprocessing as mp
+    world, ncams, steps = 8, 10, 5                           # 40 draws = 4 passes over the 10 views
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_rank_main, args=(r, world, port, q, ncams, steps)) for r in range(world)]
+    for pr in procs:
+        pr.start()
+    res = sorted([q.get(timeout=300) for _ in procs], key=lambda t: t[0])
+    for pr in procs:
+        pr.join(timeout=60)
+        assert pr.exitcode == 0
+    per_step = [[res[r][1][s] for r in range(world)] for s in range(steps)]
+    for s_, vs in enumerate(per_step):
+        assert len(set(vs)) == world, (s_, vs)               # eight DIFFERENT views in every step, also across a refill
+    flat_draws = [v for vs in per_step for v in vs]
+    for k in range(0, len(flat_draws), ncams):
+        assert sorted(flat_draws[k:k + ncams]) == list(range(ncams)), flat_draws[k:k + ncams]      # sampling without replacement per pass
+    for r in range(1, world):
+        np.testing.assert_array_equal(res[0][2], res[r][2])   # replicas stay identical without a broadcast
+    # single-process reference: the same eight views per step, averaged gradient
+    from igs_amd.refine import GaussianParams
+    raw, cams, gts = _make_scene(ncams=ncams)
+    p = GaussianParams(raw, torch.device("cpu"))
+    adam = _torch_adam_on_flat(p)
+    for vs in per_step:
+        p.zero_grad()
+        for v in vs:
+            img = _fake_render(p.activated(), cams[v], None)["images_pred"]
+            (torch.abs(img - gts[v]).mean() / world).backward()
+        adam()
+    np.testing.assert_allclose(p.flat.detach().numpy(), res[0][2], rtol=2e-5, atol=2e-6)
 
 
 def _densify_rank_main(rank, world, port, q):

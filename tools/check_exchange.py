@@ -63,16 +63,19 @@ def main():
         dist.destroy_process_group()
         sys.exit(0 if ok else 1)
     results = {}
-    for mode in ("gradients", "colors"):
+    # "colors": the gather starts from the event the library records right after the blend backward and runs underneath geom_bwd on a
+    # side stream; "colors_serial": the same exchange behind the last kernel of the step -- the two must agree (to rounding)
+    for mode in ("gradients", "colors", "colors_serial"):
         p = GaussianParams(raw, dev)
         r = Refiner(p, cams, gts, bg, loss=args.loss, world_size=world, rank=rank, seed=3)
-        r.exchange, r.clamp = mode, args.clamp
+        r.exchange, r.clamp = mode.split("_")[0], args.clamp
+        r.overlap_exchange = mode == "colors"
         for _ in range(3):
             if world > 1:
                 r.step()
             else:       # one rank: Refiner.step() would take the single-GPU path; drive the N > 1 code (and its collectives) by hand
                 view = r._next_view()
-                if mode == "colors":
+                if mode != "gradients":
                     r._colour_exchange_step(cams[view], gts[view], r.last_picks)
                 else:
                     r._fused_step(cams[view], gts[view], grads_only=True)
@@ -83,6 +86,14 @@ def main():
         # (the colour exchange applies the SH update without ever writing the SH gradient: compare the first moment instead)
         results[mode] = (p.grad[:sh0].clone(), p.exp_avg.clone(), p.flat.clone())
     ok = True
+    # (two runs of the same step differ in the last bits already -- the blend backward's float atomics land in another order -- so the
+    #  overlapped and the serial exchange are compared like the two modes: to rounding)
+    for i, what in enumerate(("small-group gradient", "first moment", "parameters")):
+        A, B = results["colors"][i], results["colors_serial"][i]
+        close = ((A - B).abs() <= 1e-5 * B.abs() + 1e-6 * float(B.abs().max())).float().mean().item()
+        if rank == 0:
+            print("%s: overlapped gather vs serial gather: within tolerance %.4f of the elements" % (what, close))
+        ok = ok and close > 0.999
     for i, what in enumerate(("small-group gradient", "first moment", "parameters")):
         A, B = results["colors"][i], results["gradients"][i]
         err = float((A - B).abs().max()); scale = float(B.abs().max())

@@ -8,7 +8,7 @@ side is doubled before it is compared with a byte count.
 import csv, glob, json, os, sys, collections
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-KEYS = {"blend_fwd": "blend_fwd_kernel", "blend_bwd": "blend_bwd_kernel", "preprocess": "preprocess_fwd_kernel",
+KEYS = {"blend_step": "blend_step_kernel", "blend_fwd": "blend_fwd_kernel", "blend_bwd": "blend_bwd_kernel", "preprocess": "preprocess_fwd_kernel",
         "geom_bwd": "geom_bwd_kernel", "radix_scatter": "radix_scatter_kernel", "radix_hist": "radix_hist_kernel",
         "emit": "emit_instances_kernel", "adam": "adam_groups_kernel", "l1": "l1_kernel", "tile_sort": "tile_sort_kernel",
         "activate_fwd": "activate_fwd_kernel", "activate_bwd": "activate_bwd_kernel"}
