@@ -17,7 +17,11 @@ static int fail(int code, const char* what, hipError_t e = hipSuccess)
     return code;
 }
 #define HIP_TRY(expr, what) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return fail(IGS_RAST_E_HIP, what, e_); } while (0)
-#define DBG_SYNC(what) do { if (debug) { hipError_t e_ = hipStreamSynchronize(s); if (e_ != hipSuccess) return fail(IGS_RAST_E_HIP, what, e_); } } while (0)
+// IGS_TRACE_LAUNCHES=1 (debugging aid): synchronise after every launch like debug mode and name it on stderr once it has completed --
+// after a GPU memory fault (which aborts the process) the launch that follows the last name printed is the one that faulted
+static const bool g_trace_launches = getenv("IGS_TRACE_LAUNCHES") != nullptr;
+#define DBG_SYNC(what) do { if (debug || g_trace_launches) { hipError_t e_ = hipStreamSynchronize(s); if (e_ != hipSuccess) return fail(IGS_RAST_E_HIP, what, e_); \
+                                                              if (g_trace_launches) { fprintf(stderr, "[igs] completed: %s\n", what); fflush(stderr); } } } while (0)
 
 // pinned status slot + event: one per host thread AND device, kept until the thread ends (a blend kernel still running on the
 // device used before may yet post into its slot, so switching devices never frees one)

@@ -224,7 +224,7 @@ __device__ __forceinline__ void blend_bwd_tile(const BlendBwdArgs& a, const uint
         if (lane == 0) wave_max[wid] = m;
         my_wave_max = __builtin_amdgcn_readfirstlane(m);
     }
-    __syncthreads();
+    tile_barrier();
     const int n = max(max(wave_max[0], wave_max[1]), max(wave_max[2], wave_max[3]));   // elements [0, n) of the range
     const int rounds = (n + BCHUNK - 1) / BCHUNK;
 
@@ -394,7 +394,7 @@ __device__ __forceinline__ void blend_bwd_tile(const BlendBwdArgs& a, const uint
     //  broadcast ds_read_b128 at all): parity-green, blend_bwd 80.0 -> 88.5 us -- the scalar cache does not keep up with 32 waves
     //  per CU pulling a fresh 40 bytes each per row.)
     for (int i = 0; i < rounds; i++) {
-        __syncthreads();
+        tile_barrier();
         uint32_t qmask = 0;
         if (tid < BCHUNK) {
             const int progress = i * BCHUNK + (int)tid;      // position counted from the back of [0, n)
@@ -423,7 +423,7 @@ __device__ __forceinline__ void blend_bwd_tile(const BlendBwdArgs& a, const uint
                 if (lane == 0) quad_bits[q][wid] = b;
             }
         }
-        __syncthreads();
+        tile_barrier();
         // positions -> slots for this round: list element e sits in slot n - 1 - i BCHUNK - e
         const int base = n - 1 - i * BCHUNK;
         j_first = base - last_contributor;                       // e < last_contributor  <=>  j > j_first

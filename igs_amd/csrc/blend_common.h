@@ -66,6 +66,22 @@ __device__ __forceinline__ uint32_t quad_reach_mask(float4 q0, float4 q1, float 
     return m;
 }
 
+// Workgroup barrier of the tile kernels: __syncthreads() with its release side spelled out.
+// Round 3: the forward's round loop ends with `wave_done[wid] = ...` (ds_write_b32) and begins with __syncthreads() followed by the
+// read of all four flags that decides `break` -- and hipcc emitted a bare s_barrier at that loop header, with no s_waitcnt lgkmcnt(0)
+// behind the store (its waitcnt scoreboard took the counter for zero across the back edge).  A wave whose store is still queued
+// when the barrier opens lets the waves that read first see a stale 0: they go round again while the others break.  In the
+// stand-alone forward that only costs the stragglers a redundant round (their pixels are finished; waves that have ended no
+// longer count at barriers).  In the fused forward + backward kernel it is fatal: the stragglers stage FORWARD records into the LDS
+// the others already use for the BACKWARD -- Gaussian ids read from that are garbage, and the accumulator atomic faults
+// (dense diagnostic scene, where nearly every tile ends its forward early; found with the ROCm debug agent: LDS dump of the faulting
+// workgroup).  The wait costs nothing where the compiler would have put it anyway.
+__device__ __forceinline__ void tile_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __syncthreads();
+}
+
 // wave-uniform copy of a 64-bit value (readfirstlane returns a SIGNED int: widen through uint32_t, not int)
 __device__ __forceinline__ uint64_t uniform64(uint64_t v)
 {

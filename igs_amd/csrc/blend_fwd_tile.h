@@ -51,7 +51,7 @@ __device__ __forceinline__ void blend_fwd_tile(const BlendFwdArgs& a, const uint
 
     if (tid < 4) wave_done[tid] = 0;
     for (int i = 0; i < rounds; i++) {
-        __syncthreads();                                           // previous chunk consumed, wave_done published
+        tile_barrier();                                           // previous chunk consumed, wave_done published
         if (wave_done[0] & wave_done[1] & wave_done[2] & wave_done[3]) break;
         const int progress = i * FWD_CHUNK + (int)tid;
         uint32_t qmask = 0;
@@ -74,7 +74,7 @@ __device__ __forceinline__ void blend_fwd_tile(const BlendFwdArgs& a, const uint
                 if (lane == 0) quad_bits[q][wid] = b;
             }
         }
-        __syncthreads();
+        tile_barrier();
         if (__ballot(Tl != 0.0f) != 0ull) {
             bool wave_finished = false;
             for (int sw = 0; sw < FWD_NSW && !wave_finished; sw++) {

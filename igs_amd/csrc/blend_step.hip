@@ -39,7 +39,7 @@ blend_step_kernel(const BlendFwdArgs f, const BlendBwdArgs b)
     if (!tile_for_block(blockIdx.x, f.gx, f.gy, tile)) return;
     FwdPix px;
     blend_fwd_tile<COORD, DEPTH, NORMAL, true, false>(f, tile, (float4*)smem, quad_bits_f, wave_done, px);
-    __syncthreads();          // every wave is done with the forward's staged records: the backward takes the LDS over
+    tile_barrier();           // every wave is done with the forward's staged records: the backward takes the LDS over
     blend_bwd_tile<false, false, false, ABS, true>(b, tile, (float4*)smem, nullptr, quad_bits_b, wave_max, (float*)(smem + BWD_CHUNK_BYTES), &px);
 }
 

@@ -629,6 +629,45 @@ def test_fused_refine_step_equals_unfused_step(dev):
     assert pa.step_count == pb.step_count == 4
 
 
+def test_fused_tile_kernel_on_dense_saturating_tiles(dev):
+    """igs_refine_step's fused forward + backward tile kernel (blend_step.hip) where its forward ends EARLY: large splats, hundreds to
+    thousands of instances per tile, every pixel saturated long before the list is through -- the regime of the dense diagnostic scene,
+    in which round 3's first version faulted (a wave that missed the `every quad is finished` flag went on staging forward records
+    into LDS the others already used for the backward: blend_common.h, tile_barrier).  Against the unfused native step (separate
+    kernels), several steps, LDS poisoned; the gradients through the moments of BOTH paths must agree."""
+    from igs_amd.refine import GaussianParams, Refiner, render
+    from igs_amd.scenes import perturbed_copy
+    raw, cams, bg = cfg1_scene(P=30000, size=224)
+    raw = {k: v.clone() for k, v in raw.items()}
+    raw["scaling"] = raw["scaling"] + 1.6                    # sigma x5: a splat covers dozens of tiles
+    raw["opacity"] = raw["opacity"] + 1.0
+    cams = [c.to(dev) for c in cams[:1]]
+    bg = bg.to(dev)
+    gt_raw = {k: v.to(dev) for k, v in perturbed_copy(raw, sigma=0.03).items()}
+    with torch.no_grad():
+        gts = [render(activate(gt_raw), c, bg)["images_pred"].clone() for c in cams]
+    pa, pb = GaussianParams(raw, dev), GaussianParams(raw, dev)
+    ra = Refiner(pa, cams, gts, bg, loss="l1", native=True, fused=True)
+    rb = Refiner(pb, cams, gts, bg, loss="l1", native=True, fused=False)
+    for it in range(6):
+        pa.flat.copy_(pb.flat); pa.exp_avg.copy_(pb.exp_avg); pa.exp_avg_sq.copy_(pb.exp_avg_sq)
+        poison_lds(dev)
+        pka = ra.step(view=0)
+        pkb = rb.step(view=0)
+        torch.cuda.synchronize()
+        if it == 0:
+            assert ra.last_num_rendered > 40 * 196 * 14          # dense: far more instances per tile than a staging round holds
+            nz = pkb["alpha"].cpu().numpy()
+            assert (nz > 0.999).mean() > 0.5                       # ... and most pixels saturate
+        la, lb = float(pka["loss"].item()), float(rb.l1.loss_sum.sum().item()) / gts[0].numel()
+        assert abs(la - lb) < 1e-5 * max(1.0, abs(lb)), (la, lb)
+        for name, x, y in (("exp_avg", pa.exp_avg, pb.exp_avg), ("exp_avg_sq", pa.exp_avg_sq, pb.exp_avg_sq)):
+            x, y = x.cpu().numpy(), y.cpu().numpy()
+            assert np.isfinite(x).all()
+            r = rel(x, y)
+            assert np.quantile(r, 0.98) < 2e-3, (it, name, np.quantile(r, 0.98))
+
+
 @pytest.mark.parametrize("shape", [(70, 53), (128, 128), (33, 200)])
 def test_fused_ssim_l1_loss_matches_torch_autograd(dev, shape):
     """(1 - lambda) L1 + lambda (1 - SSIM), forward + backward in two HIP launches, against the PyTorch restatement of
