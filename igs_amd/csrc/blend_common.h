@@ -78,7 +78,9 @@ __device__ __forceinline__ uint32_t quad_reach_mask(float4 q0, float4 q1, float 
 // workgroup).  The wait costs nothing where the compiler would have put it anyway.
 __device__ __forceinline__ void tile_barrier()
 {
+#ifndef IGS_NO_RELEASE_WAIT
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
     __syncthreads();
 }
 

@@ -668,6 +668,19 @@ def test_fused_tile_kernel_on_dense_saturating_tiles(dev):
             assert np.quantile(r, 0.98) < 2e-3, (it, name, np.quantile(r, 0.98))
 
 
+def test_fused_tile_kernel_on_the_full_size_dense_scene(dev):
+    """The regime that actually reproduced round 3's fault (the smaller test above does not: the race needs a full machine): the
+    dense diagnostic scene of bench.py (`--scene dense`, 200k Gaussians with log-scale mean -2.7 @1352x1014, 2.3 million instances,
+    tiles of up to 1500), ground truth for all eleven cameras, then refine steps through the fused tile kernel -- in a child process,
+    because a GPU memory fault aborts the process it happens in (built with -DIGS_NO_RELEASE_WAIT the child dies within four
+    steps)."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "debug", "dense_stages.py"), "-2.7", "16"], stdout=subprocess.PIPE,
+                       stderr=subprocess.STDOUT, text=True, timeout=300, cwd=root)
+    assert r.returncode == 0 and "ALL OK" in r.stdout, r.stdout[-1500:]
+
+
 @pytest.mark.parametrize("shape", [(70, 53), (128, 128), (33, 200)])
 def test_fused_ssim_l1_loss_matches_torch_autograd(dev, shape):
     """(1 - lambda) L1 + lambda (1 - SSIM), forward + backward in two HIP launches, against the PyTorch restatement of
