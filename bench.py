@@ -560,7 +560,7 @@ def main():
             per_t = {k: (ms / cnt if cnt else 0.0) for k, (ms, cnt) in stages_timed.items()}
             # igs_refine_step with the L1 loss blends forward AND backward in one kernel per tile (blend_step.hip): the "blend_fwd" stage is
             # then that launch and the "blend_bwd" stage the empty interval between two event marks
-            tile_fusion = fused and stream is False and os.environ.get("IGS_NO_TILE_FUSION") is None and \
+            tile_fusion = cfg == "cfg3" and fused and stream is False and os.environ.get("IGS_NO_TILE_FUSION") is None and \
                 per.get("blend_fwd", 0) > 0 and per.get("blend_bwd", 0) < 0.25 * per.get("blend_fwd", 0)
             T_tiles = ((args.width + 15) // 16) * ((args.height + 15) // 16)
             if tile_fusion:
@@ -635,7 +635,7 @@ def main():
                 if cfg == "cfg3" and args.scene == "bench" and P == 200000 and (args.width, args.height) == (1352, 1014) and loss == "l1" and not dn:
                     pm = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc.json")))
                     vi = {}
-                    for k in ("blend_step", "blend_fwd", "blend_bwd"):
+                    for k in (("blend_step",) if tile_fusion else ("blend_fwd", "blend_bwd")):
                         if k in pm and per.get(k, 0) > 0 and "SQ_INSTS_VALU" in pm[k]:
                             insts = sum(pm[k].get(c, 0.0) for c in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS"))
                             vi[k] = {"wave_insts_per_launch": insts, "valu": pm[k]["SQ_INSTS_VALU"], "salu": pm[k].get("SQ_INSTS_SALU"),
