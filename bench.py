@@ -332,6 +332,11 @@ def main():
             log("timed region: %d steps, %.4f ms per step" % (steps, 1000.0 * elapsed / steps))
             if world > 1:
                 out_extra["exchange_ms_per_step"] = ref.exchange_ms_per_step(steps)
+                out_extra["exchange"] = args.exchange
+                out_extra["exchange_note"] = ("exchange_ms_per_step = HIP-event time of the collectives the main stream WAITS for; with "
+                                              "--exchange colors the all-gather of the colour gradients starts from an event recorded right after "
+                                              "the blend backward and runs on a side stream underneath geom_bwd (DESIGN.md section 6), so only its "
+                                              "tail and the small-group all-reduces are inside this figure")
                 ref.exchange_events = None
             if not args.no_profile:
                 stages_timed, r_sum, calls = _cabi.profile_read(reset=True)
@@ -493,6 +498,7 @@ def main():
         log("timed region: %d frames x %d iterations, %.4f ms per step" % (frames, ITERS_PER_FRAME, 1000.0 * elapsed / steps))
         if world > 1:
             out_extra["exchange_ms_per_step"] = sum(a.elapsed_time(b) for lst in ev_lists for a, b in lst) / max(1, steps)
+            out_extra["exchange"] = args.exchange
         if not args.no_profile:
             stages, r_sum, calls = _cabi.profile_read(reset=True)
             stages_timed = stages
