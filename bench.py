@@ -610,7 +610,8 @@ def main():
                                      "algorithmic_bytes_per_launch": ab[oth], "avg_launch_ms": per.get(oth)}} if oth else
                               {"note": "forward and backward blend are one launch; IGS_NO_TILE_FUSION=1 python bench.py times them separately "
                                        "(round 3, same box: blend_fwd 55 us, blend_bwd 73 us, fused 122 us)"}),
-                    "stage_ms": {k: round(v, 4) for k, v in per.items()}}
+                    "stage_ms": {({"blend_bwd": "marks_after_blend_step"}.get(k, k) if tile_fusion else k): round(v, 4)
+                                 for k, v in per.items() if not (tile_fusion and k == "blend_fwd")}}
             # ALU-side figure (SURVEY.md 8d / hard part 3): pixel-Gaussian pairs = sum over pixels of the contributor count
             try:
                 if ref is not None:
