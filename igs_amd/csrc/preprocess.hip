@@ -38,22 +38,29 @@ __device__ __forceinline__ float3 sh_to_rgb(int deg, const float* __restrict__ s
 
 struct PreArgs { FwdParams p; };
 
-__global__ void __launch_bounds__(256)
-preprocess_fwd_kernel(const PreArgs a, float* __restrict__ rec, uint32_t* __restrict__ tiles, uint32_t* __restrict__ depth_keys,
-                      uint32_t* __restrict__ ident, int* __restrict__ radii, uint32_t* __restrict__ counters,
-                      uint32_t* __restrict__ hist0, uint32_t per_block, uint32_t* __restrict__ tile_count,
-                      uint64_t* __restrict__ pairs, uint32_t slab)
+// The kernel is latency-bound: a view sees ~40 % of the Gaussians, in Morton order whole waves are culled, and the ~1250 waves that do
+// have work each walk one serial chain (loads -> EWA -> plane fit -> SH -> record -> binning round trips) on a SIMD they have nearly to
+// themselves.  So the chain is cut in two and run by two workgroups per 256 Gaussians (round 3):
+//   ROLE_BIN    : cull tests, radius / rectangle, radii[] / tiles[], instance count and the slab binning; zero-fills the accumulators
+//   ROLE_RECORD : the same cull tests (same arithmetic, so the same verdict), then plane fit, SH -> RGB and the 128-byte record
+// The EWA projection is computed twice; the machine has the room (preprocess 43.5 -> see DESIGN.md section 5).  ROLE_BOTH is the unsplit
+// kernel (-DPRE_NO_SPLIT).
+enum { ROLE_BOTH = 0, ROLE_BIN = 1, ROLE_RECORD = 2 };
+
+template <int ROLE>
+__device__ __forceinline__ void
+preprocess_body(const FwdParams& p, const uint32_t blk, float* __restrict__ rec, uint32_t* __restrict__ tiles, uint32_t* __restrict__ depth_keys,
+                uint32_t* __restrict__ ident, int* __restrict__ radii, uint32_t* __restrict__ counters,
+                uint32_t* __restrict__ hist0, uint32_t per_block, uint32_t* __restrict__ tile_count,
+                uint64_t* __restrict__ pairs, uint32_t slab)
 {
-    __shared__ uint32_t s_incl[256], s_dkey[256];
-    __shared__ int s_x0[256], s_y0[256], s_w[256];
-    __shared__ uint32_t s_ws[4];
-    const FwdParams& p = a.p;
-    const int idx = blockIdx.x * 256 + threadIdx.x;
+    constexpr bool BIN = ROLE != ROLE_RECORD, RECORD = ROLE != ROLE_BIN;
+    const int idx = (int)blk * 256 + threadIdx.x;
     uint32_t my_tiles = 0;
     int rect_x0 = 0, rect_y0 = 0, rect_w = 1;
     uint32_t my_dkey = 0;
-    if (p.zero_stats && blockIdx.x == 0 && threadIdx.x < 4) p.zero_stats[threadIdx.x] = 0u;      // (nothing reads them before the tile sort)
-    if (p.zero_gacc) {
+    if (BIN && p.zero_stats && blk == 0 && threadIdx.x < 4) p.zero_stats[threadIdx.x] = 0u;      // (nothing reads them before the tile sort)
+    if (BIN && p.zero_gacc) {
         // refine step: this kernel is latency-bound and leaves the memory pipes idle -- zero-fill the backward's accumulator
         // line of this Gaussian (and the loss shards) here instead of in a 25 MB fill of its own
         if (idx < p.P) {
@@ -63,7 +70,7 @@ preprocess_fwd_kernel(const PreArgs a, float* __restrict__ rec, uint32_t* __rest
             for (int k = 0; k < GACC_F / 4; k++)
                 if (4 * k < p.zero_gacc_stride) Z4[k] = z;
         }
-        if (blockIdx.x == 0 && threadIdx.x < 64) {
+        if (blk == 0 && threadIdx.x < 64) {
             p.zero_loss[16 * threadIdx.x] = 0.f;
             if (p.zero_loss2) p.zero_loss2[16 * threadIdx.x] = 0.f;
         }
@@ -76,7 +83,7 @@ preprocess_fwd_kernel(const PreArgs a, float* __restrict__ rec, uint32_t* __rest
         const float3 p_view = xform4x3(p_orig, p.view);
         do {
             if (p_view.z <= 0.2f) {                       // auxiliary.h:170
-                if (p.prefiltered) atomicOr(&counters[1], 1u);
+                if (BIN && p.prefiltered) atomicOr(&counters[1], 1u);
                 break;
             }
             const float4 p_hom = xform4x4(p_orig, p.proj);
@@ -97,10 +104,10 @@ preprocess_fwd_kernel(const PreArgs a, float* __restrict__ rec, uint32_t* __rest
                 cov3d_from_scale_rot(s, p.scale_modifier, q, cov3D);
             }
             Cov2DCtx c;
-            cov2d_ctx(c, p_orig, cov3D, p.view, p.fx, p.fy, p.tan_fovx, p.tan_fovy, p.kernel_size);
+            cov2d_ctx(c, p_orig, cov3D, p.view, p.fx, p.fy, p.tan_fovx, p.tan_fovy, p.kernel_size, RECORD);      // (the binning role skips the eigen-solver)
             float cp[6] = { 0, 0, 0, 0, 0, 0 }, rp[2] = { 0, 0 };
             float3 nrm = make_float3(0, 0, 0);
-            if (!c.degenerate) {                           // forward.cu:169-262
+            if (RECORD && !c.degenerate) {                 // forward.cu:169-262
                 const float3 t = c.t;
                 const float u = c.txtz, v = c.tytz, u2 = u * u, v2 = v * v, uv = u * v;
                 const float l = sqrtf(t.x * t.x + t.y * t.y + t.z * t.z);
@@ -143,7 +150,8 @@ preprocess_fwd_kernel(const PreArgs a, float* __restrict__ rec, uint32_t* __rest
             if ((x1 - x0) * (y1 - y0) == 0) break;
             float3 rgb = make_float3(0, 0, 0);
             uint32_t clamped = 0;
-            if (p.colors_precomp == nullptr) {
+            if (!RECORD) {
+            } else if (p.colors_precomp == nullptr) {
                 float3 dir = p_orig - make_float3(p.campos[0], p.campos[1], p.campos[2]);
                 const float len = sqrtf(dot3(dir, dir));
                 dir = make_float3(dir.x / len, dir.y / len, dir.z / len);
@@ -156,6 +164,7 @@ preprocess_fwd_kernel(const PreArgs a, float* __restrict__ rec, uint32_t* __rest
             rect_x0 = x0; rect_y0 = y0; rect_w = x1 - x0;
             dkey = __float_as_uint(p_view.z);
             my_dkey = dkey;
+            if constexpr (RECORD) {
             R4[0] = make_float4(pix, piy, conic.x, conic.y);
             const float opacity = p.raw_activations ? act_sigmoid(p.opacities[idx]) : p.opacities[idx];
             R4[1] = make_float4(conic.z, opacity * coef, rgb.x, rgb.y);
@@ -165,22 +174,29 @@ preprocess_fwd_kernel(const PreArgs a, float* __restrict__ rec, uint32_t* __rest
             R4[5] = make_float4(cp[4], cp[5], nrm.y, nrm.z);
             R4[6] = make_float4(cov3D[0], cov3D[1], cov3D[2], cov3D[3]);
             R4[7] = make_float4(cov3D[4], cov3D[5], __uint_as_float(clamped), __uint_as_float(dkey));
+            }
         } while (0);
+        if constexpr (BIN) {
         radii[idx] = radius;
         tiles[idx] = my_tiles;
-        if (hist0) {                                          // radix binning: keys + first-pass histogram of the depth sort
+        }
+        if (BIN && hist0) {                                          // radix binning: keys + first-pass histogram of the depth sort
             depth_keys[idx] = dkey;
             ident[idx] = (uint32_t)idx;
             atomicAdd(&hist0[((uint32_t)idx / per_block) * 256u + (dkey & 255u)], 1u);
         }
     }
+    if constexpr (BIN) {
+    __shared__ uint32_t s_incl[256], s_dkey[256];
+    __shared__ int s_x0[256], s_y0[256], s_w[256];
+    __shared__ uint32_t s_ws[4];
     // total instance count: wave scan, one atomic per wave that has something to add (sharded, summed later)
     const uint32_t lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     uint32_t v = my_tiles;
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) { const uint32_t t = __shfl_up(v, off, 64); if (lane >= (uint32_t)off) v += t; }
     // 64 counter shards, one cache line apart: same-address atomics serialise at ~12 ns each (3128 waves -> 37 us on one word)
-    if (lane == 63 && v) atomicAdd(&counters[COUNTER_SHARD_STRIDE * (1 + (blockIdx.x & (COUNTER_SHARDS - 1)))], v);
+    if (lane == 63 && v) atomicAdd(&counters[COUNTER_SHARD_STRIDE * (1 + (blk & (COUNTER_SHARDS - 1)))], v);
     if (pairs == nullptr) return;                             // radix binning: instances are emitted after the depth sort
 
     // ---- slab binning: the workgroup drops its instances into the tile slabs cooperatively (load-balanced over the 256
@@ -227,7 +243,7 @@ preprocess_fwd_kernel(const PreArgs a, float* __restrict__ rec, uint32_t* __rest
             const uint32_t local = ok[u] ? k - (j ? s_incl[j - 1] : 0u) : 0u;
             const uint32_t w = (uint32_t)s_w[j];
             tt[u] = (uint32_t)((s_y0[j] + (int)(local / w)) * p.gx + s_x0[j] + (int)(local % w));
-            key_hi[u] = s_dkey[j]; key_lo[u] = blockIdx.x * 256u + j;
+            key_hi[u] = s_dkey[j]; key_lo[u] = blk * 256u + j;
         }
         uint32_t slot[2];
 #pragma unroll
@@ -262,7 +278,7 @@ preprocess_fwd_kernel(const PreArgs a, float* __restrict__ rec, uint32_t* __rest
             const uint32_t local = ok[u] ? k - (j ? s_incl[j - 1] : 0u) : 0u;
             const uint32_t w = (uint32_t)s_w[j];
             tt[u] = (uint32_t)((s_y0[j] + (int)(local / w)) * p.gx + s_x0[j] + (int)(local % w));
-            key_hi[u] = s_dkey[j]; key_lo[u] = blockIdx.x * 256u + j;
+            key_hi[u] = s_dkey[j]; key_lo[u] = blk * 256u + j;
             hh[u] = 0; rk[u] = 0;
             if (ok[u]) {
                 uint32_t h = (tt[u] * 2654435761u) >> 21;                      // 11 bits
@@ -298,6 +314,24 @@ preprocess_fwd_kernel(const PreArgs a, float* __restrict__ rec, uint32_t* __rest
         }
         __syncthreads();
     }
+    }      // BIN
+}
+
+template <bool SPLIT>
+__global__ void __launch_bounds__(256)
+preprocess_fwd_kernel(const PreArgs a, float* __restrict__ rec, uint32_t* __restrict__ tiles, uint32_t* __restrict__ depth_keys,
+                      uint32_t* __restrict__ ident, int* __restrict__ radii, uint32_t* __restrict__ counters,
+                      uint32_t* __restrict__ hist0, uint32_t per_block, uint32_t* __restrict__ tile_count,
+                      uint64_t* __restrict__ pairs, uint32_t slab)
+{
+    if constexpr (!SPLIT) {
+        preprocess_body<ROLE_BOTH>(a.p, blockIdx.x, rec, tiles, depth_keys, ident, radii, counters, hist0, per_block, tile_count, pairs, slab);
+    } else {
+        // neighbouring workgroups take the two roles of the same 256 Gaussians: their parameter lines are fetched once
+        const uint32_t blk = blockIdx.x >> 1;
+        if (blockIdx.x & 1u) preprocess_body<ROLE_RECORD>(a.p, blk, rec, tiles, depth_keys, ident, radii, counters, hist0, per_block, tile_count, pairs, slab);
+        else                 preprocess_body<ROLE_BIN>(a.p, blk, rec, tiles, depth_keys, ident, radii, counters, hist0, per_block, tile_count, pairs, slab);
+    }
 }
 
 hipError_t launch_preprocess_fwd(hipStream_t s, const FwdParams& p, float* rec, uint32_t* tiles, uint32_t* depth_keys,
@@ -306,8 +340,13 @@ hipError_t launch_preprocess_fwd(hipStream_t s, const FwdParams& p, float* rec, 
 {
     PreArgs a; a.p = p;
     // (staging the SH rows through LDS was tried here and lost: 50 KB/block costs more occupancy than the strided reads cost)
-    hipLaunchKernelGGL(preprocess_fwd_kernel, dim3((p.P + 255) / 256), dim3(256), 0, s, a, rec, tiles, depth_keys, ident, radii, counters,
+#ifdef PRE_NO_SPLIT
+    hipLaunchKernelGGL(preprocess_fwd_kernel<false>, dim3((p.P + 255) / 256), dim3(256), 0, s, a, rec, tiles, depth_keys, ident, radii, counters,
                        hist0, per_block, tile_count, pairs, slab);
+#else
+    hipLaunchKernelGGL(preprocess_fwd_kernel<true>, dim3(2 * ((p.P + 255) / 256)), dim3(256), 0, s, a, rec, tiles, depth_keys, ident, radii, counters,
+                       hist0, per_block, tile_count, pairs, slab);
+#endif
     return hipGetLastError();
 }
 
