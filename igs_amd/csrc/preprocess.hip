@@ -47,6 +47,21 @@ struct PreArgs { FwdParams p; };
 // kernel (-DPRE_NO_SPLIT).
 enum { ROLE_BOTH = 0, ROLE_BIN = 1, ROLE_RECORD = 2 };
 
+#ifdef PRE_TIMELINE
+// debug build only (tools/debug/preprocess_timeline.py): per wave and role, the 100 MHz clock at the marks of the chain
+#define PRE_TL_MARKS 10
+#define PRE_TL_WAVES 16384
+__device__ unsigned long long g_pre_tl[PRE_TL_WAVES * PRE_TL_MARKS];
+extern "C" int igs_debug_preprocess_timeline(unsigned long long* host, int n)
+{
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_pre_tl), (size_t)n * 8);
+}
+#define TL(k) do { const unsigned long long m_ = __ballot(1); if ((threadIdx.x & 63) == (unsigned)__ffsll((long long)m_) - 1u) { \
+    const unsigned w_ = (blockIdx.x * 4u + (threadIdx.x >> 6)); if (w_ < PRE_TL_WAVES) g_pre_tl[w_ * PRE_TL_MARKS + (k)] = wall_clock64(); } } while (0)
+#else
+#define TL(k) do { } while (0)
+#endif
+
 template <int ROLE>
 __device__ __forceinline__ void
 preprocess_body(const FwdParams& p, const uint32_t blk, float* __restrict__ rec, uint32_t* __restrict__ tiles, uint32_t* __restrict__ depth_keys,
@@ -56,31 +71,18 @@ preprocess_body(const FwdParams& p, const uint32_t blk, float* __restrict__ rec,
 {
     constexpr bool BIN = ROLE != ROLE_RECORD, RECORD = ROLE != ROLE_BIN;
     const int idx = (int)blk * 256 + threadIdx.x;
+    TL(0);
     uint32_t my_tiles = 0;
     int rect_x0 = 0, rect_y0 = 0, rect_w = 1;
     uint32_t my_dkey = 0;
     if (BIN && p.zero_stats && blk == 0 && threadIdx.x < 4) p.zero_stats[threadIdx.x] = 0u;      // (nothing reads them before the tile sort)
-    if (BIN && p.zero_gacc) {
-        // refine step: this kernel is latency-bound and leaves the memory pipes idle -- zero-fill the backward's accumulator
-        // line of this Gaussian (and the loss shards) here instead of in a 25 MB fill of its own
-        if (idx < p.P) {
-            float4* Z4 = (float4*)(p.zero_gacc + (size_t)idx * p.zero_gacc_stride);
-            const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-            for (int k = 0; k < GACC_F / 4; k++)
-                if (4 * k < p.zero_gacc_stride) Z4[k] = z;
-        }
-        if (blk == 0 && threadIdx.x < 64) {
-            p.zero_loss[16 * threadIdx.x] = 0.f;
-            if (p.zero_loss2) p.zero_loss2[16 * threadIdx.x] = 0.f;
-        }
-    }
     if (idx < p.P) {
         int radius = 0;
         uint32_t dkey = 0xFFFFFFFFu;      // culled Gaussians sort to the end (they own no instances anyway)
         float4* R4 = (float4*)(rec + (size_t)idx * REC_F);
         const float3 p_orig = make_float3(p.means3D[3 * idx], p.means3D[3 * idx + 1], p.means3D[3 * idx + 2]);
         const float3 p_view = xform4x3(p_orig, p.view);
+        TL(1);
         do {
             if (p_view.z <= 0.2f) {                       // auxiliary.h:170
                 if (BIN && p.prefiltered) atomicOr(&counters[1], 1u);
@@ -105,6 +107,7 @@ preprocess_body(const FwdParams& p, const uint32_t blk, float* __restrict__ rec,
             }
             Cov2DCtx c;
             cov2d_ctx(c, p_orig, cov3D, p.view, p.fx, p.fy, p.tan_fovx, p.tan_fovy, p.kernel_size, RECORD);      // (the binning role skips the eigen-solver)
+            TL(2);
             float cp[6] = { 0, 0, 0, 0, 0, 0 }, rp[2] = { 0, 0 };
             float3 nrm = make_float3(0, 0, 0);
             if (RECORD && !c.degenerate) {                 // forward.cu:169-262
@@ -148,6 +151,7 @@ preprocess_body(const FwdParams& p, const uint32_t blk, float* __restrict__ rec,
             int x0, y0, x1, y1;
             get_rect(pix, piy, (int)my_radius, p.gx, p.gy, x0, y0, x1, y1);
             if ((x1 - x0) * (y1 - y0) == 0) break;
+            TL(3);
             float3 rgb = make_float3(0, 0, 0);
             uint32_t clamped = 0;
             if (!RECORD) {
@@ -163,6 +167,7 @@ preprocess_body(const FwdParams& p, const uint32_t blk, float* __restrict__ rec,
             my_tiles = (uint32_t)((y1 - y0) * (x1 - x0));
             rect_x0 = x0; rect_y0 = y0; rect_w = x1 - x0;
             dkey = __float_as_uint(p_view.z);
+            TL(4);
             my_dkey = dkey;
             if constexpr (RECORD) {
             R4[0] = make_float4(pix, piy, conic.x, conic.y);
@@ -176,6 +181,7 @@ preprocess_body(const FwdParams& p, const uint32_t blk, float* __restrict__ rec,
             R4[7] = make_float4(cov3D[4], cov3D[5], __uint_as_float(clamped), __uint_as_float(dkey));
             }
         } while (0);
+        TL(5);
         if constexpr (BIN) {
         radii[idx] = radius;
         tiles[idx] = my_tiles;
@@ -184,6 +190,22 @@ preprocess_body(const FwdParams& p, const uint32_t blk, float* __restrict__ rec,
             depth_keys[idx] = dkey;
             ident[idx] = (uint32_t)idx;
             atomicAdd(&hist0[((uint32_t)idx / per_block) * 256u + (dkey & 255u)], 1u);
+        }
+    }
+    if (BIN && p.zero_gacc) {
+        // refine step: this kernel is latency-bound and leaves the memory pipes idle -- zero-fill the backward's accumulator
+        // line of this Gaussian (and the loss shards) here instead of in a 25 MB fill of its own.  AFTER the wave's loads: issued at
+        // the top, the stores sat in front of them in the memory pipeline (position loads back after 4.8 us instead of 1.0)
+        if (idx < p.P) {
+            float4* Z4 = (float4*)(p.zero_gacc + (size_t)idx * p.zero_gacc_stride);
+            const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int k = 0; k < GACC_F / 4; k++)
+                if (4 * k < p.zero_gacc_stride) Z4[k] = z;
+        }
+        if (blk == 0 && threadIdx.x < 64) {
+            p.zero_loss[16 * threadIdx.x] = 0.f;
+            if (p.zero_loss2) p.zero_loss2[16 * threadIdx.x] = 0.f;
         }
     }
     if constexpr (BIN) {
@@ -198,6 +220,7 @@ preprocess_body(const FwdParams& p, const uint32_t blk, float* __restrict__ rec,
     // 64 counter shards, one cache line apart: same-address atomics serialise at ~12 ns each (3128 waves -> 37 us on one word)
     if (lane == 63 && v) atomicAdd(&counters[COUNTER_SHARD_STRIDE * (1 + (blk & (COUNTER_SHARDS - 1)))], v);
     if (pairs == nullptr) return;                             // radix binning: instances are emitted after the depth sort
+    TL(6);
 
     // ---- slab binning: the workgroup drops its instances into the tile slabs cooperatively (load-balanced over the 256
     //      threads whatever the individual footprints are): slot = tile_count[t]++ ; pairs[t*slab + slot] = depth<<32 | id
@@ -225,6 +248,7 @@ preprocess_body(const FwdParams& p, const uint32_t blk, float* __restrict__ rec,
     const int bbx0 = min(min(s_bb[0][0], s_bb[1][0]), min(s_bb[2][0], s_bb[3][0])), bby0 = min(min(s_bb[0][1], s_bb[1][1]), min(s_bb[2][1], s_bb[3][1]));
     const int bbx1 = max(max(s_bb[0][2], s_bb[1][2]), max(s_bb[2][2], s_bb[3][2])), bby1 = max(max(s_bb[0][3], s_bb[1][3]), max(s_bb[2][3], s_bb[3][3]));
     const bool coherent = total > 0 && (long long)(bbx1 - bbx0) * (long long)(bby1 - bby0) <= 1024;       // workgroup-uniform
+    TL(7);
     if (!coherent) {
     // ---- scattered workgroup: one returning global atomic per instance
     for (uint32_t k0 = 0; k0 < total; k0 += 512) {
@@ -314,9 +338,11 @@ preprocess_body(const FwdParams& p, const uint32_t blk, float* __restrict__ rec,
         }
         __syncthreads();
     }
+    TL(8);
     }      // BIN
 }
 
+// (80 VGPRs = 6 workgroups per CU: 28 of the 1564 start late.  Forcing 7 per CU -- 72 VGPRs, 12 spilled -- changes nothing: 38.0 us)
 template <bool SPLIT>
 __global__ void __launch_bounds__(256)
 preprocess_fwd_kernel(const PreArgs a, float* __restrict__ rec, uint32_t* __restrict__ tiles, uint32_t* __restrict__ depth_keys,
