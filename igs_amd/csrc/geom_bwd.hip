@@ -678,17 +678,20 @@ geom_bwd_kernel(const GBArgs args)
                         }
                     }
                 };
+                int row_g = (4 * (int)threadIdx.x) / F, row_k = 4 * (int)threadIdx.x - row_g * F;
+                const int row_dg = (4 * NT) / F, row_dk = 4 * NT - row_dg * F;
                 auto sh_finish = [&](int batch) {
 #pragma unroll
                     for (int u = 0; u < UB; u++) {
                         const int i = (int)threadIdx.x + (batch * UB + u) * NT;
                         if (i < total4) {
-                            const int f = 4 * i, g = f / F, k = f - g * F;
-                            const float* sp = dsh_lds + g * FS + k;
+                            const float* sp = dsh_lds + row_g * FS + row_k;       // float 4 i of the span = Gaussian row_g, coefficient row_k
                             adam4(HP[u], HM[u], HV[u], sp[0], sp[1], sp[2], sp[3], fz.lr_sh);
                             const size_t o = bh / 4 + i;
                             st_param((float4*)fz.param + o, HP[u]); st_moment((float4*)fz.exp_avg + o, HM[u]); st_moment((float4*)fz.exp_avg_sq + o, HV[u]);
                         }
+                        row_g += row_dg; row_k += row_dk;                         // (items are visited in increasing i: no division per item)
+                        if (row_k >= F) { row_k -= F; row_g++; }
                     }
                 };
                 const int nbatch = (total4 + UB * NT - 1) / (UB * NT);
