@@ -402,6 +402,21 @@ __device__ __forceinline__ void wave_sort_tile(const uint64_t* __restrict__ src,
     for (int r = 0; r < E; r++) { const uint32_t i = lane * E + r; if (i < n) dst[i] = min((uint32_t)v[r], id_max); }
 }
 
+#ifdef SORT_TIMELINE
+// debug build only (tools/debug/sort_timeline.py): per tile, its size and the 100 MHz clock at the marks of its workgroup's life
+#define SORT_TL_MARKS 6
+#define SORT_TL_TILES 8192
+__device__ unsigned long long g_sort_tl[SORT_TL_TILES * SORT_TL_MARKS];
+extern "C" int igs_debug_sort_timeline(unsigned long long* host, int n)
+{
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_sort_tl), (size_t)n * 8);
+}
+#define STL(k, val) do { if (threadIdx.x == 0 && blockIdx.x < SORT_TL_TILES) g_sort_tl[blockIdx.x * SORT_TL_MARKS + (k)] = (val); } while (0)
+#define STLT(t, k, val) do { if ((threadIdx.x & 63) == 0 && (t) < SORT_TL_TILES) g_sort_tl[(t) * SORT_TL_MARKS + (k)] = (val); } while (0)
+#else
+#define STL(k, val) do { } while (0)
+#define STLT(t, k, val) do { } while (0)
+#endif
 // A workgroup of 4 waves owns 4 consecutive tiles.  Tiles of up to TILE_SORT_WAVE instances (nearly all of them) are sorted
 // by one wave each in registers; the few denser ones (up to TILE_SORT_SMALL) by the whole workgroup in LDS afterwards.
 // Tiles in (TILE_SORT_SMALL, slab] are left to tile_sort_big_kernel; tiles that overflowed their slab get an empty range and
@@ -427,6 +442,7 @@ tile_sort_kernel(uint32_t T, uint32_t* __restrict__ tile_count, const uint64_t* 
         if (lane == 0) { stats[0] = v; stats[2] = counters[1]; counters[1] = 0u; }
     }
     const uint32_t t0 = blockIdx.x * 4;
+    STLT(t0 + wid, 0, wall_clock64());
     // the four counts of the workgroup, fetched once (lane q of every wave loads tile t0+q)
     const uint32_t my_cnt = (lane < 4 && t0 + lane < T) ? tile_count[t0 + lane] : 0u;
     const uint32_t cnt0 = (uint32_t)__shfl((int)my_cnt, 0, 64), cnt1 = (uint32_t)__shfl((int)my_cnt, 1, 64);
@@ -441,6 +457,7 @@ tile_sort_kernel(uint32_t T, uint32_t* __restrict__ tile_count, const uint64_t* 
         const uint32_t t = t0 + wid;
         if (t < T) {
             const uint32_t n_true = wid == 0 ? cnt0 : wid == 1 ? cnt1 : wid == 2 ? cnt2 : cnt3;
+            STLT(t, 5, (unsigned long long)n_true); STLT(t, 1, wall_clock64());
             const size_t base = (size_t)t * slab;
             if (n_true > slab) {
                 if (lane == 0) { atomicMax(&stats[1], n_true); ranges[2 * t] = (uint32_t)base; ranges[2 * t + 1] = (uint32_t)base; }
@@ -452,8 +469,17 @@ tile_sort_kernel(uint32_t T, uint32_t* __restrict__ tile_count, const uint64_t* 
                 else if (n_true <= 64) wave_sort_tile<1>(src, dst, n_true, lane, id_max);
                 else if (n_true <= 128) wave_sort_tile<2>(src, dst, n_true, lane, id_max);
                 else if (n_true <= 256) wave_sort_tile<4>(src, dst, n_true, lane, id_max);
-                else if (n_true <= 512) wave_sort_tile<8>(src, dst, n_true, lane, id_max);
-                else if (n_true <= 1024) wave_sort_tile<16>(src, dst, n_true, lane, id_max);
+                else {
+                    // Every wave of the launch is resident at once (5.3 per SIMD on the bench scene), so the launch lasts as long as its
+                    // longest chain -- the few tiles above 256 instances (2 400-5 300 dependent instructions): those waves go first.
+                    // profiles/r03_sort_timeline.txt: a 263-instance tile took 13.5 us of a 15.1 us launch at equal priority.
+#ifndef TILE_SORT_NO_PRIO
+                    __builtin_amdgcn_s_setprio(3);
+#endif
+                    if (n_true <= 512) wave_sort_tile<8>(src, dst, n_true, lane, id_max);
+                    else if (n_true <= 1024) wave_sort_tile<16>(src, dst, n_true, lane, id_max);
+                }
+                STLT(t, 4, wall_clock64());
             }
         }
     }
