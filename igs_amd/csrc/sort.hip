@@ -357,7 +357,7 @@ __device__ __forceinline__ uint64_t lane_xor64(uint64_t v, uint32_t lane)
 }
 
 template <int E>
-__device__ __forceinline__ void wave_bitonic_sort(uint64_t (&v)[E], uint32_t lane)
+__device__ __forceinline__ void wave_bitonic_sort(uint64_t (&v)[E], uint32_t lane, uint32_t ibase = 0u)      // ibase: index of the wave's first key in a larger network
 {
 #pragma unroll
     for (int k = 2; k <= 64 * E; k <<= 1) {
@@ -368,7 +368,7 @@ __device__ __forceinline__ void wave_bitonic_sort(uint64_t (&v)[E], uint32_t lan
                 const bool lower = (lane & (uint32_t)lm) == 0;                    // this element is the lower one of its pair
 #pragma unroll
                 for (int r = 0; r < E; r++) {
-                    const uint32_t i = lane * E + r;
+                    const uint32_t i = ibase + lane * E + r;
                     const uint64_t o = lm == 1 ? lane_xor64<1>(v[r], lane) : lm == 2 ? lane_xor64<2>(v[r], lane) : lm == 4 ? lane_xor64<4>(v[r], lane)
                                      : lm == 8 ? lane_xor64<8>(v[r], lane) : lm == 16 ? lane_xor64<16>(v[r], lane) : lane_xor64<32>(v[r], lane);
                     const bool up = (i & (uint32_t)k) == 0;
@@ -380,7 +380,7 @@ __device__ __forceinline__ void wave_bitonic_sort(uint64_t (&v)[E], uint32_t lan
                 for (int r = 0; r < E; r++) {
                     const int q = r ^ j;
                     if (q > r) {
-                        const uint32_t i = lane * E + r;
+                        const uint32_t i = ibase + lane * E + r;
                         const bool up = (i & (uint32_t)k) == 0;
                         const uint64_t x = v[r], y = v[q];
                         const bool sw = (x > y) == up;
@@ -390,6 +390,69 @@ __device__ __forceinline__ void wave_bitonic_sort(uint64_t (&v)[E], uint32_t lan
             }
         }
     }
+}
+// stages j = 32 E ... 1 of level k >= 128 E of that larger network: a bitonic merge inside the wave's 64 E keys (direction: one per wave)
+template <int E>
+__device__ __forceinline__ void wave_bitonic_merge(uint64_t (&v)[E], uint32_t lane, uint32_t ibase, uint32_t k)
+{
+    const bool up = (ibase & k) == 0;
+#pragma unroll
+    for (int j = 32 * E; j > 0; j >>= 1) {
+        if (j >= E) {
+            const int lm = j / E;
+            const bool lower = (lane & (uint32_t)lm) == 0;
+#pragma unroll
+            for (int r = 0; r < E; r++) {
+                const uint64_t o = lm == 1 ? lane_xor64<1>(v[r], lane) : lm == 2 ? lane_xor64<2>(v[r], lane) : lm == 4 ? lane_xor64<4>(v[r], lane)
+                                 : lm == 8 ? lane_xor64<8>(v[r], lane) : lm == 16 ? lane_xor64<16>(v[r], lane) : lane_xor64<32>(v[r], lane);
+                const uint64_t lo = v[r] < o ? v[r] : o, hi = v[r] < o ? o : v[r];
+                v[r] = (lower == up) ? lo : hi;
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < E; r++) {
+                const int q = r ^ j;
+                if (q > r) {
+                    const uint64_t x = v[r], y = v[q];
+                    const bool sw = (x > y) == up;
+                    v[r] = sw ? y : x; v[q] = sw ? x : y;
+                }
+            }
+        }
+    }
+}
+// 256 E keys by the four waves of a workgroup: every wave sorts its 64 E keys in registers (direction as the network wants it), then the
+// two levels that span waves exchange through LDS -- three exchanges with a barrier pair each, where the all-LDS network
+// (BITONIC_SORT) has 45-66 barrier-separated stages -- and finish inside the waves again.
+template <int E>
+__device__ __forceinline__ void wg_sort_tile(const uint64_t* __restrict__ src, uint32_t* __restrict__ dst, uint32_t n, uint64_t* skeys, uint32_t tid, uint32_t id_max)
+{
+    const uint32_t lane = tid & 63, wid = tid >> 6, ibase = wid * 64u * E;
+    uint64_t v[E];
+#pragma unroll
+    for (int r = 0; r < E; r++) { const uint32_t i = ibase + lane * E + r; v[r] = i < n ? src[i] : ~0ull; }
+    wave_bitonic_sort<E>(v, lane, ibase);
+#pragma unroll
+    for (uint32_t k = 128u * E; k <= 256u * E; k <<= 1) {
+        const bool up = (ibase & k) == 0;
+#pragma unroll
+        for (uint32_t j = k >> 1; j >= 64u * E; j >>= 1) {                 // the partner sits in another wave: same lane, same register
+#pragma unroll
+            for (int r = 0; r < E; r++) skeys[ibase + lane * E + r] = v[r];
+            __syncthreads();
+            const bool lower = (ibase & j) == 0;
+#pragma unroll
+            for (int r = 0; r < E; r++) {
+                const uint64_t o = skeys[(ibase ^ j) + lane * E + r];
+                const uint64_t lo = v[r] < o ? v[r] : o, hi = v[r] < o ? o : v[r];
+                v[r] = (lower == up) ? lo : hi;
+            }
+            __syncthreads();
+        }
+        wave_bitonic_merge<E>(v, lane, ibase, k);
+    }
+#pragma unroll
+    for (int r = 0; r < E; r++) { const uint32_t i = ibase + lane * E + r; if (i < n) dst[i] = min((uint32_t)v[r], id_max); }
 }
 template <int E>
 __device__ __forceinline__ void wave_sort_tile(const uint64_t* __restrict__ src, uint32_t* __restrict__ dst, uint32_t n, uint32_t lane, uint32_t id_max)
@@ -531,6 +594,75 @@ tile_sort_big_kernel(uint32_t* __restrict__ tile_count, const uint64_t* __restri
     if (threadIdx.x == 0) { ranges[2 * t] = (uint32_t)base; ranges[2 * t + 1] = (uint32_t)(base + n); }
 }
 
+// ONE workgroup per tile, for scenes whose slabs have grown beyond TILE_SORT_WAVE_ALONE (dense views: most tiles hold several
+// hundred instances).  A tile of up to TILE_SORT_ONE_WAVE instances is sorted by the workgroup's first wave in registers while the
+// other three leave at once; a denser one by all four waves in LDS (a 512-key tile: 9.7 us against 13.5 for one wave in registers,
+// profiles/r03_sort_timeline.txt).  Replaces tile_sort_kernel + tile_sort_mid_kernel -- two launches -- there; on the bench scene
+// (densest tile 263 instances) its 5440 workgroups take 8 us to dispatch and it loses (16.5 against 16.1 us).
+#ifndef TILE_SORT_ONE_WAVE
+#define TILE_SORT_ONE_WAVE 256
+#endif
+__global__ void __launch_bounds__(256)
+tile_sort_one_kernel(uint32_t T, uint32_t* __restrict__ tile_count, const uint64_t* __restrict__ pairs,
+                     uint32_t* __restrict__ point_list, uint32_t* __restrict__ ranges, uint32_t slab, uint32_t* __restrict__ stats,
+                     uint32_t* __restrict__ counters, uint32_t id_max, int clean_counts)
+{
+    __shared__ __attribute__((aligned(16))) uint64_t skeys[TILE_SORT_SMALL];        // 16 KB
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    if (blockIdx.x == 0 && wid == 0 && counters) {
+        // R = sum of the preprocess kernel's counter shards
+        uint32_t v = counters[COUNTER_SHARD_STRIDE * (1 + lane)];
+        counters[COUNTER_SHARD_STRIDE * (1 + lane)] = 0u;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+        if (lane == 0) { stats[0] = v; stats[2] = counters[1]; counters[1] = 0u; }
+    }
+    const uint32_t t = blockIdx.x;
+    if (t >= T) return;
+    STL(0, wall_clock64());
+    const uint32_t n = tile_count[t];
+    STL(5, (unsigned long long)n);
+    if (clean_counts) {
+        __syncthreads();                               // every thread has its copy of n
+        if (tid == 0) tile_count[t] = 0u;
+    }
+    const size_t base = (size_t)t * slab;
+    if (n > slab) {
+        if (tid == 0) { atomicMax(&stats[1], n); ranges[2 * t] = (uint32_t)base; ranges[2 * t + 1] = (uint32_t)base; }
+        return;
+    }
+    if (tid == 0 && n <= TILE_SORT_SMALL) { ranges[2 * t] = (uint32_t)base; ranges[2 * t + 1] = (uint32_t)(base + n); }
+    STL(1, wall_clock64());
+    if (n == 0 || n > TILE_SORT_SMALL) return;         // (denser tiles: tile_sort_big_kernel)
+    const uint64_t* src = pairs + base;
+    uint32_t* dst = point_list + base;
+    if (n <= TILE_SORT_ONE_WAVE) {
+        if (wid != 0) return;
+        if (n <= 64) wave_sort_tile<1>(src, dst, n, lane, id_max);
+        else if (n <= 128) wave_sort_tile<2>(src, dst, n, lane, id_max);
+        else if (n <= 256) wave_sort_tile<4>(src, dst, n, lane, id_max);
+#if TILE_SORT_ONE_WAVE > 256
+        else if (n <= 512) wave_sort_tile<8>(src, dst, n, lane, id_max);
+#endif
+        STL(4, wall_clock64());
+        return;
+    }
+#ifdef TILE_SORT_ALL_LDS
+    uint32_t N = 2;
+    while (N < n) N <<= 1;
+    for (uint32_t i = tid; i < N; i += 256) skeys[i] = (i < n) ? src[i] : ~0ull;
+    __syncthreads();
+    BITONIC_SORT(skeys, N, tid, 256, __syncthreads())
+    for (uint32_t i = tid; i < n; i += 256) dst[i] = min((uint32_t)skeys[i], id_max);
+#else
+    if (n <= 256) wg_sort_tile<1>(src, dst, n, skeys, tid, id_max);
+    else if (n <= 512) wg_sort_tile<2>(src, dst, n, skeys, tid, id_max);
+    else if (n <= 1024) wg_sort_tile<4>(src, dst, n, skeys, tid, id_max);
+    else wg_sort_tile<8>(src, dst, n, skeys, tid, id_max);
+#endif
+    STL(4, wall_clock64());
+}
+
 #ifndef TILE_SORT_WAVE_ALONE
 #define TILE_SORT_WAVE_ALONE 1024         // slabs up to this size: every tile by one wave in registers, no second launch
 #endif
@@ -543,10 +675,17 @@ hipError_t launch_tile_sort(hipStream_t s, uint32_t T, uint32_t* tile_count, con
     const bool mid = slab > TILE_SORT_WAVE_ALONE, big = slab > TILE_SORT_SMALL;
     const uint32_t id_max = P ? P - 1u : 0u;
     const uint32_t wave_max = mid ? TILE_SORT_WAVE_WITH_MID : TILE_SORT_WAVE;
+#ifndef TILE_SORT_NO_ONE_PER_WG
+    if (mid) {
+        hipLaunchKernelGGL(tile_sort_one_kernel, dim3(T), dim3(256), 0, s, T, tile_count, pairs, point_list, ranges, slab, stats, counters, id_max, big ? 0 : 1);
+    } else
+#endif
+    {
     // whichever launch reads the fill cursors last resets them
     hipLaunchKernelGGL(tile_sort_kernel, dim3((T + 3) / 4), dim3(256), 0, s, T, tile_count, pairs, point_list, ranges, slab, stats, counters,
                        id_max, mid ? 0 : 1, wave_max);
     if (mid) hipLaunchKernelGGL(tile_sort_mid_kernel, dim3(T), dim3(256), 0, s, tile_count, pairs, point_list, slab, id_max, big ? 0 : 1, wave_max);
+    }
     if (big) {
         static bool attr_set = false;
         if (!attr_set) {

@@ -13,7 +13,8 @@ MARKS, TILES = 6, 8192
 
 def main():
     dev = torch.device("cuda", 0)
-    raw, cams, bg = sear_steak_like_scene(P=200000, n_cams=10, width=1352, height=1014)
+    dense = "--dense" in sys.argv          # the diagnostic scene of `bench.py --scene dense`
+    raw, cams, bg = sear_steak_like_scene(P=200000, n_cams=10, width=1352, height=1014, **({"scale_mean": -2.7} if dense else {}))
     cams = [c.to(dev) for c in cams]; bg = bg.to(dev)
     gt_raw = {k: v.to(dev) for k, v in perturbed_copy(raw).items()}
     with torch.no_grad():
@@ -36,7 +37,7 @@ def main():
     print("workgroup start since launch: median %.2f p90 %.2f last %.2f us" % (np.median(st), np.percentile(st, 90), st.max()))
     c1 = (t[:, 1] - t[:, 0]) * 0.01
     print("count read (+ reset): median %.2f p90 %.2f max %.2f us" % (np.median(c1), np.percentile(c1, 90), c1.max()))
-    for lo, hi in ((1, 64), (65, 128), (129, 256), (257, 512), (513, 1024), (1025, 2048)):
+    for lo, hi in ((1, 64), (65, 128), (129, 256), (257, 512), (513, 1024), (1025, 2048), (2049, 1 << 20)):
         m = (n >= lo) & (n <= hi) & (t[:, 4] >= t[:, 0])
         if m.any():
             life = (t[m, 4] - t[m, 0]) * 0.01
