@@ -827,6 +827,19 @@ extern "C" int igs_morton_order(void* stream, int P, const float* xyz, const flo
     return 0;
 }
 
+// Test support: the per-tile sort of the slab binning on caller-made slabs (sort.hip: launch_tile_sort).  tile_count[T] instances per
+// tile (reset to zero by the launch), pairs[T * slab] = depth bits << 32 | Gaussian id, out: point_list[T * slab] (ids, sorted by the
+// 64-bit key inside every tile's slab), ranges[2 T], stats[4] ([1] = largest tile that overflowed its slab).  Everything device memory.
+extern "C" int igs_debug_tile_sort(void* stream, int T, uint32_t* tile_count, const unsigned long long* pairs, uint32_t* point_list,
+                                   uint32_t* ranges, int slab, uint32_t* stats, int P)
+{
+    if (T <= 0 || slab <= 0 || P <= 0) return fail(IGS_RAST_E_INVALID, "igs_debug_tile_sort: bad sizes");
+    if (!tile_count || !pairs || !point_list || !ranges || !stats) return fail(IGS_RAST_E_INVALID, "igs_debug_tile_sort: NULL pointer");
+    HIP_TRY(launch_tile_sort((hipStream_t)stream, (uint32_t)T, tile_count, (const uint64_t*)pairs, point_list, ranges, (uint32_t)slab, stats,
+                             nullptr, (uint32_t)P), "tile_sort launch");
+    return 0;
+}
+
 extern "C" int igs_rast_mark_visible(void* stream, int P, const float* means3D, const float* viewmatrix,
                                      const float* projmatrix, uint8_t* present)
 {

@@ -367,6 +367,14 @@ int igs_l1_loss_fwd_bwd(void* stream, size_t n, const float* pred, const float* 
  * of the library itself, no PyTorch / rocPRIM sort on the stream path).  lohi: {lo.xyz, hi.xyz} of the positions, 6 floats in
  * DEVICE memory; bits: 1..10 per axis; scratch: igs_morton_order_scratch_bytes(P) bytes. */
 size_t igs_morton_order_scratch_bytes(int P);
+
+/* Test support: the per-tile sort of the slab binning (the replacement of cub::DeviceRadixSort::SortPairs + identifyTileRanges,
+ * rasterizer_impl.cu:373-391, for instances that were binned per tile) on caller-made slabs.  tile_count[T]: instances per tile (reset
+ * to zero by the call); pairs[T * slab]: depth bits << 32 | Gaussian id; out: point_list[T * slab] = the ids of every tile's slab in
+ * ascending key order, ranges[2 T] = {t * slab, t * slab + count} (empty for a tile whose count exceeds `slab`), stats[4]: [1] = the
+ * largest such count.  ids are clamped to P - 1.  All pointers DEVICE memory. */
+int igs_debug_tile_sort(void* stream, int T, unsigned int* tile_count, const unsigned long long* pairs, unsigned int* point_list,
+                        unsigned int* ranges, int slab, unsigned int* stats, int P);
 int igs_morton_order(void* stream, int P, const float* xyz, const float* lohi, int bits, void* scratch, int* perm);
 
 /* Densification support (igs/models/gaussian_model.py:586-663,865-868; driven by infer_batch.py:308-321).

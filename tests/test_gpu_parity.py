@@ -1790,3 +1790,52 @@ def test_self_cleaning_binning_counters_survive_a_broken_promise(dev, poison):
     pa.grad.zero_()
     ra.step(view=0)                      # ... and the buffer is clean again
     check()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("slab", [1024, 2048, 4096])
+def test_tile_sort_every_size_class_against_numpy(dev, slab):
+    """The per-tile sort on hand-made slabs, one tile per size at and around every boundary of its code paths (register sorts of 64 E
+    keys by one wave, the four-wave register + LDS-exchange sort of the grown-slab kernel, the 128 KB LDS kernel above 2048), keys with
+    many equal depths: ids come out in ascending (depth bits << 32 | id) order, ranges and the reset of the fill cursors are right, a tile
+    beyond its slab gets an empty range and reports its size."""
+    import ctypes as C
+    from igs_amd import _cabi
+    L = _cabi.lib()
+    P = 1 << 20
+    sizes = [0, 1, 2, 63, 64, 65, 127, 128, 129, 255, 256, 257, 300, 511, 512, 513, 700, 1000, 1023, 1024]
+    if slab > 1024:
+        sizes += [1025, 1500, 2047, 2048]
+    if slab > 2048:
+        sizes += [2049, 3000, 4095, 4096]
+    sizes += [slab + 5]                                  # overflows its slab
+    sizes = sizes * 2                                    # (two tiles of every size: neighbours in a workgroup differ)
+    rng = np.random.default_rng(slab)
+    T = len(sizes)
+    pairs = np.zeros((T, slab), dtype=np.uint64)
+    expect = []
+    for t, n in enumerate(sizes):
+        m = min(n, slab)
+        depth = rng.integers(0, 40, size=m, dtype=np.uint64) if t % 3 == 0 else rng.integers(0, 1 << 32, size=m, dtype=np.uint64)
+        ids = rng.permutation(P)[:m].astype(np.uint64)
+        keys = (depth << np.uint64(32)) | ids
+        pairs[t, :m] = keys
+        expect.append((np.sort(keys) & np.uint64(0xFFFFFFFF)).astype(np.uint32))
+    d_pairs = torch.from_numpy(pairs.view(np.int64)).to(dev)
+    d_cnt = torch.tensor(sizes, dtype=torch.int32, device=dev)
+    d_list = torch.full((T, slab), -1, dtype=torch.int32, device=dev)
+    d_ranges = torch.full((T, 2), -1, dtype=torch.int32, device=dev)
+    d_stats = torch.zeros(4, dtype=torch.int32, device=dev)
+    rc = L.igs_debug_tile_sort(torch.cuda.current_stream(dev).cuda_stream, T, d_cnt.data_ptr(), d_pairs.data_ptr(), d_list.data_ptr(),
+                               d_ranges.data_ptr(), slab, d_stats.data_ptr(), P)
+    assert rc == 0
+    torch.cuda.synchronize()
+    got = d_list.cpu().numpy().view(np.uint32); ranges = d_ranges.cpu().numpy().view(np.uint32)
+    assert int(d_cnt.abs().sum()) == 0                   # every fill cursor reset
+    assert int(d_stats[1]) == slab + 5
+    for t, n in enumerate(sizes):
+        if n > slab:
+            assert ranges[t, 0] == ranges[t, 1] == t * slab
+            continue
+        assert (ranges[t, 0], ranges[t, 1]) == (t * slab, t * slab + n), (t, n)
+        np.testing.assert_array_equal(got[t, :n], expect[t], err_msg="tile %d of %d instances" % (t, n))
