@@ -187,6 +187,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None, help="timed steps (default: 200 for cfg3 / cfg2, 2500 for cfg4, 15000 for cfg5)")
     ap.add_argument("--warmup", type=int, default=30)
+    ap.add_argument("--spinup-ms", type=float, default=200.0,
+                    help="before the W warm-up steps: keep the GPU busy this long with the same step on a SCRATCH copy of the scene\n"
+                         "(the real parameters are not touched).  A fresh or idle MI355X runs the same 20 steps at 0.277 ms each and,\n"
+                         "~50 ms of work later, at 0.244 (clock ramp; tools/experiments/spin_test.py, DESIGN.md section 5).  0 = off")
     ap.add_argument("--config", default="cfg3", choices=["cfg2", "cfg3", "cfg4", "cfg5"], help="BASELINE.json configs[1..4] (see module docstring)")
     ap.add_argument("--mode", default=None, choices=["refine", "forward"], help="alias: --mode forward = --config cfg2")
     ap.add_argument("--scene", default="bench", choices=["bench", "dense"],
@@ -313,6 +317,24 @@ def main():
             ref.want_viewspace_grad = args.viewspace_grad
             ref.exchange = args.exchange
             psnr_before = eval_psnr()
+            if args.spinup_ms > 0:
+                # device spin-up on a scratch copy (no collectives, the real parameters and optimiser state stay as they are)
+                p_spin = GaussianParams(raw, dev)
+                if not args.no_spatial_sort:
+                    p_spin.spatial_sort()
+                r_spin = Refiner(p_spin, cams, gts, bg, loss=loss, seed=12345, lambda_depth_normal=ldn)
+                r_spin.require_geometry, r_spin.clamp, r_spin.want_viewspace_grad = ref.require_geometry, clamp, args.viewspace_grad
+                t_spin, n_spin = time.perf_counter(), 0
+                while (time.perf_counter() - t_spin) * 1e3 < args.spinup_ms:
+                    for _ in range(20):
+                        r_spin.step()
+                    torch.cuda.synchronize()
+                    n_spin += 20
+                out_extra["spinup"] = {"ms": args.spinup_ms, "steps_on_a_scratch_copy": n_spin,
+                                       "note": "untimed, before the W warm-up steps, on a separate copy of the parameters: brings the GPU's clocks to "
+                                               "their steady state (the same 20 steps: 0.277 ms each on an idle GPU, 0.244 after ~50 ms of work; "
+                                               "tools/experiments/spin_test.py); --spinup-ms 0 turns it off"}
+                del r_spin, p_spin
             for _ in range(args.warmup):
                 ref.step()
             torch.cuda.synchronize()
@@ -397,6 +419,14 @@ def main():
                                                       cam.world_view_transform, cam.full_proj_transform, cam.tanfovx, cam.tanfovy, 0.0,
                                                       cam.height, cam.width, a["shs"], 3, cam.camera_center, False,
                                                       not args.colour_only_forward, not args.colour_only_forward, False, buffers=bufs)
+            if args.spinup_ms > 0:              # device spin-up (the forward has no state to disturb)
+                t_spin, n_spin = time.perf_counter(), 0
+                while (time.perf_counter() - t_spin) * 1e3 < args.spinup_ms:
+                    for i in range(20):
+                        fwd(i)
+                    torch.cuda.synchronize()
+                    n_spin += 20
+                out_extra["spinup"] = {"ms": args.spinup_ms, "frames": n_spin, "note": "untimed, before the W warm-up frames (GPU clock ramp; --spinup-ms 0 = off)"}
             for i in range(args.warmup):
                 fwd(i)
             torch.cuda.synchronize()
