@@ -21,6 +21,10 @@ Configurations (BASELINE.json `configs`; every scene is the synthe
   cfg5  cfg4 with the RaDe-GS depth-normal regulariser (lambda 0.05: the <depth, normal> backward instance) and the clamp
         variant's +-15 gradient clamp; default 15000 steps = 300 frames.
 
+Before the W warm-up steps cfg3 / cfg2 keep the GPU busy for --spinup-ms (default 200 ms, untimed) with the same step on a SCRATCH copy
+of the scene: an idle MI355X runs the same 20 steps 13 % slower than 50 ms of work later (clock ramp; tools/experiments/spin_test.py,
+profiles/r03_spin_test.txt).  The real parameters, optimiser state and view sequence are not touched; `spinup` in the JSON line says what ran.
+
 value = Gaussians x views processed / seconds, whole job (all ranks), inputs resident in HBM when the timed region starts.
 Rank 0 prints ONE JSON line with `roofline` (dominant kernel: HIP-event stage timing + algorithmic bytes + pixel-Gaussian pairs/s),
 `cpu_baseline` (N = 1 only: the pure-PyTorch restatement on BASELINE cfg-1 on all host cores, plus the scalar C port on a bounded
