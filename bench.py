@@ -681,6 +681,13 @@ def main():
                             insts = sum(pm[k].get(c, 0.0) for c in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS"))
                             vi[k] = {"wave_insts_per_launch": insts, "valu": pm[k]["SQ_INSTS_VALU"], "salu": pm[k].get("SQ_INSTS_SALU"),
                                      "lds": pm[k].get("SQ_INSTS_LDS"), "issue_frac": insts * 2.5 / 1024.0 / (per[k] * 1e-3 * 2.4e9)}
+                    if dom in pm and pm[dom].get("hbm_bytes_per_launch"):
+                        # HBM bytes per launch of the dominant kernel: FETCH_SIZE + WRITE_SIZE passes of rocprofv3 on this same command,
+                        # with the guide's unit and gfx950 corrections (tools/summarize_profile.py) -- the committed profile, not this process
+                        roof["traffic"] = pm[dom]["hbm_bytes_per_launch"]
+                        roof["traffic_note"] = ("HBM bytes per launch from the committed rocprofv3 PMC passes of this same command (separate FETCH_SIZE / "
+                                                "WRITE_SIZE runs, corrected as MI355X_MICROARCH.md prescribes: profiles/r03_pmc.json, tools/profile_all.sh); "
+                                                "NOT counted in this process")
                     roof["issue"] = dict(vi, note="vector + scalar + LDS wave-instructions per launch from profiles/r03_pmc.json (NOT counted in this "
                                          "process) x 2.5 cycles per instruction and SIMD -- scalar instructions cost an issue slot like vector ones "
                                          "(tools/ubench/scalar_cost, profiles/r03_ubench_scalar_cost.txt) -- / 1024 SIMDs / (this run's launch time x "
