@@ -246,6 +246,7 @@ static int forward_impl(
     uint32_t* point_list = nullptr;
     uint32_t R = 0;
     bool slab_pending = false;            // slab path: the host has not looked at R yet
+    bool use_step_order = false; uint32_t* step_cursors = nullptr;      // fused refine step: see the tile sort below
     uint32_t slab_size = 0;                // slab size of this call
     const uint32_t* slab_stats = nullptr;
 
@@ -284,8 +285,14 @@ static int forward_impl(
                 "preprocess_fwd launch");
         DBG_SYNC("preprocess_fwd");
         prof_mark(s, ST_PREPROCESS);
-        HIP_TRY(launch_tile_sort(s, (uint32_t)Tn, tile_count, pairs, point_list, ranges, slab_size, stats, counters, (uint32_t)P), "tile_sort launch");
-        g_counters_dirty = false;
+        // fused refine step: the tile sort also writes the blend kernel's dispatch order and leaves the fill cursors for that kernel to zero
+        static const bool no_step_order = getenv("IGS_NO_STEP_ORDER") != nullptr;      // (A/B switch for measurements)
+        use_step_order = !no_step_order && ex.fused_bwd && ex.skip_bwd_state && !colors_precomp && (require_coord != 0) == (require_depth != 0)
+                         && step_order_usable((uint32_t)gx, (uint32_t)gy, slab_size);
+        step_cursors = tile_count;
+        HIP_TRY(launch_tile_sort(s, (uint32_t)Tn, tile_count, pairs, point_list, ranges, slab_size, stats, counters, (uint32_t)P,
+                                 use_step_order ? (uint32_t*)(ibase + IL.tile_order) : nullptr, (uint32_t)gx, (uint32_t)gy), "tile_sort launch");
+        g_counters_dirty = use_step_order;          // (then clean only once the blend kernel below has been launched)
         DBG_SYNC("tile_sort");
         prof_mark(s, ST_TILE_SORT);
         slab_stats = stats;
@@ -384,8 +391,14 @@ static int forward_impl(
         bb.ranges = ranges; bb.point_list = point_list; bb.rec = rec; bb.colors_precomp = nullptr;
         bb.tile_order = nullptr;
         ba.tile_order = nullptr;                 // (no separate backward kernel that could use a load order)
+        if (use_step_order) { ba.step_order = (const uint32_t*)(ibase + IL.tile_order); ba.reset_cursors = step_cursors; }
         HIP_TRY(launch_blend_step(s, ba, bb, require_coord != 0, require_depth != 0, ex.fused_instance), "blend_step launch");
+        if (use_step_order) g_counters_dirty = false;
     } else {
+        if (use_step_order) {                    // (cannot happen: the two conditions are the same terms -- but the cursors must not stay dirty)
+            HIP_TRY(zero_fill_async(s, step_cursors, (size_t)Tn * 4), "zero tile counters");
+            g_counters_dirty = false;
+        }
         HIP_TRY(launch_blend_fwd(s, ba, require_coord != 0, require_depth != 0), "blend_fwd launch");
     }
     DBG_SYNC("blend_fwd");

@@ -50,12 +50,14 @@ blend_step_kernel(const BlendFwdArgs f, const BlendBwdArgs b)
     }
     uint32_t tile;
     BTL(0, wall_clock64());
-    // (Dispatch order: plain.  A 250-instance tile that comes up at t = 45 us keeps a few workgroups busy for 35 us after the other 2000
-    //  slots have drained -- profiles/r03_blend_timeline.txt -- but every reordering tried cost more than that tail: heavy tiles first
-    //  [two passes over the grid in one launch] +3 us, light tiles last through an order array built by a one-workgroup kernel +5 us
-    //  [the small launch], light tiles last in two passes -1.9 us but at the price of 5440 workgroups that leave at once:
-    //  tools/experiments/blend_step_order_r03.hip.txt)
-    if (!tile_for_block(blockIdx.x, f.gx, f.gy, tile)) return;
+    // Dispatch order: tile_sort's extra workgroup wrote it (sort.hip: build_step_order -- the plain XCD-aware order with the light tiles
+    // last); without it (dense scenes, huge images) the plain order.  Every reordering that needed a launch or empty workgroups of its
+    // own cost more than the drain it removes (profiles/r03_blend_order_ab.txt).
+    if (f.step_order) {
+        tile = f.step_order[blockIdx.x];
+        if (tile >= (uint32_t)(f.gx * f.gy)) return;
+    } else if (!tile_for_block(blockIdx.x, f.gx, f.gy, tile)) return;
+    if (f.reset_cursors && threadIdx.x == 0) f.reset_cursors[tile] = 0u;          // (the tile sort left this fill cursor for us to zero)
     BTL(3, (unsigned long long)(f.ranges[2 * tile + 1] - f.ranges[2 * tile]));
     FwdPix px;
     blend_fwd_tile<COORD, DEPTH, NORMAL, true, false>(f, tile, (float4*)smem, quad_bits_f, wave_done, px);

@@ -99,7 +99,8 @@ struct ImgLayout {
         stats = o;         o += 256;                       // ... [0] R, [1] largest tile that overflowed its slab (0 = none), [2] prefilter flag
         counters = o;      o += (COUNTER_SHARDS + 1) * COUNTER_SHARD_STRIDE * 4;   // ... instance-count shards; these three are zeroed by one fill
         zero_end = o;
-        tile_order = o;    o += align_up((T + 1) * 4, 256);  // tile ids, heaviest load class first, then [T] = "use it" (blend_fwd's workgroup 0)
+        tile_order = o;    o += align_up((8 * T + 16) * 4, 256);  // tile ids, heaviest load class first, then [T] = "use it" (blend_fwd's workgroup 0);
+                                                                  // or one tile id per workgroup of the fused blend kernel (its grid has < 8 T + 8 of them)
         total = o + 256;
     }
 };
@@ -124,7 +125,8 @@ hipError_t launch_preprocess_fwd(hipStream_t s, const FwdParams& p, float* rec, 
                                  uint32_t* tile_count, uint64_t* pairs, uint32_t slab);
 void sort_geometry(uint32_t n, uint32_t* nb, uint32_t* per);
 hipError_t launch_tile_sort(hipStream_t s, uint32_t T, uint32_t* tile_count, const uint64_t* pairs, uint32_t* point_list,
-                            uint32_t* ranges, uint32_t slab, uint32_t* stats, uint32_t* counters, uint32_t P);
+                            uint32_t* ranges, uint32_t slab, uint32_t* stats, uint32_t* counters, uint32_t P,
+                            uint32_t* step_order = nullptr, uint32_t gx = 0, uint32_t gy = 0);
 hipError_t launch_compact_lists(hipStream_t s, uint32_t T, const uint32_t* ranges_in, const uint32_t* list_in, uint32_t* ranges_out,
                                 uint32_t* list_out, uint32_t out_capacity);
 hipError_t launch_mark_visible(hipStream_t s, int P, const float* means3D, const float* view, uint8_t* present);
@@ -154,6 +156,9 @@ struct BlendFwdArgs {
     int skip_bwd_state = 0;      // igs_refine_step with a colour-only loss: the backward instance that will run reads none of accum_coord /
                                  // accum_depth / normal_length / the median index -- do not write them (24 of 88 bytes per pixel)
     uint32_t* tile_order = nullptr;            // [T] out: tile ids by descending load class, built by workgroup 0 on the side (for the backward)
+    // fused step (blend_step.hip) only: step_order[b] = the tile of workgroup b (tile_sort's extra workgroup wrote it: light tiles last);
+    // reset_cursors[T] = the slab binning's fill cursors, which tile_sort then leaves for this kernel to zero (one word per tile)
+    const uint32_t* step_order = nullptr; uint32_t* reset_cursors = nullptr;
 };
 hipError_t launch_blend_fwd(hipStream_t s, const BlendFwdArgs& a, bool coord, bool depth);
 
@@ -314,6 +319,10 @@ __device__ __forceinline__ bool tile_for_block(uint32_t b, uint32_t gx, uint32_t
     return row < gy;
 }
 static inline uint32_t tile_grid_blocks(uint32_t gx, uint32_t gy) { return 8u * ((gy + 7u) / 8u) * gx; }
+// The fused blend kernel's dispatch order (sort.hip: build_step_order): usable when tile_sort's one-wave-per-tile kernel runs (slabs
+// of at most 1024 slots) and an XCD group has at most 64 * STEP_ORDER_CHUNKS workgroups.
+#define STEP_ORDER_CHUNKS 16
+static inline bool step_order_usable(uint32_t gx, uint32_t gy, uint32_t slab) { return slab <= 1024u && ((gy + 7u) / 8u) * gx <= 64u * STEP_ORDER_CHUNKS; }
 
 // Longest-first dispatch of the BACKWARD blend.  A tile's blend time is proportional to its instance count, which ranges from 0 to
 // several times the mean; workgroups are dispatched in block order, and with ~2.7 generations of resident workgroups a heavy tile

@@ -490,11 +490,58 @@ extern "C" int igs_debug_sort_timeline(unsigned long long* host, int n)
 // caller that keeps its buffers (igs_refine_step, scratch_clean) needs no zero-fill launch per frame.  Every id written to the
 // sorted list is clamped to id_max = P - 1: whatever a caller's broken promise puts into the slabs, the blend kernels never gather
 // outside the record array.
+// Dispatch order of the fused blend kernel (blend_step.hip), built on the side by TWO extra workgroups of the tile sort -- the counts are
+// all there when this launch starts, and nobody resets them during it in that mode.  The order is the plain XCD-aware one
+// (common.h: tile_for_block) except that the LIGHT tiles come last: a tile's forward + backward takes 8 us (empty) to 85 us (250
+// instances), and in plain order a heavy tile that comes up at t = 45 us keeps a few workgroups busy for 35 us after the other 2000
+// slots have drained (profiles/r03_blend_timeline.txt).  Heaviest-first is not the answer (heavy tiles together run slower and the
+// store-bound near-empty ones no longer hide under them); keeping the mix and moving the tiles below STEP_ORDER_T0 / T1 instances and
+// the empty ones to the end makes the drain phase consist of short workgroups: blend_step 121.4 -> 117.6 us (rocprofv3, same box).
+// Every XCD group (workgroups b = 8 k + x) is partitioned on its own (stable), so every tile stays on the L2 it had; one wave per group
+// (two extra workgroups).
+#define STEP_ORDER_T0 64u
+#define STEP_ORDER_T1 32u
+__device__ __forceinline__ void build_step_order(const uint32_t* __restrict__ tile_count, uint32_t slab, uint32_t gx, uint32_t gy,
+                                                 uint32_t* __restrict__ order, uint32_t half)
+{
+    const uint32_t lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const uint32_t per = ((gy + 7u) / 8u) * gx;                   // workgroups of one XCD group (<= 64 * STEP_ORDER_CHUNKS: step_order_usable)
+    {
+        const uint32_t x = 4u * half + wid;               // two extra workgroups: wave w of workgroup `half` takes XCD group 4 half + w
+        // every count of the group in ONE memory round trip, then four passes over registers
+        uint32_t tl[STEP_ORDER_CHUNKS], cl[STEP_ORDER_CHUNKS];
+#pragma unroll
+        for (int i = 0; i < STEP_ORDER_CHUNKS; i++) {
+            const uint32_t k = 64u * i + lane;
+            uint32_t tile = 0xFFFFFFFFu, n = 0u;
+            const bool ok = k < per && tile_for_block(8u * k + x, gx, gy, tile);
+            if (ok) { n = tile_count[tile]; if (n > slab) n = 0u; }                       // (an overflowed tile gets an empty range)
+            tl[i] = ok ? tile : 0xFFFFFFFFu;
+            cl[i] = k >= per ? 4u : !ok ? 3u : n >= STEP_ORDER_T0 ? 0u : n >= STEP_ORDER_T1 ? 1u : n > 0u ? 2u : 3u;
+        }
+        uint32_t out = 0;
+        for (uint32_t c = 0; c < 4u; c++) {
+#pragma unroll
+            for (int i = 0; i < STEP_ORDER_CHUNKS; i++) {
+                const bool mine = cl[i] == c;
+                const unsigned long long m = __ballot(mine);
+                if (mine) order[8u * (out + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))) + x] = tl[i];
+                out += (uint32_t)__popcll(m);
+            }
+        }
+    }
+}
+
 __global__ void __launch_bounds__(256)
 tile_sort_kernel(uint32_t T, uint32_t* __restrict__ tile_count, const uint64_t* __restrict__ pairs,
                  uint32_t* __restrict__ point_list, uint32_t* __restrict__ ranges, uint32_t slab, uint32_t* __restrict__ stats,
-                 uint32_t* __restrict__ counters, uint32_t id_max, int clean_counts, uint32_t wave_max)
+                 uint32_t* __restrict__ counters, uint32_t id_max, int clean_counts, uint32_t wave_max,
+                 uint32_t* __restrict__ step_order, uint32_t gx, uint32_t gy)
 {
+    if (step_order && blockIdx.x >= gridDim.x - 2) {          // the extra workgroups (clean_counts is 0 in this mode: nobody writes the counts)
+        build_step_order(tile_count, slab, gx, gy, step_order, blockIdx.x - (gridDim.x - 2));
+        return;
+    }
     const uint32_t tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     if (blockIdx.x == 0 && wid == 0 && counters) {
         // R = sum of the preprocess kernel's counter shards
@@ -670,7 +717,8 @@ tile_sort_one_kernel(uint32_t T, uint32_t* __restrict__ tile_count, const uint64
 #define TILE_SORT_WAVE_WITH_MID 1024      // ... larger slabs: the register sort keeps the tiles up to this size, the LDS kernel takes the rest
 #endif                                    // (256 / 512 measured: no better on the dense scene, and a second launch for nothing on the bench scene's 1024-slot slabs)
 hipError_t launch_tile_sort(hipStream_t s, uint32_t T, uint32_t* tile_count, const uint64_t* pairs, uint32_t* point_list,
-                            uint32_t* ranges, uint32_t slab, uint32_t* stats, uint32_t* counters, uint32_t P)
+                            uint32_t* ranges, uint32_t slab, uint32_t* stats, uint32_t* counters, uint32_t P,
+                            uint32_t* step_order, uint32_t gx, uint32_t gy)
 {
     const bool mid = slab > TILE_SORT_WAVE_ALONE, big = slab > TILE_SORT_SMALL;
     const uint32_t id_max = P ? P - 1u : 0u;
@@ -682,8 +730,11 @@ hipError_t launch_tile_sort(hipStream_t s, uint32_t T, uint32_t* tile_count, con
 #endif
     {
     // whichever launch reads the fill cursors last resets them
-    hipLaunchKernelGGL(tile_sort_kernel, dim3((T + 3) / 4), dim3(256), 0, s, T, tile_count, pairs, point_list, ranges, slab, stats, counters,
-                       id_max, mid ? 0 : 1, wave_max);
+    // with a step order wanted (fused refine step, step_order_usable): one extra workgroup builds it from the fill cursors, and these stay
+    // as they are -- the fused blend kernel zeroes them (BlendFwdArgs::reset_cursors)
+    const bool ord = step_order != nullptr && !mid;
+    hipLaunchKernelGGL(tile_sort_kernel, dim3((T + 3) / 4 + (ord ? 2 : 0)), dim3(256), 0, s, T, tile_count, pairs, point_list, ranges, slab, stats, counters,
+                       id_max, (mid || ord) ? 0 : 1, wave_max, ord ? step_order : nullptr, gx, gy);
     if (mid) hipLaunchKernelGGL(tile_sort_mid_kernel, dim3(T), dim3(256), 0, s, tile_count, pairs, point_list, slab, id_max, big ? 0 : 1, wave_max);
     }
     if (big) {
