@@ -499,8 +499,12 @@ extern "C" int igs_debug_sort_timeline(unsigned long long* host, int n)
 // the empty ones to the end makes the drain phase consist of short workgroups: blend_step 121.4 -> 117.6 us (rocprofv3, same box).
 // Every XCD group (workgroups b = 8 k + x) is partitioned on its own (stable), so every tile stays on the L2 it had; one wave per group
 // (two extra workgroups).
+#ifndef STEP_ORDER_T0
 #define STEP_ORDER_T0 64u
+#endif
+#ifndef STEP_ORDER_T1
 #define STEP_ORDER_T1 32u
+#endif
 __device__ __forceinline__ void build_step_order(const uint32_t* __restrict__ tile_count, uint32_t slab, uint32_t gx, uint32_t gy,
                                                  uint32_t* __restrict__ order, uint32_t half)
 {
