@@ -22,7 +22,7 @@ Configurations (BASELINE.json `configs`; every scene is the synthe
         variant's +-15 gradient clamp; default 15000 steps = 300 frames.
 
 Before the W warm-up steps cfg3 / cfg2 keep the GPU busy for --spinup-ms (default 200 ms, untimed) with the same step on a SCRATCH copy
-of the scene: an idle MI355X runs the same 20 steps 13 % slower than 50 ms of work later (clock ramp; tools/experiments/spin_test.py,
+of the scene: an idle MI355X runs the same 20 steps 13 % slower than 50 ms of work later (clock ramp; tools/experiments/spin_probe.py,
 profiles/r03_spin_test.txt).  The real parameters, optimiser state and view sequence are not touched; `spinup` in the JSON line says what ran.
 
 value = Gaussians x views processed / seconds, whole job (all ranks), inputs resident in HBM when the timed region starts.
@@ -194,7 +194,7 @@ def main():
     ap.add_argument("--spinup-ms", type=float, default=200.0,
                     help="before the W warm-up steps: keep the GPU busy this long with the same step on a SCRATCH copy of the scene\n"
                          "(the real parameters are not touched).  A fresh or idle MI355X runs the same 20 steps at 0.277 ms each and,\n"
-                         "~50 ms of work later, at 0.244 (clock ramp; tools/experiments/spin_test.py, DESIGN.md section 5).  0 = off")
+                         "~50 ms of work later, at 0.244 (clock ramp; tools/experiments/spin_probe.py, DESIGN.md section 5).  0 = off")
     ap.add_argument("--config", default="cfg3", choices=["cfg2", "cfg3", "cfg4", "cfg5"], help="BASELINE.json configs[1..4] (see module docstring)")
     ap.add_argument("--mode", default=None, choices=["refine", "forward"], help="alias: --mode forward = --config cfg2")
     ap.add_argument("--scene", default="bench", choices=["bench", "dense"],
@@ -337,7 +337,7 @@ def main():
                 out_extra["spinup"] = {"ms": args.spinup_ms, "steps_on_a_scratch_copy": n_spin,
                                        "note": "untimed, before the W warm-up steps, on a separate copy of the parameters: brings the GPU's clocks to "
                                                "their steady state (the same 20 steps: 0.277 ms each on an idle GPU, 0.244 after ~50 ms of work; "
-                                               "tools/experiments/spin_test.py); --spinup-ms 0 turns it off"}
+                                               "tools/experiments/spin_probe.py); --spinup-ms 0 turns it off"}
                 del r_spin, p_spin
             for _ in range(args.warmup):
                 ref.step()

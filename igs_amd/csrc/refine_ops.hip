@@ -99,6 +99,62 @@ extern "C" int igs_adam_step_groups(void* stream, int ngroups, const size_t* off
     return hipGetLastError() == hipSuccess ? 0 : IGS_RAST_E_HIP;
 }
 
+// The same update over up to 8 SEPARATE tensors in one launch (igs_amd/optim.py: a torch.optim.Optimizer whose parameters are ordinary
+// nn.Parameters, each with its own gradient / moment allocation and its own step count).  blockIdx.y = tensor.
+struct AdamMulti { int n; float* p[8]; const float* g[8]; float* m[8]; float* v[8]; size_t cnt[8]; float lr_over_bc1[8]; float inv_sqrt_bc2[8]; };
+__global__ void __launch_bounds__(256)
+adam_multi_kernel(const AdamMulti G, float b1, float b2, float eps)
+{
+    const int k = blockIdx.y;
+    if (k >= G.n) return;
+    const size_t n = G.cnt[k];
+    const float lr = G.lr_over_bc1[k], isb = G.inv_sqrt_bc2[k];
+    float* pp = G.p[k]; const float* gg = G.g[k]; float* mm = G.m[k]; float* vv = G.v[k];
+    const bool aligned = (((uintptr_t)pp | (uintptr_t)gg | (uintptr_t)mm | (uintptr_t)vv) & 15) == 0;
+    const size_t n4 = aligned ? n / 4 : 0;
+    const size_t stride = (size_t)gridDim.x * 256;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+        float4 P4 = ((float4*)pp)[i], M4 = ld_moment((const float4*)mm + i), V4 = ld_moment((const float4*)vv + i);
+        const float4 G4 = ((const float4*)gg)[i];
+        float* a = (float*)&P4; float* b = (float*)&M4; float* c = (float*)&V4; const float* d = (const float*)&G4;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            b[q] = b1 * b[q] + (1.f - b1) * d[q];
+            c[q] = b2 * c[q] + (1.f - b2) * d[q] * d[q];
+            a[q] -= lr * b[q] / (sqrtf(c[q]) * isb + eps);
+        }
+        ((float4*)pp)[i] = P4; st_moment((float4*)mm + i, M4); st_moment((float4*)vv + i, V4);
+    }
+    for (size_t i = n4 * 4 + (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+        const float gi = gg[i];
+        const float mi = b1 * mm[i] + (1.f - b1) * gi;
+        const float vi = b2 * vv[i] + (1.f - b2) * gi * gi;
+        mm[i] = mi; vv[i] = vi;
+        pp[i] -= lr * mi / (sqrtf(vi) * isb + eps);
+    }
+}
+extern "C" int igs_adam_step_multi(void* stream, int ntensors, float* const* param, const float* const* grad, float* const* exp_avg,
+                                   float* const* exp_avg_sq, const size_t* count, const float* lr, const float* bias_correction1,
+                                   const float* bias_correction2_sqrt, float beta1, float beta2, float eps)
+{
+    if (ntensors <= 0) return 0;
+    if (ntensors > 8 || !param || !grad || !exp_avg || !exp_avg_sq || !count || !lr || !bias_correction1 || !bias_correction2_sqrt)
+        return IGS_RAST_E_INVALID;
+    AdamMulti G; G.n = ntensors;
+    size_t nmax = 0;
+    for (int k = 0; k < ntensors; k++) {
+        if (count[k] && (!param[k] || !grad[k] || !exp_avg[k] || !exp_avg_sq[k])) return IGS_RAST_E_INVALID;
+        G.p[k] = param[k]; G.g[k] = grad[k]; G.m[k] = exp_avg[k]; G.v[k] = exp_avg_sq[k]; G.cnt[k] = count[k];
+        G.lr_over_bc1[k] = lr[k] / bias_correction1[k]; G.inv_sqrt_bc2[k] = 1.0f / bias_correction2_sqrt[k];
+        if (count[k] > nmax) nmax = count[k];
+    }
+    size_t blocks = (nmax / 4 + 255) / 256;
+    if (blocks > 1024) blocks = 1024;
+    if (blocks == 0) blocks = 1;
+    hipLaunchKernelGGL(adam_multi_kernel, dim3((unsigned)blocks, (unsigned)ntensors), dim3(256), 0, (hipStream_t)stream, G, beta1, beta2, eps);
+    return hipGetLastError() == hipSuccess ? 0 : IGS_RAST_E_HIP;
+}
+
 // L1: loss_sum += sum |pred - gt| ; grad = sign(pred - gt) * scale        (mean => scale = upstream / n)
 __global__ void __launch_bounds__(256)
 l1_kernel(size_t n4, size_t n, const float* __restrict__ pred, const float* __restrict__ gt, float* __restrict__ grad, float* __restrict__ loss_sum, float scale)

@@ -3,10 +3,11 @@
 The reference's SSIM runs five grouped 11x11 convolutions forward and their autograd graph backward: 7.3 ms per step at
 1352x1014 on this GPU through PyTorch, against 0.08 ms for the two fused launches here.  `ssim` keeps the reference's signature;
 the fused path serves the call the refine loop makes (`ssim(render, gt.unsqueeze(0), size_average=False)`, infer_batch.py:302,
-gradient w.r.t. the first image only); anything else goes through the PyTorch restatement.
+gradient w.r.t. the first image only); any other call shape raises.  `depth_normal_loss` is RaDe-GS's regulariser
+(train.py:143-160) from one launch.  No PyTorch arithmetic and no CPU path in this module (the restatements the kernels are
+checked against live in oracle/torch_losses.py).
 """
 import torch
-import torch.nn.functional as F
 
 from . import _cabi
 
@@ -45,32 +46,50 @@ class _FusedSsimMean(torch.autograd.Function):
         return (-g * grad).reshape(ctx.in_shape), None
 
 
-def _ssim_torch(img1, img2, window_size, size_average):
-    """loss_utils.py:21-63, as written."""
-    from math import exp
-    channel = img1.size(-3)
-    gauss = torch.Tensor([exp(-(x - window_size // 2) ** 2 / float(2 * 1.5 ** 2)) for x in range(window_size)])
-    w1 = (gauss / gauss.sum()).unsqueeze(1)
-    window = w1.mm(w1.t()).float().unsqueeze(0).unsqueeze(0).expand(channel, 1, window_size, window_size).contiguous().type_as(img1).to(img1.device)
-    pad = window_size // 2
-    mu1 = F.conv2d(img1, window, padding=pad, groups=channel)
-    mu2 = F.conv2d(img2, window, padding=pad, groups=channel)
-    mu1_sq, mu2_sq, mu1_mu2 = mu1.pow(2), mu2.pow(2), mu1 * mu2
-    sigma1_sq = F.conv2d(img1 * img1, window, padding=pad, groups=channel) - mu1_sq
-    sigma2_sq = F.conv2d(img2 * img2, window, padding=pad, groups=channel) - mu2_sq
-    sigma12 = F.conv2d(img1 * img2, window, padding=pad, groups=channel) - mu1_mu2
-    C1, C2 = 0.01 ** 2, 0.03 ** 2
-    ssim_map = ((2 * mu1_mu2 + C1) * (2 * sigma12 + C2)) / ((mu1_sq + mu2_sq + C1) * (sigma1_sq + sigma2_sq + C2))
-    if size_average:
-        return ssim_map.mean(), ssim_map
-    return ssim_map.mean(1).mean(1).mean(1)
-
-
 def ssim(img1, img2, window_size=11, size_average=True):
-    """loss_utils.py:34-63 (same returns: `(mean, map)` with size_average, the per-batch means without).  Fused path: CUDA/HIP
-    tensors, window 11, one image ([3,H,W] or [1,3,H,W] on either side), size_average=False, no gradient needed for img2."""
+    """loss_utils.py:34-63, served by the fused HIP kernels for the call the refine loop makes: GPU tensors, window 11, one image
+    ([3,H,W] or [1,3,H,W] on either side), `size_average=False` (returns the per-batch mean, shape [1]), gradient w.r.t. img1 only.
+    Any other call shape raises: there is no PyTorch / CPU fallback in this package."""
     single = all(t.dim() == 3 or (t.dim() == 4 and t.size(0) == 1) for t in (img1, img2))
     if (img1.is_cuda and img2.is_cuda and window_size == 11 and not size_average and single and not img2.requires_grad
             and img1.shape[-3:] == img2.shape[-3:]):
         return _FusedSsimMean.apply(img1, img2).reshape(1)
-    return _ssim_torch(img1, img2, window_size, size_average)
+    raise NotImplementedError("igs_amd.losses.ssim serves ssim(render, gt.unsqueeze(0), size_average=False) on GPU tensors with the "
+                              "11x11 window (infer_batch.py:302); other call shapes are not implemented (no CPU / PyTorch fallback)")
+
+
+class _DepthNormalLoss(torch.autograd.Function):
+    """RaDe-GS depth-normal consistency (train.py:143-160, graphics_utils.py:97-126): value and the three gradient maps from ONE
+    launch (igs_depth_normal_loss_fwd_bwd); backward scales the stored maps by the upstream gradient."""
+
+    @staticmethod
+    def forward(ctx, depth, mdepth, normal, tan_fovx, tan_fovy, depth_ratio):
+        L = _cabi.lib()
+        dev = depth.device
+        H, W = int(normal.shape[-2]), int(normal.shape[-1])
+        d, m, n = depth.contiguous().float(), mdepth.contiguous().float(), normal.contiguous().float()
+        gd, gm, gn = torch.empty_like(d), torch.empty_like(m), torch.empty_like(n)
+        shards = torch.empty(1024, dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            rc = L.igs_depth_normal_loss_fwd_bwd(torch.cuda.current_stream(dev).cuda_stream, W, H, float(tan_fovx), float(tan_fovy),
+                                                 d.data_ptr(), m.data_ptr(), n.data_ptr(), 1.0, float(depth_ratio), gd.data_ptr(),
+                                                 gm.data_ptr(), gn.data_ptr(), shards.data_ptr())
+        if rc != 0:
+            raise RuntimeError("igs_depth_normal_loss_fwd_bwd failed: %d" % rc)
+        ctx.save_for_backward(gd, gm, gn)
+        ctx.shapes = (depth.shape, mdepth.shape, normal.shape)
+        return shards[::16].sum()
+
+    @staticmethod
+    def backward(ctx, g):
+        gd, gm, gn = ctx.saved_tensors
+        sd, sm, sn = ctx.shapes
+        return (g * gd).reshape(sd), (g * gm).reshape(sm), (g * gn).reshape(sn), None, None, None
+
+
+def depth_normal_loss(pkg, cam, depth_ratio=0.6):
+    """`(1 - depth_ratio) * mean(1 - n . n(depth)) + depth_ratio * mean(1 - n . n(mdepth))` on the rasterizer's outputs
+    (`pkg`: depth_pred, mdepth, normal), differentiable w.r.t. all three; GPU tensors only."""
+    if not pkg["normal"].is_cuda:
+        raise RuntimeError("igs_amd.losses.depth_normal_loss: tensors must be on a GPU (no CPU fallback)")
+    return _DepthNormalLoss.apply(pkg["depth_pred"], pkg["mdepth"], pkg["normal"], cam.tanfovx, cam.tanfovy, depth_ratio)

@@ -18,7 +18,7 @@ import math
 import os
 
 import torch
-import torch.nn.functional as F
+import torch.nn.functional as F      # (F.normalize of the raw quaternion: the caller-side activation)
 
 from . import _cabi
 from . import rasterizer as _rast
@@ -171,29 +171,6 @@ def render(params_act, cam, bg, sh_degree=3, require_coord=True, require_depth=T
                 coord=coord, mcoord=mcoord, mdepth=mdepth, alpha=alpha, normal=normal)
 
 
-def _gaussian_window(size, sigma, channel, device):
-    g = torch.tensor([math.exp(-(x - size // 2) ** 2 / float(2 * sigma ** 2)) for x in range(size)])
-    g = (g / g.sum()).unsqueeze(1)
-    w2 = g.mm(g.t()).float().unsqueeze(0).unsqueeze(0)
-    return w2.expand(channel, 1, size, size).contiguous().to(device)
-
-
-def ssim(img1, img2, window_size=11):
-    """igs/utils/loss_utils.py:34-63 with size_average=False semantics reduced to a scalar (mean over all dims)."""
-    channel = img1.size(-3)
-    window = _gaussian_window(window_size, 1.5, channel, img1.device)
-    x, y = img1.unsqueeze(0), img2.unsqueeze(0)
-    pad = window_size // 2
-    mu1, mu2 = F.conv2d(x, window, padding=pad, groups=channel), F.conv2d(y, window, padding=pad, groups=channel)
-    mu1_sq, mu2_sq, mu1_mu2 = mu1.pow(2), mu2.pow(2), mu1 * mu2
-    s1 = F.conv2d(x * x, window, padding=pad, groups=channel) - mu1_sq
-    s2 = F.conv2d(y * y, window, padding=pad, groups=channel) - mu2_sq
-    s12 = F.conv2d(x * y, window, padding=pad, groups=channel) - mu1_mu2
-    C1, C2 = 0.01 ** 2, 0.03 ** 2
-    m = ((2 * mu1_mu2 + C1) * (2 * s12 + C2)) / ((mu1_sq + mu2_sq + C1) * (s1 + s2 + C2))
-    return m.mean()
-
-
 class L1Fused:
     """Fused L1 forward+backward on the HIP side: returns d(mean |pred-gt|)/dpred without autograd bookkeeping."""
 
@@ -302,7 +279,7 @@ class Refiner:
         self.cache_gt_stats = True
         # RaDe-GS depth-normal regulariser (train.py:143-164; BASELINE cfg-5 uses 0.05): needs dL/d depth, mdepth, normal -- the
         # fused step evaluates it in one HIP launch and runs the <depth, normal> backward instance; the unfused native path does
-        # not implement it (the autograd path does, through igs_amd/regularizers.py)
+        # not implement it (the autograd path does, through igs_amd.losses.depth_normal_loss = the same kernel)
         self.lambda_depth_normal = float(lambda_depth_normal)
         self.native = native          # drive the C ABI directly instead of going through autograd
         self.fused = fused            # ... and on a single GPU run the whole iteration as one library call (igs_refine_step)
@@ -310,7 +287,6 @@ class Refiner:
         self.gen = torch.Generator().manual_seed(seed)      # same seed on every rank -> same view permutation
         self.order = []
         self.last_num_rendered = 0
-        self.torch_ssim = False       # autograd path: use the PyTorch SSIM (five grouped convolutions) instead of the fused one
         # optional densify-and-prune (configs/demo.yaml:57-62): a DensifyConfig; statistics and iteration counter per frame
         self.densify = densify
         # fused step: also return dL/d(screen-space mean) with its absolute-gradient column (what the densification statistics read);
@@ -491,6 +467,22 @@ class Refiner:
         self.last_num_rendered = nr
         return dict(images_pred=imgs[0:3], radii=radii, visibility_filter=None, viewspace_points=self._fused["m2d"] if self.want_viewspace_grad else None,
                     alpha=imgs[11:12], depth_pred=imgs[9:10], normal=imgs[12:15], loss=self._fused["loss"])
+
+    def _ssim_value(self, img, gt):
+        """Autograd path: mean SSIM from the fused HIP kernels (igs_amd.losses.ssim); `ssim_fn` lets a test inject another
+        differentiable implementation (the PyTorch restatement of the test tree) for an independent comparison."""
+        fn = getattr(self, "ssim_fn", None)
+        if fn is not None:
+            return fn(img, gt)
+        from .losses import ssim as fused_ssim
+        return fused_ssim(img, gt.unsqueeze(0), size_average=False).squeeze()
+
+    def _depth_normal_value(self, pkg, cam):
+        fn = getattr(self, "depth_normal_fn", None)
+        if fn is not None:
+            return fn(pkg, cam)
+        from .losses import depth_normal_loss
+        return depth_normal_loss(pkg, cam)
 
     def start_frame(self):
         """A new frame of the stream begins (infer_batch.py:270-278): iteration counter and densification statistics restart."""
@@ -678,12 +670,9 @@ class Refiner:
                 if self.loss == "l1":
                     loss = Ll1
                 else:
-                    from .losses import ssim as fused_ssim
-                    s_val = ssim(img, gt) if self.torch_ssim else fused_ssim(img, gt.unsqueeze(0), size_average=False).squeeze()
-                    loss = self.lambda_l1 * Ll1 + (1.0 - self.lambda_l1) * (1.0 - s_val)
+                    loss = self.lambda_l1 * Ll1 + (1.0 - self.lambda_l1) * (1.0 - self._ssim_value(img, gt))
                 if self.lambda_depth_normal > 0.0:
-                    from .regularizers import depth_normal_loss
-                    self.last_depth_normal_loss = depth_normal_loss(pkg, cam)
+                    self.last_depth_normal_loss = self._depth_normal_value(pkg, cam)
                     loss = loss + self.lambda_depth_normal * self.last_depth_normal_loss
                 grads = torch.autograd.grad([loss * getattr(self, "loss_scale", 1.0)], leaves)
             L = _cabi.lib()
@@ -710,12 +699,9 @@ class Refiner:
             if self.loss == "l1":
                 loss = Ll1
             else:       # infer_batch.py:302, with the drop-in fused SSIM (igs_amd/losses.py) unless the caller asked for torch's
-                from .losses import ssim as fused_ssim
-                s_val = ssim(img, gt) if self.torch_ssim else fused_ssim(img, gt.unsqueeze(0), size_average=False).squeeze()
-                loss = self.lambda_l1 * Ll1 + (1.0 - self.lambda_l1) * (1.0 - s_val)
+                loss = self.lambda_l1 * Ll1 + (1.0 - self.lambda_l1) * (1.0 - self._ssim_value(img, gt))
             if self.lambda_depth_normal > 0.0:
-                from .regularizers import depth_normal_loss
-                self.last_depth_normal_loss = depth_normal_loss(pkg, cam)
+                self.last_depth_normal_loss = self._depth_normal_value(pkg, cam)
                 loss = loss + self.lambda_depth_normal * self.last_depth_normal_loss
             (loss * getattr(self, "loss_scale", 1.0) / self.world_size).backward()
         if self.world_size > 1:

@@ -242,6 +242,13 @@ int igs_adam_step_groups(void* stream, int ngroups, const size_t* offset, const 
                          const float* grad, float* exp_avg, float* exp_avg_sq, float beta1, float beta2, float eps,
                          float bias_correction1, float bias_correction2_sqrt);
 
+/* The same for up to 8 SEPARATE tensors in one launch (each parameter of the reference's optimiser is its own nn.Parameter with its own
+ * gradient and state tensors, torch.optim.Adam keeps one step count per parameter: gaussian_model.py:303-348): arrays of `ntensors`
+ * device pointers / element counts / learning rates / bias corrections in HOST memory, read before the call returns. */
+int igs_adam_step_multi(void* stream, int ntensors, float* const* param, const float* const* grad, float* const* exp_avg,
+                        float* const* exp_avg_sq, const size_t* count, const float* lr, const float* bias_correction1,
+                        const float* bias_correction2_sqrt, float beta1, float beta2, float eps);
+
 /* ---- one whole refine iteration on one view, single GPU --------------------------------------------------------------
  * Native form of the body of the reference's per-frame refine loop (infer_batch.py:279-324 with the L1 photometric loss,
  * igs/utils/loss_utils.py:17; activations of igs/models/gaussian_model.py:90-127; torch.optim.Adam of :295-348):

@@ -685,7 +685,8 @@ def test_fused_tile_kernel_on_the_full_size_dense_scene(dev):
 def test_fused_ssim_l1_loss_matches_torch_autograd(dev, shape):
     """(1 - lambda) L1 + lambda (1 - SSIM), forward + backward in two HIP launches, against the PyTorch restatement of
     igs/utils/loss_utils.py:17-63 (11x11 window, zero padding) differentiated by autograd; ragged sizes cover the borders."""
-    from igs_amd.refine import L1SsimFused, ssim
+    from igs_amd.refine import L1SsimFused
+    from oracle.torch_losses import ssim_mean as ssim
     H, W = shape
     g = torch.Generator().manual_seed(H * 1000 + W)
     gt = torch.rand((3, H, W), generator=g)
@@ -722,12 +723,14 @@ def test_refine_step_with_reference_loss_l1_plus_dssim(dev):
     rf = Refiner(ps[0], cams, gts, bg, loss="l1_ssim", native=True, fused=True)
     rn = Refiner(ps[1], cams, gts, bg, loss="l1_ssim", native=True, fused=False)
     ra = Refiner(ps[2], cams, gts, bg, loss="l1_ssim", native=False)
+    from oracle.torch_losses import ssim_mean
+    ra.ssim_fn = ssim_mean                                 # the autograd step with the PyTorch SSIM restatement (five grouped convolutions)
     pkf = rf.step(view=0); rn.step(view=0); ra.step(view=0)
     lf = float(pkf["loss"].item())
     ln = rn.l1.value(gts[0].numel())
     assert abs(lf - ln) < 1e-5, (lf, ln)
     with torch.no_grad():
-        from igs_amd.refine import ssim
+        from oracle.torch_losses import ssim_mean as ssim
         img = render(activate({k: v.to(dev) for k, v in raw.items()}), cams[0], bg)["images_pred"]
         lt = 0.8 * torch.abs(img - gts[0]).mean() + 0.2 * (1.0 - ssim(img, gts[0]))
     assert abs(lf - float(lt.item())) < 1e-5, (lf, float(lt.item()))
@@ -864,7 +867,7 @@ def test_depth_normal_regulariser_drives_the_full_backward(dev):
     """BASELINE cfg-5 shape: loss + 0.05 * depth_normal_loss (RaDe-GS train.py:143-164) through the autograd Function of the
     clamp-free API: gradients arrive through depth, mdepth and normal (full backward instance), the regulariser goes down."""
     from igs_amd.refine import GaussianParams, Refiner, render
-    from igs_amd.regularizers import depth_normal_loss
+    from oracle.torch_losses import depth_normal_loss
     from igs_amd.scenes import perturbed_copy
     raw, cams, bg = cfg1_scene(P=3000, size=128)
     cams = [cams[0].to(dev)]
@@ -883,7 +886,7 @@ def test_depth_normal_regulariser_drives_the_full_backward(dev):
     assert float(params.leaves["shs"].grad.abs().max()) == 0.0                  # colour does not enter the regulariser
     # (2) refine steps with the regulariser switched on (lr of the geometry only, so that the colour loss cannot hide it)
     params = GaussianParams(raw, dev, lrs=dict(xyz=0.0, rotation=0.01, shs=0.0, opacity=0.0, scaling=0.005))
-    ref = Refiner(params, cams, gts, bg, loss="l1", lambda_depth_normal=1.0, native=False)      # autograd path (regularizers.py)
+    ref = Refiner(params, cams, gts, bg, loss="l1", lambda_depth_normal=1.0, native=False)      # autograd path (igs_amd.losses.depth_normal_loss)
     vals = []
     for _ in range(12):
         ref.step(view=0)
@@ -1155,8 +1158,9 @@ def test_full_size_fused_step_instances_match_oracle(dev, mode):
 
 def test_drop_in_ssim_matches_the_reference_formula(dev):
     """igs_amd.losses.ssim with the reference's call shape (`ssim(render, gt.unsqueeze(0), size_average=False)`): value and
-    gradient against the PyTorch restatement of loss_utils.py:34-63; other argument shapes fall back to that restatement."""
-    from igs_amd.losses import ssim as fused, _ssim_torch
+    gradient against the PyTorch restatement of loss_utils.py:34-63 (oracle/torch_losses.py); other argument shapes raise."""
+    from igs_amd.losses import ssim as fused
+    from oracle.torch_losses import ssim_reference_call as _ssim_torch
     g = torch.Generator().manual_seed(9)
     gt = torch.rand((3, 90, 131), generator=g).to(dev)
     x = (gt + 0.1 * torch.randn(gt.shape, generator=g).to(dev)).clamp(0, 1)
@@ -1168,18 +1172,20 @@ def test_drop_in_ssim_matches_the_reference_formula(dev):
     torch.testing.assert_close(va, vb, rtol=1e-5, atol=1e-6)
     (1.0 - va).sum().backward(); (1.0 - vb).sum().backward()
     assert float((a.grad - b.grad).abs().max()) < 2e-4 * float(b.grad.abs().max())
-    m, mp = fused(x, gt, size_average=True)                       # fallback keeps the (mean, map) return
-    assert mp.shape == (3, 90, 131) and abs(float(m.detach()) - float(vb.detach())) < 1e-5
+    with pytest.raises(NotImplementedError):                      # no PyTorch fallback in the product package
+        fused(x, gt, size_average=True)
+    with pytest.raises(NotImplementedError):
+        fused(x.cpu(), gt.cpu().unsqueeze(0), size_average=False)
 
 
 @pytest.mark.parametrize("shape", [(64, 80), (45, 37)])
 def test_fused_depth_normal_regulariser_matches_autograd(dev, shape):
     """igs_depth_normal_loss_fwd_bwd (one launch: value + dL/ddepth, dL/dmdepth, dL/dnormal) against autograd through the PyTorch
-    restatement of RaDe-GS graphics_utils.py:97-126 / train.py:143-160 (igs_amd/regularizers.py)."""
+    restatement of RaDe-GS graphics_utils.py:97-126 / train.py:143-160 (oracle/torch_losses.py)."""
     import math
     from igs_amd import _cabi
     from igs_amd.camera import Camera
-    from igs_amd.regularizers import depth_normal_loss
+    from oracle.torch_losses import depth_normal_loss
     H, W = shape
     cam = Camera(torch.eye(4), 2 * math.atan(W / (2 * 55.0)), 2 * math.atan(H / (2 * 60.0)), (H, W))
     g = torch.Generator().manual_seed(H + W)
@@ -1207,7 +1213,7 @@ def test_fused_depth_normal_regulariser_matches_autograd(dev, shape):
 
 def test_fused_step_with_depth_normal_regulariser(dev):
     """BASELINE cfg-5 shape natively: igs_refine_step with lambda_depth_normal (regulariser in one HIP launch, <depth, normal>
-    backward instance, L1 or L1 + D-SSIM alongside) against the autograd step through igs_amd/regularizers.py."""
+    backward instance, L1 or L1 + D-SSIM alongside) against the autograd step (igs_amd.losses.depth_normal_loss = the same kernel as an autograd Function) and the loss value of the PyTorch restatement (oracle/torch_losses.py)."""
     from igs_amd.refine import GaussianParams, Refiner, render
     from igs_amd.scenes import perturbed_copy
     raw, cams, bg = cfg1_scene(P=3000, size=128)
@@ -1220,7 +1226,8 @@ def test_fused_step_with_depth_normal_regulariser(dev):
         pa, pb = GaussianParams(raw, dev), GaussianParams(raw, dev)
         ra = Refiner(pa, cams, gts, bg, loss=loss, lambda_depth_normal=0.05, fused=True)
         rb = Refiner(pb, cams, gts, bg, loss=loss, lambda_depth_normal=0.05, native=False)
-        rb.torch_ssim = True
+        from oracle import torch_losses as _tl
+        rb.ssim_fn, rb.depth_normal_fn = _tl.ssim_mean, _tl.depth_normal_loss          # independent PyTorch restatements
         ra.adam_fn = lambda: None          # gradients only (the fused launches end in the flat gradient)
         rb.adam_fn = lambda: None
         pka = ra.step(view=0); rb.step(view=0)
@@ -1230,8 +1237,8 @@ def test_fused_step_with_depth_normal_regulariser(dev):
             assert np.quantile(r, 0.99) < 5e-3 and np.median(r) < 1e-4, (loss, k, np.quantile(r, 0.99), np.median(r))
         # loss value: colour term + 0.05 * regulariser
         with torch.no_grad():
-            from igs_amd.refine import ssim
-            from igs_amd.regularizers import depth_normal_loss
+            from oracle.torch_losses import ssim_mean as ssim
+            from oracle.torch_losses import depth_normal_loss
             pk = render(pb.activated(), cams[0], bg)
             col = torch.abs(pk["images_pred"] - gts[0]).mean()
             if loss == "l1_ssim":
@@ -1648,7 +1655,8 @@ def test_full_size_stream_step_fused_equals_autograd(dev, cfg):
     pa, pb = GaussianParams(raw, dev), GaussianParams(raw, dev)
     ra = Refiner(pa, cams, gts, bg, loss="l1_ssim", lambda_depth_normal=ldn, fused=True)
     rb = Refiner(pb, cams, gts, bg, loss="l1_ssim", lambda_depth_normal=ldn, native=False)
-    rb.torch_ssim = True
+    from oracle import torch_losses as _tl
+    rb.ssim_fn, rb.depth_normal_fn = _tl.ssim_mean, _tl.depth_normal_loss              # independent PyTorch restatements
     ra.clamp = rb.clamp = cfg == "cfg5"
     ra.adam_fn = lambda: None          # gradients only
     rb.adam_fn = lambda: None
@@ -1660,8 +1668,8 @@ def test_full_size_stream_step_fused_equals_autograd(dev, cfg):
         r = rel(A, B)
         assert np.quantile(r, 0.99) < 5e-3 and np.median(r) < 1e-4, (cfg, k, np.quantile(r, 0.99), np.median(r))
     with torch.no_grad():
-        from igs_amd.refine import ssim
-        from igs_amd.regularizers import depth_normal_loss
+        from oracle.torch_losses import ssim_mean as ssim
+        from oracle.torch_losses import depth_normal_loss
         pk = render(pb.activated(), cams[1], bg)
         ref_loss = 0.8 * torch.abs(pk["images_pred"] - gts[1]).mean() + 0.2 * (1.0 - ssim(pk["images_pred"], gts[1]))
         if ldn:

@@ -333,7 +333,7 @@ def test_depth_to_normal_on_an_analytic_plane():
     import math
     import torch
     from igs_amd.camera import Camera
-    from igs_amd.regularizers import depth_double_to_normal, depths_double_to_points
+    from oracle.torch_losses import depth_pair_to_normals as depth_double_to_normal, backproject
     H, W = 24, 32
     cam = Camera(torch.eye(4), 2 * math.atan(W / (2 * 40.0)), 2 * math.atan(H / (2 * 40.0)), (H, W))
     # plane n . p = d in camera space, seen along the pixel rays: depth z = d / (n . ray)
@@ -341,7 +341,7 @@ def test_depth_to_normal_on_an_analytic_plane():
     ys, xs = torch.meshgrid(torch.arange(H) + 0.5, torch.arange(W) + 0.5, indexing="ij")
     rays = torch.stack([(xs - W / 2) / 40.0, (ys - H / 2) / 40.0, torch.ones_like(xs)], dim=0)
     z = d / (rays * n.view(3, 1, 1)).sum(0)
-    p1, p2 = depths_double_to_points(cam, z[None], 2 * z[None])
+    p1, p2 = backproject(cam, z[None]), backproject(cam, 2 * z[None])
     torch.testing.assert_close(p1, rays * z, rtol=1e-5, atol=1e-6)
     torch.testing.assert_close(p2, 2 * p1)
     nm = depth_double_to_normal(cam, z[None], 2 * z[None])

@@ -75,16 +75,17 @@ def test_densify_rotation_and_logit_helpers_match_reference(golden_torch_only):
 
 
 def test_loss_restatements_match_reference_loss_utils(golden_torch_only):
-    """The PyTorch restatements the GPU loss kernels are compared with elsewhere (igs_amd.losses._ssim_torch / l1_loss,
-    igs_amd.refine.ssim / psnr) against values and autograd gradients produced by the reference's own loss_utils.py /
+    """The PyTorch restatements the GPU loss kernels are compared with elsewhere (oracle/torch_losses.py: l1_mean,
+    ssim_reference_call / ssim_mean, psnr) against values and autograd gradients produced by the reference's own loss_utils.py /
     image_utils.py -- so the chain  HIP kernel == restatement == reference  is closed by data, not by reading."""
-    from igs_amd import losses, refine
+    from oracle import torch_losses as tl
+    from igs_amd import refine
     g = golden_torch_only
     for tag in ("a", "b"):
         img, gt = torch.from_numpy(g["loss_%s_img" % tag]), torch.from_numpy(g["loss_%s_gt" % tag])
         x = img.clone().requires_grad_(True)
-        l1 = losses.l1_loss(x, gt)
-        s_call = losses.ssim(x, gt.unsqueeze(0), size_average=False)          # CPU tensors -> the PyTorch restatement
+        l1 = tl.l1_mean(x, gt)
+        s_call = tl.ssim_reference_call(x, gt.unsqueeze(0), size_average=False)
         np.testing.assert_allclose(l1.item(), g["loss_%s_l1" % tag], rtol=1e-6)
         np.testing.assert_allclose(s_call.detach().numpy(), g["loss_%s_ssim_call" % tag], rtol=1e-5)
         loss = 0.8 * l1 + 0.2 * (1.0 - s_call)
@@ -92,8 +93,9 @@ def test_loss_restatements_match_reference_loss_utils(golden_torch_only):
         np.testing.assert_allclose(loss.detach().numpy(), g["loss_%s_total" % tag], rtol=1e-5)
         G = g["loss_%s_grad" % tag]
         np.testing.assert_allclose(x.grad.numpy(), G, rtol=0, atol=2e-5 * float(np.abs(G).max()))
-        m, ssim_map = losses.ssim(img, gt, size_average=True)
+        m, ssim_map = tl.ssim_reference_call(img, gt, size_average=True)
         np.testing.assert_allclose(m.item(), g["loss_%s_ssim" % tag], rtol=1e-5)
-        np.testing.assert_allclose(refine.ssim(img, gt).item(), g["loss_%s_ssim" % tag], rtol=1e-5)
+        np.testing.assert_allclose(tl.ssim_mean(img, gt).item(), g["loss_%s_ssim" % tag], rtol=1e-5)
         # infer_batch.py:350-353's PSNR == image_utils.psnr when the image is already inside [0, 1]
         np.testing.assert_allclose(refine.psnr(img, gt).item(), g["psnr_%s" % tag].item(), rtol=1e-5)
+        np.testing.assert_allclose(tl.psnr(img, gt).item(), g["psnr_%s" % tag].item(), rtol=1e-5)

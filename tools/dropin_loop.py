@@ -1,0 +1,106 @@
+"""The UNCHANGED caller: one refine iteration exactly as `infer_batch.py:279-324` drives the rasterizer package -- used by bench.py's
+`dropin` leg, tools/trace_dropin.sh and the GPU tests; caller-side code, not part of the product package.
+
+What is kept from the reference's loop, statement for statement in behaviour (not in text):
+  * the model's parameters are five `nn.Parameter`s (xyz, shs, opacity logit, log-scale, rotation) in a `torch.optim.Adam(l, lr=0.0,
+    eps=1e-15)` with one group each (`gaussian_model.py:303-348`), activations are separate PyTorch ops in the property getters
+    (`:90-127`: sigmoid / exp / F.normalize);
+  * `forward_single_view` (`infer_batch.py:39-124`): a fresh zeros+0 `screenspace_points` with `retain_grad()`, a fresh
+    `GaussianRasterizationSettings` / `GaussianRasterizer` per call, keyword arguments, the eight outputs;
+  * the per-iteration PSNR of the rendered image (`:300`), `l1_loss`, `ssim(render, gt.unsqueeze(0), size_average=False)`,
+    `loss.backward()`, `optimizer.step()`, `optimizer.zero_grad(set_to_none=True)` (`:301-324`).
+Not reproduced: building the Camera from a c2w matrix per iteration (`Camera.from_c2w`, `:296` -- caller-side matrix algebra on the
+host, nothing the package under test sees) and moving the image to the GPU (`:290-291`); cameras and images are resident.
+
+`optimizer`: "torch" = torch.optim.Adam as the reference constructs it; "fused" = igs_amd.optim.Adam, the one-line replacement
+that runs all groups in one HIP launch (same update rule).
+`losses`: "igs" = `from igs_amd.losses import l1_loss, ssim` (the one-line import change of INTEGRATION.md); "torch" = plain
+PyTorch l1 (abs/mean) and -- SSIM only on request, 7 ms -- the reference's conv2d SSIM restated in the test tree.
+"""
+import math
+
+import torch
+import torch.nn as nn
+
+
+class CallerModel:
+    """Refine-time parameter container in the shape of `GaussianModel.load_fromstream` (gaussian_model.py:265-348)."""
+
+    def __init__(self, raw, device, lrs, optimizer="torch"):
+        mk = lambda t: nn.Parameter(t.detach().clone().to(device).contiguous().requires_grad_(True))
+        self._xyz, self._shs = mk(raw["xyz"]), mk(raw["shs"])
+        self._opacity, self._scaling, self._rotation = mk(raw["opacity"]), mk(raw["scaling"]), mk(raw["rotation"])
+        l = [{"params": [self._xyz], "lr": lrs["xyz"], "name": "xyz"},
+             {"params": [self._rotation], "lr": lrs["rotation"], "name": "rotation"},
+             {"params": [self._shs], "lr": lrs["shs"], "name": "shs"},
+             {"params": [self._opacity], "lr": lrs["opacity"], "name": "opacity"},
+             {"params": [self._scaling], "lr": lrs["scaling"], "name": "scaling"}]
+        if optimizer == "torch":
+            self.optimizer = torch.optim.Adam(l, lr=0.0, eps=1e-15)
+        elif optimizer == "torch_fused":
+            self.optimizer = torch.optim.Adam(l, lr=0.0, eps=1e-15, fused=True)
+        else:
+            from igs_amd.optim import Adam
+            self.optimizer = Adam(l, lr=0.0, eps=1e-15)
+
+    get_xyz = property(lambda self: self._xyz)
+    get_features = property(lambda self: self._shs)
+    get_opacity = property(lambda self: torch.sigmoid(self._opacity))
+    get_scaling = property(lambda self: torch.exp(self._scaling))
+    get_rotation = property(lambda self: torch.nn.functional.normalize(self._rotation))
+
+    def raw(self):
+        return dict(xyz=self._xyz.detach(), shs=self._shs.detach(), opacity=self._opacity.detach(), scaling=self._scaling.detach(),
+                    rotation=self._rotation.detach())
+
+
+def forward_single_view(gs, cam, bg, sh_degree=3, package=None):
+    """`infer_batch.py:39-124` against `package` (default: diff_gaussian_rasterization_rade)."""
+    if package is None:
+        import diff_gaussian_rasterization_rade as package
+    tanfovx = math.tan(cam.FoVx * 0.5)
+    tanfovy = math.tan(cam.FoVy * 0.5)
+    screenspace_points = torch.zeros_like(gs.get_xyz, dtype=gs.get_xyz.dtype, requires_grad=True, device="cuda") + 0
+    try:
+        screenspace_points.retain_grad()
+    except Exception:  # noqa: BLE001
+        pass
+    raster_settings = package.GaussianRasterizationSettings(
+        image_height=int(cam.height), image_width=int(cam.width), tanfovx=tanfovx, tanfovy=tanfovy, bg=bg, scale_modifier=1.0,
+        viewmatrix=cam.world_view_transform, projmatrix=cam.full_proj_transform.float(), sh_degree=sh_degree,
+        campos=cam.camera_center, prefiltered=False, debug=False, kernel_size=0.0, require_coord=True, require_depth=True)
+    rasterizer = package.GaussianRasterizer(raster_settings=raster_settings)
+    means2D = screenspace_points.contiguous().float()
+    image, radii, coord, mcoord, depth, mdepth, alpha, normal = rasterizer(
+        means3D=gs.get_xyz, means2D=means2D, shs=gs.get_features, colors_precomp=None, opacities=gs.get_opacity,
+        scales=gs.get_scaling, rotations=gs.get_rotation, cov3D_precomp=None)
+    return {"images_pred": image, "bg_color": bg, "depth_pred": depth, "radii": radii, "visibility_filter": radii > 0,
+            "viewspace_points": screenspace_points, "mdepth": mdepth, "normal": normal, "alpha": alpha, "coord": coord, "mcoord": mcoord}
+
+
+def make_losses(kind):
+    if kind == "igs":
+        from igs_amd.losses import l1_loss, ssim
+        return l1_loss, ssim
+    l1 = lambda a, b: torch.abs((a - b)).mean()
+    from tests.reference_restatements import ssim_torch
+    return l1, (lambda a, b, size_average=False: ssim_torch(a, b, 11, size_average))
+
+
+def refine_iteration(gs, cam, gt_image, bg, loss="l1_ssim", lambda_l1=0.8, losses=None, package=None, psnr_line=True):
+    """One pass of the loop body `infer_batch.py:296-324` (densification off).  Returns the render package and the loss tensor."""
+    l1_loss, ssim = losses
+    pkg = forward_single_view(gs, cam, bg, sh_degree=3, package=package)
+    render_image = pkg["images_pred"]
+    if psnr_line:
+        pkg["psnr"] = -10 * torch.log10(torch.mean((render_image.detach() - gt_image) ** 2))
+    Ll1 = l1_loss(render_image, gt_image)
+    if loss == "l1":
+        total = Ll1                                  # BASELINE configs[2]: L1 only
+    else:
+        total = lambda_l1 * Ll1 + (1 - lambda_l1) * (1.0 - ssim(render_image, gt_image.unsqueeze(0), size_average=False))
+    total.backward()
+    with torch.no_grad():
+        gs.optimizer.step()
+        gs.optimizer.zero_grad(set_to_none=True)
+    return pkg, total

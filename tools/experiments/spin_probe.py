@@ -1,5 +1,5 @@
 """How long does a fresh process need before the SAME 20 refine steps (steps 6-25 from the same start) run at their steady speed?
-python tools/experiments/spin_test.py     (one GPU; prints the wall clock since the first GPU work and the per-step time of every repeat)"""
+python tools/experiments/spin_probe.py     (one GPU; prints the wall clock since the first GPU work and the per-step time of every repeat)"""
 import sys, os, time, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from igs_amd.refine import GaussianParams, Refiner, render
