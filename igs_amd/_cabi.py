@@ -40,8 +40,8 @@ class RefineStepArgs(C.Structure):
 
 EXPORTS = ["igs_rast_version", "igs_rast_last_error", "igs_rast_forward", "igs_rast_backward_workspace_bytes",
            "igs_rast_forward_async", "igs_rast_forward_finish", "igs_rast_forward_nowait", "igs_rast_last_status", "igs_rast_hint_scratch_clean", "igs_rast_set_slab_hint", "igs_rast_get_slab_hint", "igs_rast_backward", "igs_rast_mark_visible", "igs_rast_debug_dump",
-           "igs_rast_profile_enable", "igs_rast_profile_read", "igs_adam_step", "igs_adam_step_groups", "igs_adam_step_multi", "igs_densify_stats", "igs_densify_remap", "igs_refine_step", "igs_refine_loss_scratch_bytes", "igs_ssim_l1_scratch_bytes", "igs_ssim_l1_loss_fwd_bwd", "igs_ssim_l1_loss_fwd_bwd_cached", "igs_ssim_gt_stats_bytes", "igs_depth_normal_loss_fwd_bwd", "igs_l1_loss_fwd_bwd", "igs_activate_fwd", "igs_activate_bwd",
-           "igs_sh_grad_from_view_colors", "igs_adam_sh_from_view_colors", "igs_rast_last_backward_instance", "igs_refine_step_args_size", "igs_rast_debug_poison_lds", "igs_adam_exchange_step", "igs_morton_order", "igs_morton_order_scratch_bytes", "igs_debug_tile_sort"]
+           "igs_rast_profile_enable", "igs_rast_profile_read", "igs_adam_step", "igs_adam_step_groups", "igs_adam_step_multi", "igs_densify_stats", "igs_densify_remap", "igs_refine_step", "igs_refine_loss_scratch_bytes", "igs_ssim_l1_scratch_bytes", "igs_ssim_l1_loss_fwd_bwd", "igs_ssim_l1_loss_fwd_bwd_cached", "igs_ssim_gt_stats_bytes", "igs_depth_normal_loss_fwd_bwd", "igs_l1_loss_fwd_bwd", "igs_l1_mean_fwd_bwd", "igs_activate_fwd", "igs_activate_bwd",
+           "igs_sh_grad_from_view_colors", "igs_adam_sh_from_view_colors", "igs_rast_last_backward_instance", "igs_rast_next_backward_options", "igs_rast_nan_report_wait", "igs_refine_step_args_size", "igs_rast_debug_poison_lds", "igs_adam_exchange_step", "igs_morton_order", "igs_morton_order_scratch_bytes", "igs_debug_tile_sort"]
 
 VERSION = 4       # IGS_RAST_VERSION this binding was written against (include/igs_rast.h)
 
@@ -79,6 +79,10 @@ def lib():
                            % (L.igs_refine_step_args_size(), C.sizeof(RefineStepArgs)))
     L.igs_rast_last_backward_instance.restype = _i
     L.igs_rast_last_backward_instance.argtypes = []
+    L.igs_rast_next_backward_options.restype = None
+    L.igs_rast_next_backward_options.argtypes = [_i, _f]
+    L.igs_rast_nan_report_wait.restype = _i
+    L.igs_rast_nan_report_wait.argtypes = []
     L.igs_rast_debug_poison_lds.restype = _i
     L.igs_rast_debug_poison_lds.argtypes = [_vp]
     L.igs_rast_last_error.restype = C.c_char_p
@@ -145,6 +149,8 @@ def lib():
         L.igs_depth_normal_loss_fwd_bwd.argtypes = [_vp, _i, _i, _f, _f, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp]
         L.igs_l1_loss_fwd_bwd.restype = _i
         L.igs_l1_loss_fwd_bwd.argtypes = [_vp, C.c_size_t, _vp, _vp, _vp, _vp, _f]
+        L.igs_l1_mean_fwd_bwd.restype = _i
+        L.igs_l1_mean_fwd_bwd.argtypes = [_vp, C.c_size_t, _vp, _vp, _vp, _vp, _vp, _vp]
         L.igs_activate_fwd.restype = _i
         L.igs_activate_fwd.argtypes = [_vp, _i] + [_vp] * 6
         L.igs_activate_bwd.restype = _i
@@ -157,6 +163,30 @@ def lib():
         L.igs_adam_exchange_step.argtypes = [_vp, _i, _i, _i, _i, _vp, _vp, _f, _vp, _vp, _vp, _vp] + [C.c_size_t] * 5 + [_f] * 10
     _LIB = L
     return L
+
+
+_EXT = None
+
+
+def ext():
+    """The compiled `_C` module (igs_amd/_C.*.so, igs_amd/csrc_torch/igs_torch_ext.cpp), built in-tree on first use.  No fallback:
+    raises if it cannot be built or does not match the C-ABI library."""
+    global _EXT
+    if _EXT is not None:
+        return _EXT
+    lib()                                   # libigs_rast.so first (build / stamp / version checks; torch's HIP runtime mapped before ours)
+    from . import build_ext as _bx
+    try:
+        _bx.build()
+    except Exception as e:  # noqa: BLE001
+        if not (os.path.exists(_bx.TARGET) and not _bx.needs_build()):
+            raise RuntimeError("igs_amd: the compiled _C module is missing or stale and could not be built: %s" % e)
+    import importlib
+    m = importlib.import_module("igs_amd._C")
+    if m.abi_version() != VERSION:
+        raise RuntimeError("igs_amd: the compiled _C module was built against C-ABI version %d, this binding needs %d" % (m.abi_version(), VERSION))
+    _EXT = m
+    return m
 
 
 def last_backward_instance():

@@ -564,6 +564,40 @@ extern "C" unsigned igs_rast_get_slab_hint(void) { return g_hint.slab; }
 // autograd backward functions on its own worker thread): bit 0 coord, 1 depth, 2 normal, 3 abs-gradient moment; -1 = none
 // (R == 0 / no backward yet).  Tests use it to prove that absent upstream gradients select the cheaper instance.
 static int g_last_bwd_instance = -1;
+
+// NaN report of the per-Gaussian backward kernel (replaces the reference's seven `assert not torch.isnan(g).any()` host syncs,
+// DGR/diff_gaussian_rasterization_rade/__init__.py:156-162, by one word the kernel posts into pinned host memory)
+// (64 pinned bytes per host thread and device, never freed: the thread that runs autograd backward functions may outlive the HIP runtime)
+struct NanSlot { uint32_t* pinned = nullptr; uint32_t* pinned_dev = nullptr; uint32_t seq = 0; bool requested = false; bool pending = false; hipStream_t stream = nullptr; };
+static thread_local float g_next_clamp = 0.f;     // one-shot: clamp of the NEXT igs_rast_backward of this thread (clamp package)
+static thread_local NanSlot g_nan[IGS_MAX_DEVICES];
+static thread_local int g_nan_dev = -1;          // device of the last backward that was asked for a report
+extern "C" void igs_rast_next_backward_options(int nan_report, float clamp_grads)
+{
+    g_next_clamp = clamp_grads > 0.f ? clamp_grads : 0.f;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= IGS_MAX_DEVICES) return;
+    g_nan[dev].requested = nan_report != 0;
+}
+extern "C" int igs_rast_nan_report_wait(void)
+{
+    if (g_nan_dev < 0 || !g_nan[g_nan_dev].pending) return fail(IGS_RAST_E_INVALID, "igs_rast_nan_report_wait: no backward with a NaN report pending on this thread");
+    NanSlot& n = g_nan[g_nan_dev];
+    n.pending = false;
+    volatile uint32_t* seq = (volatile uint32_t*)&n.pinned[1];
+    double t0 = 0.0;
+    for (long spins = 0;; spins++) {
+        if (__atomic_load_n(seq, __ATOMIC_ACQUIRE) == n.seq) return n.pinned[0] ? 1 : 0;
+        if ((spins & 0x3FFF) == 0x3FFF) {
+            const hipError_t q = hipStreamQuery(n.stream);
+            if (q != hipSuccess && q != hipErrorNotReady) return fail(IGS_RAST_E_HIP, "stream error while waiting for the NaN report", q);
+            if (q == hipSuccess && __atomic_load_n(seq, __ATOMIC_ACQUIRE) != n.seq) return fail(IGS_RAST_E_HIP, "the NaN report was never posted");
+            const double t = now_s();
+            if (t0 == 0.0) t0 = t;
+            else if (t - t0 > wait_limit_s()) return fail(IGS_RAST_E_HIP, "timed out waiting for the NaN report (IGS_RAST_WAIT_TIMEOUT_S)");
+        }
+    }
+}
 extern "C" int igs_rast_last_backward_instance(void) { return __atomic_load_n(&g_last_bwd_instance, __ATOMIC_RELAXED); }
 
 // l1_gt != NULL: L1 loss fused into the blend backward (dL_dpix ignored); fuse != NULL: activation backward + Adam fused into
@@ -606,13 +640,30 @@ static int backward_impl(
     float* gacc = (float*)align_ptr((const char*)workspace);
     const float fy = height / (2.0f * tan_fovy), fx = width / (2.0f * tan_fovx);
 
+    // NaN report asked for this backward (one-shot, consumed here even if the call fails later)
+    NanSlot* nan = nullptr;
+    const float clamp_next = g_next_clamp; g_next_clamp = 0.f;
+    if (!fuse) {
+        int dev = 0;
+        if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < IGS_MAX_DEVICES && g_nan[dev].requested) {
+            g_nan[dev].requested = false;
+            NanSlot& n = g_nan[dev];
+            if (!n.pinned) {
+                HIP_TRY(hipHostMalloc((void**)&n.pinned, 64, hipHostMallocDefault), "hipHostMalloc");
+                HIP_TRY(hipHostGetDevicePointer((void**)&n.pinned_dev, n.pinned, 0), "hipHostGetDevicePointer");
+                n.pinned[0] = 0; n.pinned[1] = 0;
+            }
+            nan = &n; g_nan_dev = dev;
+        }
+    }
     prof_mark(s, ST_GAP);
     float* loss_shards = (float*)((char*)gacc + ws_gacc_bytes(P));
+    uint32_t* nan_words = (uint32_t*)((char*)loss_shards + WS_LOSS_BYTES);      // {flag, workgroups done}: inside the workspace's spare tail
     // which blend instance will run (launch_blend_bwd decides the same way): the colour-only one packs its moments into 64-byte rows
     const bool will_compact = !(require_coord && (dL_dpix_coord || dL_dpix_mcoord)) && !(require_depth && (dL_dpix_depth || dL_dpix_mdepth))
                               && !((require_coord || require_depth) && dL_dpixel_normals);
     if (!(fuse && fuse->prezeroed)) {              // (igs_refine_step: the forward's preprocess kernel zero-filled the accumulators)
-        HIP_TRY(zero_fill_async(s, gacc, (size_t)P * (will_compact ? GACC_COMPACT_F : GACC_F) * 4), "zero gacc");
+        HIP_TRY(zero_fill_async(s, gacc, (size_t)P * (will_compact ? GACC_COMPACT_F : GACC_F) * 4, nan ? nan_words : nullptr, nan ? 2 : 0), "zero gacc");
         if (l1_gt) HIP_TRY(zero_fill_async(s, loss_shards, WS_LOSS_BYTES), "zero loss shards");
     }
     prof_mark(s, ST_MEMSET);
@@ -663,6 +714,12 @@ static int backward_impl(
         }
         HIP_TRY(launch_geom_bwd_adam(s, ga, f), "geom_bwd_adam launch");
     } else {
+        ga.clamp = clamp_next;
+        if (nan) {
+            nan->seq = nan->seq + 1 ? nan->seq + 1 : 1;
+            ga.nan_dev = nan_words; ga.nan_host = nan->pinned_dev; ga.nan_seq = nan->seq;
+            nan->stream = s; nan->pending = true;
+        }
         HIP_TRY(launch_geom_bwd(s, ga), "geom_bwd launch");
     }
     DBG_SYNC("geom_bwd");

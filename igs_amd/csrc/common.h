@@ -188,6 +188,10 @@ struct GeomBwdArgs {
     const float* rec; const float* gacc;
     int gacc_compact;                       // gacc rows hold {colour 3, Q0, Qx, Qy, Qxx, Qxy, Qyy, Z} in slots 0..9 (colour-only blend instance)
     float *dL_dmean2D, *dL_dcolor, *dL_dopacity, *dL_dmean3D, *dL_dcov3D, *dL_dsh, *dL_dscale, *dL_drot;
+    // NaN report (igs_rast_request_nan_report): nan_dev = {flag, workgroups done} in device memory, both zero at launch and left zero;
+    // the last workgroup posts {flag, nan_seq} into nan_host (pinned host memory).  NULL = no report.
+    uint32_t* nan_dev = nullptr; uint32_t* nan_host = nullptr; uint32_t nan_seq = 0;
+    float clamp = 0.f;          // > 0 (unfused kernel): dL/d(means3D, sh, opacity, scale, rotation) clamped to +-clamp as they are written (clamp package)
 };
 hipError_t launch_geom_bwd(hipStream_t s, const GeomBwdArgs& a);
 
@@ -415,5 +419,6 @@ __device__ __forceinline__ void st_param(float4* p, const float4& x)
 // Zero-fill of a 4-byte-aligned span by a kernel of this library (refine_ops.hip) instead of hipMemsetAsync: the same cost on the
 // stream (the runtime's memset is a fill kernel too), and a plain kernel node when the stream is being captured into a hipGraph --
 // captured memset nodes misbehaved on this runtime (round 2: stale counters in the replay, a crash at hipStreamEndCapture).
-hipError_t zero_fill_async(hipStream_t s, void* p, size_t bytes);
+// `extra` / `extra_words`: a second range of at most 256 words zeroed by the same launch.
+hipError_t zero_fill_async(hipStream_t s, void* p, size_t bytes, void* extra = nullptr, int extra_words = 0);
 

@@ -281,6 +281,7 @@ geom_bwd_kernel(const GBArgs args)
     float4 o_rot = make_float4(0, 0, 0, 0);
     float* dsh = a.M ? dsh_lds + threadIdx.x * FS : nullptr;
     bool sh_written = false;
+    bool found_nan = false;          // (!FUSED, a.nan_dev: any NaN among the gradients the reference asserts on, __init__.py:156-162)
     __shared__ float small_lds[FUSED ? NT * 12 : 1];      // xyz 3 | rotation 4 | opacity 1 | scale 3 gradients of every thread
 
     if (active && a.radii[idx] > 0) {
@@ -585,6 +586,15 @@ geom_bwd_kernel(const GBArgs args)
             a.dL_dmean2D[3 * idx] = o_m2d.x; a.dL_dmean2D[3 * idx + 1] = o_m2d.y; a.dL_dmean2D[3 * idx + 2] = o_m2d.z;
         }
         if constexpr (!FUSED) {
+            if (a.clamp > 0.f) {        // diff_gaussian_rasterization_rade_clamp/__init__.py:156-162 (means2D, colours, cov3D are not clamped)
+                const float c = a.clamp;
+                auto cl = [c](float x) { return x < -c ? -c : (x > c ? c : x); };      // (a NaN stays a NaN, as through torch.clamp)
+                o_mean = make_float3(cl(o_mean.x), cl(o_mean.y), cl(o_mean.z));
+                o_opacity = cl(o_opacity);
+                o_scale = make_float3(cl(o_scale.x), cl(o_scale.y), cl(o_scale.z));
+                o_rot = make_float4(cl(o_rot.x), cl(o_rot.y), cl(o_rot.z), cl(o_rot.w));
+                if (dsh && sh_written) for (int k = 0; k < F; k++) dsh[k] = cl(dsh[k]);
+            }
             a.dL_dcolor[3 * idx] = o_color.x; a.dL_dcolor[3 * idx + 1] = o_color.y; a.dL_dcolor[3 * idx + 2] = o_color.z;
             a.dL_dopacity[idx] = o_opacity;
             a.dL_dmean3D[3 * idx] = o_mean.x; a.dL_dmean3D[3 * idx + 1] = o_mean.y; a.dL_dmean3D[3 * idx + 2] = o_mean.z;
@@ -592,10 +602,17 @@ geom_bwd_kernel(const GBArgs args)
             for (int k = 0; k < 6; k++) a.dL_dcov3D[6 * (size_t)idx + k] = o_cov[k];
             a.dL_dscale[3 * idx] = o_scale.x; a.dL_dscale[3 * idx + 1] = o_scale.y; a.dL_dscale[3 * idx + 2] = o_scale.z;
             a.dL_drot[4 * idx] = o_rot.x; a.dL_drot[4 * idx + 1] = o_rot.y; a.dL_drot[4 * idx + 2] = o_rot.z; a.dL_drot[4 * idx + 3] = o_rot.w;
+            if (a.nan_dev) {
+                // x != x for every element of means2D, colors, opacity, means3D, scales, rotations (not cov3D: the reference does not look at it)
+                const float chk[17] = { o_m2d.x, o_m2d.y, o_m2d.z, o_color.x, o_color.y, o_color.z, o_opacity, o_mean.x, o_mean.y, o_mean.z,
+                                        o_scale.x, o_scale.y, o_scale.z, o_rot.x, o_rot.y, o_rot.z, o_rot.w };
+#pragma unroll
+                for (int k = 0; k < 17; k++) found_nan |= chk[k] != chk[k];
+            }
         } else {
             if (fz.clamp > 0.f) {       // diff_gaussian_rasterization_rade_clamp/__init__.py:156-162 (means2D is not clamped)
                 const float c = fz.clamp;
-                auto cl = [c](float x) { return fminf(fmaxf(x, -c), c); };
+                auto cl = [c](float x) { return x < -c ? -c : (x > c ? c : x); };      // (a NaN stays a NaN, as through torch.clamp)
                 o_mean = make_float3(cl(o_mean.x), cl(o_mean.y), cl(o_mean.z));
                 o_opacity = cl(o_opacity);
                 o_scale = make_float3(cl(o_scale.x), cl(o_scale.y), cl(o_scale.z));
@@ -779,6 +796,7 @@ geom_bwd_kernel(const GBArgs args)
                     ((float4*)dst)[i] = P4; ((float4*)dst_m)[i] = M4; ((float4*)dst_v)[i] = V4;
                 } else {
                     ((float4*)dst)[i] = make_float4(sp[0], sp[1], sp[2], sp[3]);
+                    if (a.nan_dev) found_nan |= (sp[0] != sp[0]) | (sp[1] != sp[1]) | (sp[2] != sp[2]) | (sp[3] != sp[3]);
                 }
                 g += dg; k += dk;
                 if (k >= F) { k -= F; g++; }
@@ -796,6 +814,7 @@ geom_bwd_kernel(const GBArgs args)
                     dst[i] = p; dst_m[i] = m; dst_v[i] = v;
                 } else {
                     dst[i] = dsh_lds[g * FS + k];
+                    if (a.nan_dev) found_nan |= dst[i] != dst[i];
                 }
                 g += dg; k += dk;
                 if (k >= F) { k -= F; g++; }
@@ -805,7 +824,27 @@ geom_bwd_kernel(const GBArgs args)
         }      // !fast_done
     }
     GTL(5);
+    if constexpr (!FUSED) {
+        if (a.nan_dev && found_nan) atomicOr(a.nan_dev, 1u);
+    }
     if (grp + (int)gridDim.x < ngroups) __syncthreads();          // the LDS rows are reused by the next group
+    }
+    if constexpr (!FUSED) {
+        if (a.nan_dev) {
+            // the workgroup that finishes last posts the verdict to the host and leaves the two device words zero for the next call
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                __threadfence();
+                if (atomicAdd(a.nan_dev + 1, 1u) == gridDim.x - 1) {
+                    __threadfence();
+                    const uint32_t verdict = atomicExch(a.nan_dev, 0u);
+                    a.nan_dev[1] = 0u;
+                    __atomic_store_n(a.nan_host, verdict, __ATOMIC_RELAXED);
+                    __threadfence_system();
+                    __atomic_store_n(a.nan_host + 1, a.nan_seq, __ATOMIC_RELEASE);
+                }
+            }
+        }
     }
 }
 

@@ -155,6 +155,69 @@ extern "C" int igs_adam_step_multi(void* stream, int ntensors, float* const* par
     return hipGetLastError() == hipSuccess ? 0 : IGS_RAST_E_HIP;
 }
 
+// mean |pred - gt| and its gradient in ONE launch, the value finished on the device: every workgroup leaves its partial sum in
+// partials[blockIdx.x]; the workgroup that finishes last (self-resetting counter) adds the partials IN INDEX ORDER -- the value does not
+// depend on which workgroup that was -- and stores the mean.  For `igs_amd.losses.l1_loss` (loss_utils.py:17-18) as an autograd Function:
+// PyTorch's sub / abs / mean and their three backward kernels become this launch plus one scale.
+__global__ void __launch_bounds__(256)
+l1_mean_kernel(size_t n4, size_t n, const float* __restrict__ pred, const float* __restrict__ gt, float* __restrict__ grad,
+               float* __restrict__ mean_out, float* __restrict__ partials, unsigned* __restrict__ counter, float inv_n)
+{
+    __shared__ float ws[4];
+    __shared__ bool last;
+    const size_t stride = (size_t)gridDim.x * 256;
+    float acc = 0.f;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+        const float4 a = ((const float4*)pred)[i], b = ((const float4*)gt)[i];
+        float4 g;
+        float d;
+        d = a.x - b.x; acc += fabsf(d); g.x = d > 0.f ? inv_n : (d < 0.f ? -inv_n : 0.f);
+        d = a.y - b.y; acc += fabsf(d); g.y = d > 0.f ? inv_n : (d < 0.f ? -inv_n : 0.f);
+        d = a.z - b.z; acc += fabsf(d); g.z = d > 0.f ? inv_n : (d < 0.f ? -inv_n : 0.f);
+        d = a.w - b.w; acc += fabsf(d); g.w = d > 0.f ? inv_n : (d < 0.f ? -inv_n : 0.f);
+        ((float4*)grad)[i] = g;
+    }
+    for (size_t i = n4 * 4 + (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+        const float d = pred[i] - gt[i];
+        acc += fabsf(d);
+        grad[i] = d > 0.f ? inv_n : (d < 0.f ? -inv_n : 0.f);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+    if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        partials[blockIdx.x] = ws[0] + ws[1] + ws[2] + ws[3];
+        __threadfence();
+        last = atomicAdd(counter, 1u) == gridDim.x - 1;
+    }
+    __syncthreads();
+    if (!last) return;
+    __threadfence();
+    float t = 0.f;
+    for (unsigned i = threadIdx.x; i < gridDim.x; i += 256) t += __builtin_nontemporal_load(partials + i);      // (fixed order per lane)
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) t += __shfl_down(t, off, 64);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = t;
+    __syncthreads();
+    if (threadIdx.x == 0) { mean_out[0] = (ws[0] + ws[1] + ws[2] + ws[3]) * inv_n; *counter = 0u; }
+}
+extern "C" int igs_l1_mean_fwd_bwd(void* stream, size_t n, const float* pred, const float* gt, float* grad, float* mean_out, float* partials,
+                                   unsigned* counter)
+{
+    if (n == 0) return IGS_RAST_E_INVALID;
+    if (!pred || !gt || !grad || !mean_out || !partials || !counter) return IGS_RAST_E_INVALID;
+    const bool aligned = (((uintptr_t)pred | (uintptr_t)gt | (uintptr_t)grad) & 15) == 0;
+    const size_t n4 = aligned ? n / 4 : 0;
+    size_t blocks = (n / 4 + 255) / 256;
+    if (blocks > 1024) blocks = 1024;
+    if (blocks == 0) blocks = 1;
+    hipLaunchKernelGGL(l1_mean_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, n4, n, pred, gt, grad, mean_out, partials, counter,
+                       (float)(1.0 / (double)n));
+    return hipGetLastError() == hipSuccess ? 0 : IGS_RAST_E_HIP;
+}
+
 // L1: loss_sum += sum |pred - gt| ; grad = sign(pred - gt) * scale        (mean => scale = upstream / n)
 __global__ void __launch_bounds__(256)
 l1_kernel(size_t n4, size_t n, const float* __restrict__ pred, const float* __restrict__ gt, float* __restrict__ grad, float* __restrict__ loss_sum, float scale)
@@ -326,8 +389,9 @@ extern "C" int igs_densify_remap(void* stream, int P_new, int M, const int* src,
     return hipGetLastError() == hipSuccess ? 0 : IGS_RAST_E_HIP;
 }
 
-__global__ void __launch_bounds__(256) zero_fill_kernel(uint32_t* __restrict__ p, size_t words)
+__global__ void __launch_bounds__(256) zero_fill_kernel(uint32_t* __restrict__ p, size_t words, uint32_t* __restrict__ extra, int extra_words)
 {
+    if (blockIdx.x == 0 && (int)threadIdx.x < extra_words) extra[threadIdx.x] = 0u;      // (a second, tiny range: at most 256 words)
     // 16-byte stores over the aligned middle, single words at the ragged ends
     const size_t head = min(words, (size_t)((16u - ((uintptr_t)p & 15u)) & 15u) / 4);
     const size_t n4 = (words - head) / 4;
@@ -340,15 +404,16 @@ __global__ void __launch_bounds__(256) zero_fill_kernel(uint32_t* __restrict__ p
         if (tail0 + threadIdx.x < words) p[tail0 + threadIdx.x] = 0u;
     }
 }
-hipError_t zero_fill_async(hipStream_t s, void* p, size_t bytes)
+hipError_t zero_fill_async(hipStream_t s, void* p, size_t bytes, void* extra, int extra_words)
 {
-    if (bytes == 0) return hipSuccess;
-    if ((((uintptr_t)p) | bytes) & 3u) return hipMemsetAsync(p, 0, bytes, s);      // (not word-granular: never the case in this library)
+    if (bytes == 0 && extra_words == 0) return hipSuccess;
+    if (extra_words < 0 || extra_words > 256) return hipErrorInvalidValue;
+    if (extra_words == 0 && ((((uintptr_t)p) | bytes) & 3u)) return hipMemsetAsync(p, 0, bytes, s);      // (not word-granular: never the case in this library)
     const size_t words = bytes / 4;
     size_t blocks = (words / 4 + 255) / 256;
     if (blocks < 1) blocks = 1;
     if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(zero_fill_kernel, dim3((unsigned)blocks), dim3(256), 0, s, (uint32_t*)p, words);
+    hipLaunchKernelGGL(zero_fill_kernel, dim3((unsigned)blocks), dim3(256), 0, s, (uint32_t*)p, words, (uint32_t*)extra, extra_words);
     return hipGetLastError();
 }
 

@@ -12,8 +12,46 @@ import torch
 from . import _cabi
 
 
+class _L1Mean(torch.autograd.Function):
+    """mean |a - b| and d/da in ONE launch (igs_l1_mean_fwd_bwd: the value is finished on the device by the workgroup that ends last);
+    backward is one scale of the stored sign / n map.  PyTorch's own sub / abs / mean take three launches forward and three backward."""
+    _scratch = {}          # (device, stream) -> [1024 partial sums | counter word], zero-filled once
+
+    @staticmethod
+    def forward(ctx, a, b):
+        L = _cabi.lib()
+        dev = a.device
+        x, y = a.contiguous().float(), b.contiguous().float()
+        with torch.cuda.device(dev):
+            stream = torch.cuda.current_stream(dev).cuda_stream
+            sc = _L1Mean._scratch.get((dev, stream))
+            if sc is None:
+                sc = _L1Mean._scratch[(dev, stream)] = torch.zeros(1025, dtype=torch.float32, device=dev)
+            grad = torch.empty_like(x)
+            out = torch.empty((), dtype=torch.float32, device=dev)
+            rc = L.igs_l1_mean_fwd_bwd(stream, x.numel(), x.data_ptr(), y.data_ptr(), grad.data_ptr(), out.data_ptr(), sc.data_ptr(),
+                                       sc.data_ptr() + 4096)
+        if rc != 0:
+            raise RuntimeError("igs_l1_mean_fwd_bwd failed: %d" % rc)
+        ctx.save_for_backward(grad)
+        ctx.needs = (ctx.needs_input_grad[0], ctx.needs_input_grad[1])
+        ctx.shapes = (a.shape, b.shape)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (grad,) = ctx.saved_tensors
+        ga = (g * grad).reshape(ctx.shapes[0]) if ctx.needs[0] else None
+        gb = (-(g * grad)).reshape(ctx.shapes[1]) if ctx.needs[1] else None
+        return ga, gb
+
+
 def l1_loss(network_output, gt):
-    """loss_utils.py:17-18."""
+    """loss_utils.py:17-18 (`torch.abs(network_output - gt).mean()`).  Two float32 GPU tensors of the same shape go through the fused
+    kernel; anything else is PyTorch's own three ops on the caller's tensors (no arithmetic of this package involved)."""
+    if (network_output.is_cuda and gt.is_cuda and network_output.shape == gt.shape and network_output.dtype == torch.float32
+            and gt.dtype == torch.float32 and network_output.numel() > 0 and not torch.cuda.is_current_stream_capturing()):
+        return _L1Mean.apply(network_output, gt)
     return torch.abs((network_output - gt)).mean()
 
 

@@ -11,7 +11,6 @@ more than the whole render + backward).  A caller replaces one constructor:
 State layout and names are torch.optim.Adam's (`state[p] = {"step", "exp_avg", "exp_avg_sq"}`), so `state_dict()` / the densification
 code that edits `optimizer.state` (gaussian_model.py:466-557) keep working.  There is no CPU path: parameters must be float32 GPU tensors.
 """
-import ctypes as C
 import math
 
 import torch
@@ -31,7 +30,7 @@ class Adam(torch.optim.Optimizer):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
-        L = _cabi.lib()
+        Cx = _cabi.ext()
         # batches of up to 8 tensors that share (device, betas, eps): one launch each
         batches = {}
         for group in self.param_groups:
@@ -54,15 +53,8 @@ class Adam(torch.optim.Optimizer):
                 batches.setdefault((p.device, b1, b2, group["eps"]), []).append(
                     (p, g, st["exp_avg"], st["exp_avg_sq"], group["lr"], 1.0 - b1 ** t, math.sqrt(1.0 - b2 ** t)))
         for (dev, b1, b2, eps), items in batches.items():
-            stream = torch.cuda.current_stream(dev).cuda_stream
-            with torch.cuda.device(dev):
-                for i in range(0, len(items), 8):
-                    chunk = items[i:i + 8]
-                    n = len(chunk)
-                    ptr = lambda j: (C.c_void_p * n)(*[c[j].data_ptr() for c in chunk])
-                    rc = L.igs_adam_step_multi(stream, n, ptr(0), ptr(1), ptr(2), ptr(3), (C.c_size_t * n)(*[c[0].numel() for c in chunk]),
-                                               (C.c_float * n)(*[c[4] for c in chunk]), (C.c_float * n)(*[c[5] for c in chunk]),
-                                               (C.c_float * n)(*[c[6] for c in chunk]), b1, b2, eps)
-                    if rc != 0:
-                        raise RuntimeError("igs_adam_step_multi failed: %d" % rc)
+            for i in range(0, len(items), 8):
+                chunk = items[i:i + 8]
+                col = lambda j: [c[j] for c in chunk]
+                Cx.adam_step_multi(col(0), col(1), col(2), col(3), col(4), col(5), col(6), b1, b2, eps)
         return loss

@@ -1,18 +1,18 @@
-"""Host-side mirror of the reference's rasterizer binding, on top of the C ABI (include/igs_rast.h).
+"""Host-side mirror of the reference's rasterizer binding.
 
 Layers (reference file:line in parentheses; DGR = submodules/RaDe-GS/submodules/diff-gaussian-rasterization):
-  * `_C`-level functions `rasterize_gaussians`, `rasterize_gaussians_backward`, `mark_visible`,
-    `integrate_gaussians_to_points` with the positional signatures of DGR/rasterize_points.h:18-107
-    (what DGR/ext.cpp:15-20 exports);
-  * `_RasterizeGaussians`, `GaussianRasterizationSettings`, `GaussianRasterizer`, `rasterize_gaussians_autograd`
-    = DGR/diff_gaussian_rasterization_rade/__init__.py:21-243, same field order, argument validation messages,
-    saved tensors and 8-tuple output order `(color, radii, coord, mcoord, depth, mdepth, alpha, normal)`.
+  * `_C` = igs_amd/_C.*.so, the COMPILED module (igs_amd/csrc_torch/igs_torch_ext.cpp) with the four functions DGR/ext.cpp:15-20 exports
+    -- `rasterize_gaussians`, `rasterize_gaussians_backward`, `mark_visible`, `integrate_gaussians_to_points` (raises) -- and the
+    positional signatures of DGR/rasterize_points.h:18-107: torch glue over the C ABI of include/igs_rast.h (libigs_rast.so);
+  * this module: `_RasterizeGaussians`, `GaussianRasterizationSettings`, `GaussianRasterizer`, `rasterize_gaussians_autograd`
+    = DGR/diff_gaussian_rasterization_rade/__init__.py:21-243, same field order, argument validation messages, saved tensors and
+    8-tuple output order `(color, radii, coord, mcoord, depth, mdepth, alpha, normal)`; plus thin wrappers of the `_C` functions
+    with the extensions the refine loop uses (reusable buffers, deferred instance count, preallocated gradient destinations).
 
 torch is used for device memory and the current stream only; all arithmetic runs in libigs_rast.so.
-There is no CPU path: calling these functions without the HIP library / a GPU raises.
+There is no CPU path: calling these functions without the HIP library / the compiled module / a GPU raises.
 """
 import ctypes as C
-import os
 from typing import NamedTuple
 
 import torch
@@ -20,49 +20,15 @@ import torch.nn as nn
 
 from . import _cabi
 
-
-class RasterizerError(RuntimeError):
-    pass
-
-
-def _ptr(t):
-    """Device pointer or NULL for the reference's "empty tensor" convention (data_ptr()==nullptr)."""
-    if t is None or t.numel() == 0:
-        return None
-    return t.data_ptr()
+_C = _cabi.ext()                       # builds (first use in a fresh tree) and imports igs_amd/_C.*.so; raises if that is impossible
+RasterizerError = _C.RasterizerError   # RuntimeError subclass raised by the compiled module
+ScratchSet = _C.ScratchSet
 
 
-def _prep(t, device, what):
-    if t is None or t.numel() == 0:
-        return None
-    if t.dtype is torch.float32 and t.device == device and t.is_contiguous():      # (the common case, kept cheap)
-        return t
-    if t.device != device:
-        raise RasterizerError("%s must live on %s (got %s)" % (what, device, t.device))
-    if t.dtype != torch.float32:
-        t = t.float()
-    return t.contiguous()
-
-
-class _Scratch:
-    """uint8 tensor grown on demand by the library (rasterize_points.cu:27-33, resizeFunctional)."""
-
-    def __init__(self, device, persistent=False):
-        self.device = device
-        self.persistent = persistent
-        self.tensor = torch.empty(0, dtype=torch.uint8, device=device)
-        self.cb = _cabi.ALLOC_FN(self._alloc)
-
-    def _alloc(self, _user, nbytes):
-        try:
-            if self.tensor.numel() < int(nbytes):          # persistent scratch only grows (by 25 % to avoid churn)
-                # persistent scratch is born zero-filled: the library leaves its binning counters zeroed after every frame, which
-                # lets igs_refine_step (scratch_clean) skip its per-frame zero-fill launch
-                self.tensor = (torch.zeros if self.persistent else torch.empty)(int(nbytes * (1.25 if self.persistent else 1.0)),
-                                                                                dtype=torch.uint8, device=self.device)
-            return self.tensor.data_ptr()
-        except Exception:  # noqa: BLE001  (an exception must not cross the C frame)
-            return None
+def _check(rc, what):
+    if rc < 0:
+        raise RasterizerError("%s failed (%d): %s" % (what, rc, _cabi.last_error()))
+    return rc
 
 
 class RasterBuffers:
@@ -78,8 +44,8 @@ class RasterBuffers:
             self.key = key
             self.imgs = torch.zeros((15, H, W), dtype=torch.float32, device=dev)
             self.radii = torch.zeros((P,), dtype=torch.int32, device=dev)
-            self.scratch = (_Scratch(dev, True), _Scratch(dev, True), _Scratch(dev, True))
-            self.workspace = torch.empty(_cabi.lib().igs_rast_backward_workspace_bytes(P), dtype=torch.uint8, device=dev)
+            self.scratch = ScratchSet(dev, True)          # persistent: born zero-filled, used by this library only
+            self.workspace = self.scratch.workspace(P)
         return self.imgs, self.radii, self.scratch
 
 
@@ -99,9 +65,7 @@ class _ScratchPool:
         lst = self.free.get(key)
         if lst:
             return lst.pop()
-        dev = key[3]
-        ws = torch.empty(_cabi.lib().igs_rast_backward_workspace_bytes(key[0]), dtype=torch.uint8, device=dev)
-        return (_Scratch(dev, True), _Scratch(dev, True), _Scratch(dev, True), ws)
+        return ScratchSet(key[3], True)
 
     def release(self, key, item):
         lst = self.free.setdefault(key, [])
@@ -124,15 +88,10 @@ class _Lease:
     share it and a pool eviction would let the allocator recycle it under later replays."""
     __slots__ = ("key", "item", "pooled")
 
-    def __init__(self, key):
+    def __init__(self, key, capturing):
         self.key = key
-        self.pooled = not torch.cuda.is_current_stream_capturing()
-        if self.pooled:
-            self.item = _POOL.acquire(key)
-        else:
-            dev = key[3]
-            ws = torch.empty(_cabi.lib().igs_rast_backward_workspace_bytes(key[0]), dtype=torch.uint8, device=dev)
-            self.item = (_Scratch(dev, True), _Scratch(dev, True), _Scratch(dev, True), ws)
+        self.pooled = not capturing
+        self.item = _POOL.acquire(key) if self.pooled else ScratchSet(key[3], True)
 
     def __del__(self):
         try:
@@ -142,75 +101,36 @@ class _Lease:
             pass
 
 
-def _check(rc, what):
-    if rc < 0:
-        raise RasterizerError("%s failed (%d): %s" % (what, rc, _cabi.last_error()))
-    return rc
-
-
 def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp, viewmatrix,
                         projmatrix, tan_fovx, tan_fovy, kernel_size, image_height, image_width, sh, degree, campos,
                         prefiltered, require_coord, require_depth, debug, buffers=None, defer=False, scratch=None):
-    """`_C.rasterize_gaussians` (RasterizeGaussiansCUDA, DGR/rasterize_points.cu:35-133).
+    """`_C.rasterize_gaussians` (RasterizeGaussiansCUDA, DGR/rasterize_points.cu:35-133) with this library's extensions.
 
     Returns (num_rendered, color, coord, mcoord, alpha, normal, depth, mdepth, radii, geomBuffer, binningBuffer, imgBuffer).
-    `buffers` (extension) is a RasterBuffers object whose image / radii / scratch tensors are reused across calls;
-    `scratch` (extension) a (geometry, binning, image) triple of _Scratch objects to use instead of fresh byte tensors.
-    `defer=True` (extension) does not wait for the instance count: num_rendered is then an upper bound (accepted by
-    rasterize_gaussians_backward) and `rasterize_finish()` must be called before the results are trusted.
+    `buffers` is a RasterBuffers object whose image / radii / scratch tensors are reused across calls; `scratch` a ScratchSet to use
+    instead of fresh byte tensors.  `defer=True` does not wait for the instance count: num_rendered is then an upper bound (accepted
+    by rasterize_gaussians_backward) and `rasterize_finish()` must be called before the results are trusted.
     On a CAPTURING stream (torch.cuda.graph) the no-wait entry point igs_rast_forward_nowait is used by itself: the launches are
     recorded, num_rendered is the same upper bound, and `capture_status()` reports on a replay after the fact."""
-    if means3D.dim() != 2 or means3D.size(1) != 3:
-        raise RasterizerError("means3D must have dimensions (num_points, 3)")
-    if not means3D.is_cuda:
-        raise RasterizerError("igs_amd rasterizer: tensors must be on a GPU (no CPU fallback)")
-    L = _cabi.lib()
-    dev = means3D.device
-    P, H, W = means3D.size(0), int(image_height), int(image_width)
-    with torch.cuda.device(dev):
-        means3D_c = _prep(means3D, dev, "means3D")
-        colors_c, opacity_c, scales_c, rotations_c = (_prep(colors, dev, "colors_precomp"), _prep(opacity, dev, "opacities"),
-                                                      _prep(scales, dev, "scales"), _prep(rotations, dev, "rotations"))
-        cov_c, sh_c = _prep(cov3D_precomp, dev, "cov3D_precomp"), _prep(sh, dev, "shs")
-        bg_c, view_c, proj_c, campos_c = (_prep(background, dev, "bg"), _prep(viewmatrix, dev, "viewmatrix"),
-                                          _prep(projmatrix, dev, "projmatrix"), _prep(campos, dev, "campos"))
-        M = sh_c.size(1) if sh_c is not None else 0
-        # one allocation for the seven images; every pixel is written by the kernels when P > 0
-        if buffers is not None:
-            imgs, radii, (geom, binning, img) = buffers.get(P, H, W, dev)
-        else:
-            imgs = (torch.empty if P > 0 else torch.zeros)((15, H, W), dtype=torch.float32, device=dev)
-            radii = torch.empty((P,), dtype=torch.int32, device=dev) if P > 0 else torch.zeros((0,), dtype=torch.int32, device=dev)
-            geom, binning, img = scratch[:3] if scratch is not None else (_Scratch(dev), _Scratch(dev), _Scratch(dev))
-        color, coord, mcoord = imgs[0:3], imgs[3:6], imgs[6:9]
-        depth, mdepth, alpha, normal = imgs[9:10], imgs[10:11], imgs[11:12], imgs[12:15]
-        rendered = 0
-        if P != 0:
-            stream = torch.cuda.current_stream(dev).cuda_stream
-            fwd = L.igs_rast_forward_async if defer else L.igs_rast_forward
-            if torch.cuda.is_current_stream_capturing():
-                fwd = L.igs_rast_forward_nowait
-            if buffers is not None and os.environ.get("IGS_SCRATCH_CLEAN") != "0":
-                L.igs_rast_hint_scratch_clean(1)          # RasterBuffers scratch: zero-filled at allocation, used by this library only
-            rendered = fwd(
-                stream, geom.cb, None, binning.cb, None, img.cb, None, P, int(degree), M, _ptr(bg_c), W, H,
-                _ptr(means3D_c), _ptr(sh_c), _ptr(colors_c), _ptr(opacity_c), _ptr(scales_c), float(scale_modifier),
-                _ptr(rotations_c), _ptr(cov_c), _ptr(view_c), _ptr(proj_c), _ptr(campos_c), float(tan_fovx), float(tan_fovy),
-                float(kernel_size), int(bool(prefiltered)), _ptr(color), _ptr(coord), _ptr(mcoord), _ptr(depth), _ptr(mdepth),
-                _ptr(alpha), _ptr(normal), _ptr(radii), int(bool(require_coord)), int(bool(require_depth)), int(bool(debug)))
-            _check(rendered, "igs_rast_forward")
-    return (rendered, color, coord, mcoord, alpha, normal, depth, mdepth, radii, geom.tensor, binning.tensor, img.tensor)
+    mode = 2 if (means3D.is_cuda and torch.cuda.is_current_stream_capturing()) else (1 if defer else 0)
+    if buffers is not None:
+        if means3D.dim() != 2 or means3D.size(1) != 3:
+            raise RasterizerError("means3D must have dimensions (num_points, 3)")
+        imgs, radii, ss = buffers.get(means3D.size(0), int(image_height), int(image_width), means3D.device)
+        return _C.rasterize_gaussians(background, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp, viewmatrix,
+                                      projmatrix, tan_fovx, tan_fovy, kernel_size, image_height, image_width, sh, degree, campos,
+                                      prefiltered, require_coord, require_depth, debug, scratch=ss, out_images=imgs, out_radii=radii,
+                                      mode=mode, scratch_clean=True)
+    return _C.rasterize_gaussians(background, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp, viewmatrix,
+                                  projmatrix, tan_fovx, tan_fovy, kernel_size, image_height, image_width, sh, degree, campos,
+                                  prefiltered, require_coord, require_depth, debug, scratch=scratch, mode=mode)
 
 
 def rasterize_finish():
     """Completes a `rasterize_gaussians(..., defer=True)`: returns the true num_rendered, or None when the optimistic
     instance-list capacity was too small -- everything computed from that frame must then be discarded and the frame redone
     (igs_rast_forward_finish, include/igs_rast.h)."""
-    rc = _cabi.lib().igs_rast_forward_finish()
-    if rc == _cabi.E_RETRY:
-        return None
-    _check(rc, "igs_rast_forward_finish")
-    return rc
+    return _C.forward_finish()
 
 
 def capture_status():
@@ -225,63 +145,10 @@ def capture_status():
     return n.value, ov.value
 
 
-def _backward(background, means3D, radii, colors, scales, rotations, scale_modifier, cov3D_precomp,
-              viewmatrix, projmatrix, tan_fovx, tan_fovy, kernel_size, dL_dout_color, dL_dout_coord,
-              dL_dout_mcoord, dL_dout_depth, dL_dout_mdepth, dL_dout_alpha, dL_dout_normal, normalmap, sh,
-              degree, campos, geomBuffer, R, binningBuffer, imageBuffer, alphas, require_coord,
-              require_depth, debug, out=None, workspace=None):
-    """Body of `rasterize_gaussians_backward`; also returns the dense block that holds the seven small gradients
-    (m2d 3 | colors 3 | opacity 1 | means3D 3 | scales 3 | rot 4 | cov3D 6 floats per Gaussian) for the fused NaN check."""
-    L = _cabi.lib()
-    dev = means3D.device
-    P = means3D.size(0)
-    H, W = alphas.size(-2), alphas.size(-1)
-    with torch.cuda.device(dev):
-        sh_c = _prep(sh, dev, "shs")
-        M = sh_c.size(1) if sh_c is not None else 0
-        f32 = dict(dtype=torch.float32, device=dev)
-        alloc = torch.empty if P > 0 else torch.zeros
-        dL_dsh = alloc((P, M, 3), **f32)
-        block = alloc((23 * P,), **f32)
-        o = 0
-        def carve(k):
-            nonlocal o
-            t = block[o:o + k * P].view(P, k)
-            o += k * P
-            return t
-        dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D = carve(3), carve(3), carve(1), carve(3)
-        dL_dscales, dL_drotations, dL_dcov3D = carve(3), carve(4), carve(6)
-        if out:
-            dL_dmeans2D = out.get("means2D", dL_dmeans2D); dL_dcolors = out.get("colors", dL_dcolors)
-            dL_dopacity = out.get("opacity", dL_dopacity); dL_dmeans3D = out.get("means3D", dL_dmeans3D)
-            dL_dcov3D = out.get("cov3D", dL_dcov3D); dL_dsh = out.get("sh", dL_dsh)
-            dL_dscales = out.get("scales", dL_dscales); dL_drotations = out.get("rotations", dL_drotations)
-        if P != 0:
-            means3D_c = _prep(means3D, dev, "means3D")
-            colors_c, scales_c, rotations_c, cov_c = (_prep(colors, dev, "colors_precomp"), _prep(scales, dev, "scales"),
-                                                      _prep(rotations, dev, "rotations"), _prep(cov3D_precomp, dev, "cov3D_precomp"))
-            bg_c, view_c, proj_c, campos_c = (_prep(background, dev, "bg"), _prep(viewmatrix, dev, "viewmatrix"),
-                                              _prep(projmatrix, dev, "projmatrix"), _prep(campos, dev, "campos"))
-            grads = [None if g is None else _prep(g, dev, "grad") for g in (dL_dout_color, dL_dout_coord, dL_dout_mcoord,
-                                                                            dL_dout_depth, dL_dout_mdepth, dL_dout_alpha,
-                                                                            dL_dout_normal)]
-            alphas_c, normal_c = _prep(alphas, dev, "alphas"), _prep(normalmap, dev, "normalmap")
-            radii_c = radii.contiguous()
-            need = L.igs_rast_backward_workspace_bytes(P)
-            ws = workspace if (workspace is not None and workspace.numel() >= need) else torch.empty(need, dtype=torch.uint8, device=dev)
-            stream = torch.cuda.current_stream(dev).cuda_stream
-            rc = L.igs_rast_backward(
-                stream, P, int(degree), M, int(R), _ptr(bg_c), W, H, _ptr(means3D_c), _ptr(sh_c), _ptr(colors_c), _ptr(alphas_c),
-                _ptr(scales_c), float(scale_modifier), _ptr(rotations_c), _ptr(cov_c), _ptr(view_c), _ptr(proj_c), _ptr(campos_c),
-                float(tan_fovx), float(tan_fovy), float(kernel_size), _ptr(radii_c), _ptr(normal_c), _ptr(geomBuffer),
-                _ptr(binningBuffer), _ptr(imageBuffer), *[_ptr(g) for g in grads], _ptr(ws),
-                _ptr(dL_dmeans2D), _ptr(dL_dcolors), _ptr(dL_dopacity), _ptr(dL_dmeans3D), _ptr(dL_dcov3D), _ptr(dL_dsh),
-                _ptr(dL_dscales), _ptr(dL_drotations), int(bool(require_coord)), int(bool(require_depth)), int(bool(debug)))
-            _check(rc, "igs_rast_backward")
-    return (dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations), block
+_OUT_NAMES = ("means2D", "colors", "opacity", "means3D", "cov3D", "sh", "scales", "rotations")
 
 
-def rasterize_gaussians_backward(*args, **kw):
+def rasterize_gaussians_backward(*args, out=None, workspace=None):
     """`_C.rasterize_gaussians_backward` (RasterizeGaussiansBackwardCUDA, DGR/rasterize_points.cu:135-246), same 32 positional
     arguments (background, means3D, radii, colors, scales, rotations, scale_modifier, cov3D_precomp, viewmatrix, projmatrix,
     tan_fovx, tan_fovy, kernel_size, dL_dout_color, dL_dout_coord, dL_dout_mcoord, dL_dout_depth, dL_dout_mdepth, dL_dout_alpha,
@@ -292,32 +159,15 @@ def rasterize_gaussians_backward(*args, **kw):
     Extensions over the reference: any upstream gradient may be None (= zeros: the output was not used by the loss);
     `out=` may name preallocated contiguous destination tensors by those eight names (e.g. spans of a flat gradient
     buffer), `workspace=` a reusable uint8 scratch tensor."""
-    return _backward(*args, **kw)[0]
+    kw = {}
+    if out:
+        kw = {"out_" + k: v for k, v in out.items() if k in _OUT_NAMES}
+    return _C.rasterize_gaussians_backward(*args, workspace=workspace, **kw)
 
 
 last_backward_instance = _cabi.last_backward_instance
-
-
-def mark_visible(means3D, viewmatrix, projmatrix):
-    """`_C.mark_visible` (DGR/rasterize_points.cu:248-267)."""
-    L = _cabi.lib()
-    if not means3D.is_cuda:
-        raise RasterizerError("igs_amd rasterizer: tensors must be on a GPU (no CPU fallback)")
-    dev = means3D.device
-    P = means3D.size(0)
-    present = torch.zeros((P,), dtype=torch.bool, device=dev)
-    if P != 0:
-        with torch.cuda.device(dev):
-            m, v, p = _prep(means3D, dev, "means3D"), _prep(viewmatrix, dev, "viewmatrix"), _prep(projmatrix, dev, "projmatrix")
-            _check(L.igs_rast_mark_visible(torch.cuda.current_stream(dev).cuda_stream, P, _ptr(m), _ptr(v), _ptr(p),
-                                           present.data_ptr()), "igs_rast_mark_visible")
-    return present
-
-
-def integrate_gaussians_to_points(*_args, **_kw):
-    """`_C.integrate_gaussians_to_points` (GOF tetrahedra integration, DGR/rasterize_points.cu:269-387) is mesh-extraction
-    only and never reached from IGS (out of scope)."""
-    raise NotImplementedError("integrate_gaussians_to_points is outside the IGS hot path and is not implemented")
+mark_visible = _C.mark_visible
+integrate_gaussians_to_points = _C.integrate_gaussians_to_points
 
 
 def debug_dump(P, R, W, H, geomBuffer, binningBuffer, imgBuffer):
@@ -325,14 +175,15 @@ def debug_dump(P, R, W, H, geomBuffer, binningBuffer, imgBuffer):
     L = _cabi.lib()
     dev = geomBuffer.device
     T = ((W + 15) // 16) * ((H + 15) // 16)
+    ptr = lambda t: t.data_ptr() if t.numel() else None
     with torch.cuda.device(dev):
         rec = torch.zeros((P, 32), dtype=torch.float32, device=dev)
         tiles = torch.zeros((P,), dtype=torch.int32, device=dev)
         pl = torch.zeros((R,), dtype=torch.int32, device=dev)
         ranges = torch.zeros((T, 2), dtype=torch.int32, device=dev)
         nc = torch.zeros((2, H, W), dtype=torch.int32, device=dev)
-        _check(L.igs_rast_debug_dump(torch.cuda.current_stream(dev).cuda_stream, P, R, W, H, _ptr(geomBuffer), _ptr(binningBuffer),
-                                     _ptr(imgBuffer), rec.data_ptr(), tiles.data_ptr(), _ptr(pl), ranges.data_ptr(), nc.data_ptr()),
+        _check(L.igs_rast_debug_dump(torch.cuda.current_stream(dev).cuda_stream, P, R, W, H, ptr(geomBuffer), ptr(binningBuffer),
+                                     ptr(imgBuffer), rec.data_ptr(), tiles.data_ptr(), ptr(pl), ranges.data_ptr(), nc.data_ptr()),
                "igs_rast_debug_dump")
     return dict(rec=rec, tiles_touched=tiles, point_list=pl, ranges=ranges, n_contrib=nc)
 
@@ -345,35 +196,39 @@ def cpu_deep_copy_tuple(input_tuple):
 
 
 def _make_function(clamp_grads):
+    clamp_value = 15.0 if clamp_grads else 0.0      # DGRC/diff_gaussian_rasterization_rade_clamp/__init__.py:156-162
+
     class _RasterizeGaussians(torch.autograd.Function):
         @staticmethod
         def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings):
-            args = (raster_settings.bg, means3D, colors_precomp, opacities, scales, rotations, raster_settings.scale_modifier,
-                    cov3Ds_precomp, raster_settings.viewmatrix, raster_settings.projmatrix, raster_settings.tanfovx,
-                    raster_settings.tanfovy, raster_settings.kernel_size, raster_settings.image_height,
-                    raster_settings.image_width, sh, raster_settings.sh_degree, raster_settings.campos,
-                    raster_settings.prefiltered, raster_settings.require_coord, raster_settings.require_depth,
-                    raster_settings.debug)
+            rs = raster_settings
+            args = (rs.bg, means3D, colors_precomp, opacities, scales, rotations, rs.scale_modifier, cov3Ds_precomp, rs.viewmatrix,
+                    rs.projmatrix, rs.tanfovx, rs.tanfovy, rs.kernel_size, rs.image_height, rs.image_width, sh, rs.sh_degree,
+                    rs.campos, rs.prefiltered, rs.require_coord, rs.require_depth, rs.debug)
             # outputs that take no part in the loss arrive in backward as None (not as zero-filled tensors): the C ABI reads
             # NULL as zeros and then runs the cheapest blend-backward instance that covers the gradients actually present
             ctx.set_materialize_grads(False)
-            lease = None
+            lease, mode = None, 0
             if means3D.is_cuda and means3D.dim() == 2:
                 dev = means3D.device
-                lease = _Lease((means3D.size(0), int(raster_settings.image_height), int(raster_settings.image_width), dev,
-                                torch.cuda.current_stream(dev).cuda_stream))
-            if raster_settings.debug:
+                capturing = torch.cuda.is_current_stream_capturing()
+                mode = 2 if capturing else 0
+                lease = _Lease((means3D.size(0), int(rs.image_height), int(rs.image_width), dev,
+                                torch.cuda.current_stream(dev).cuda_stream), capturing)
+            ss = lease.item if lease else None
+            if rs.debug:
                 cpu_args = cpu_deep_copy_tuple(args)
                 try:
-                    out = rasterize_gaussians(*args, scratch=lease.item if lease else None)
+                    out = _C.rasterize_gaussians(*args, scratch=ss, mode=mode, scratch_clean=ss is not None)
                 except Exception as ex:
                     torch.save(cpu_args, "snapshot_fw.dump")
                     print("\nAn error occured in forward. Please forward snapshot_fw.dump for debugging.")
                     raise ex
             else:
-                out = rasterize_gaussians(*args, scratch=lease.item if lease else None)
+                # (pooled / capture-owned sets are born zero-filled and touched by this library only: no per-frame zero-fill launch)
+                out = _C.rasterize_gaussians(*args, scratch=ss, mode=mode, scratch_clean=ss is not None)
             num_rendered, color, coord, mcoord, alpha, normal, depth, mdepth, radii, geomBuffer, binningBuffer, imgBuffer = out
-            ctx.raster_settings = raster_settings
+            ctx.raster_settings = rs
             ctx.num_rendered = num_rendered
             ctx.lease = lease               # the scratch set goes back to the pool when this context dies
             ctx.save_for_backward(colors_precomp, means3D, scales, rotations, cov3Ds_precomp, normal, radii, sh, geomBuffer,
@@ -383,45 +238,35 @@ def _make_function(clamp_grads):
 
         @staticmethod
         def backward(ctx, grad_color, grad_radii, grad_coord, grad_mcoord, grad_depth, grad_mdepth, grad_alpha, grad_normal):
-            num_rendered = ctx.num_rendered
-            raster_settings = ctx.raster_settings
+            rs = ctx.raster_settings
             (colors_precomp, means3D, scales, rotations, cov3Ds_precomp, normal, radii, sh, geomBuffer, binningBuffer, imgBuffer,
              alpha) = ctx.saved_tensors
-            args = (raster_settings.bg, means3D, radii, colors_precomp, scales, rotations, raster_settings.scale_modifier,
-                    cov3Ds_precomp, raster_settings.viewmatrix, raster_settings.projmatrix, raster_settings.tanfovx,
-                    raster_settings.tanfovy, raster_settings.kernel_size, grad_color, grad_coord, grad_mcoord,
-                    grad_depth, grad_mdepth, grad_alpha, grad_normal, normal, sh,
-                    raster_settings.sh_degree, raster_settings.campos, geomBuffer, num_rendered, binningBuffer, imgBuffer, alpha,
-                    raster_settings.require_coord, raster_settings.require_depth, raster_settings.debug)
-            ws = ctx.lease.item[3] if getattr(ctx, "lease", None) is not None else None
-            if raster_settings.debug:
+            args = (rs.bg, means3D, radii, colors_precomp, scales, rotations, rs.scale_modifier, cov3Ds_precomp, rs.viewmatrix,
+                    rs.projmatrix, rs.tanfovx, rs.tanfovy, rs.kernel_size, grad_color, grad_coord, grad_mcoord, grad_depth,
+                    grad_mdepth, grad_alpha, grad_normal, normal, sh, rs.sh_degree, rs.campos, geomBuffer, ctx.num_rendered,
+                    binningBuffer, imgBuffer, alpha, rs.require_coord, rs.require_depth, rs.debug)
+            lease = getattr(ctx, "lease", None)
+            ws = lease.item.workspace(means3D.size(0)) if lease is not None else None
+            # The reference asserts on seven gradient tensors with seven `.any()` reductions and host syncs (__init__.py:156-162); here
+            # the per-Gaussian kernel tests what it writes and posts ONE word to the host (igs_rast_next_backward_options): no extra
+            # launch, one wait.  The clamp package's five torch.clamp calls are applied by that kernel as well.
+            nan_report = NAN_CHECKS and not (means3D.is_cuda and torch.cuda.is_current_stream_capturing())      # (a host-side assert cannot be captured)
+            if rs.debug:
                 cpu_args = cpu_deep_copy_tuple(args)
                 try:
-                    out, block = _backward(*args, workspace=ws)
+                    out, has_nan = _C.rasterize_gaussians_backward_ex(*args, workspace=ws, nan_report=nan_report, clamp=clamp_value)
                 except Exception as ex:
                     torch.save(cpu_args, "snapshot_bw.dump")
                     print("\nAn error occured in backward. Writing snapshot_bw.dump for debugging.\n")
                     raise ex
             else:
-                out, block = _backward(*args, workspace=ws)
+                out, has_nan = _C.rasterize_gaussians_backward_ex(*args, workspace=ws, nan_report=nan_report, clamp=clamp_value)
             grad_means2D, grad_colors_precomp, grad_opacities, grad_means3D, grad_cov3Ds_precomp, grad_sh, grad_scales, grad_rotations = out
-            if clamp_grads:     # DGRC/diff_gaussian_rasterization_rade_clamp/__init__.py:156-162
-                grad_means3D = torch.clamp(grad_means3D, -15, 15)
-                grad_sh = torch.clamp(grad_sh, -15, 15)
-                grad_opacities = torch.clamp(grad_opacities, -15, 15)
-                grad_scales = torch.clamp(grad_scales, -15, 15)
-                grad_rotations = torch.clamp(grad_rotations, -15, 15)
-            if NAN_CHECKS and not torch.cuda.is_current_stream_capturing():      # (a host-side assert cannot be captured)
-                # the reference asserts on seven tensors with seven `.any()` host syncs (__init__.py:156-162); six of them are
-                # one dense block here (its first 17 floats per Gaussian; the cov3D gradient behind them is not checked there
-                # either), so: two reductions, one host sync
-                P = means3D.size(0)
-                assert not bool(torch.isnan(block[:17 * P]).any() | torch.isnan(grad_sh).any())
+            assert not has_nan
             # shapes autograd expects: the gradient of an absent (empty CPU) input is None
-            def m(g, ref):
-                return g if (ref is not None and ref.numel() > 0) else None
-            return (grad_means3D, grad_means2D, m(grad_sh, sh), m(grad_colors_precomp, colors_precomp), grad_opacities,
-                    m(grad_scales, scales), m(grad_rotations, rotations), m(grad_cov3Ds_precomp, cov3Ds_precomp), None)
+            return (grad_means3D, grad_means2D, grad_sh if sh.numel() else None, grad_colors_precomp if colors_precomp.numel() else None,
+                    grad_opacities, grad_scales if scales.numel() else None, grad_rotations if rotations.numel() else None,
+                    grad_cov3Ds_precomp if cov3Ds_precomp.numel() else None, None)
 
     return _RasterizeGaussians
 

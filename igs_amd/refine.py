@@ -414,13 +414,18 @@ class Refiner:
         H, W = int(cam.height), int(cam.width)
         if not hasattr(self, "_bufs"):
             self._bufs = _rast.RasterBuffers()
-        imgs, radii, (geom, binning, img) = self._bufs.get(P, H, W, dev)
+        imgs, radii, ss = self._bufs.get(P, H, W, dev)
         if not hasattr(self, "_fused") or self._fused["m2d"].shape[0] != P:
             self._fused = dict(m2d=torch.zeros((P, 3), dtype=torch.float32, device=dev),
                                loss=torch.zeros(1, dtype=torch.float32, device=dev))
         a = _cabi.RefineStepArgs()
         a.stream = torch.cuda.current_stream(dev).cuda_stream
-        a.geometry_buffer, a.binning_buffer, a.image_buffer = geom.cb, binning.cb, img.cb
+        if getattr(self, "_cb_of", None) is not ss:          # (callback address + the set's three `user` words, valid while `ss` lives)
+            cb, ug, ub, ui = ss.callbacks()
+            self._cb_of, self._cb = ss, (_cabi.ALLOC_FN(cb), ug, ub, ui)
+        fn, ug, ub, ui = self._cb
+        a.geometry_buffer, a.binning_buffer, a.image_buffer = fn, fn, fn
+        a.geometry_user, a.binning_user, a.image_user = ug, ub, ui
         a.workspace = self._bufs.workspace.data_ptr()
         a.P, a.D, a.M, a.width, a.height = P, 3, 16, W, H
         a.background = self.bg.data_ptr()

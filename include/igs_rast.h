@@ -222,6 +222,18 @@ int igs_rast_debug_dump(void* stream, int P, int R, int width, int height,
 /* Which backward tile-blend instance the last igs_rast_backward / igs_refine_step of this process launched (any thread): bit 0 coord, bit 1
  * depth, bit 2 normal gradients present, bit 3 the |screen-space gradient| moment; -1 = none.  (The reference instantiates from
  * require_coord / require_depth alone, backward.cu:1153-1160; here branches whose upstream gradients are all NULL are left out.) */
+/* Options of the NEXT igs_rast_backward of this host thread (extension; one-shot, consumed by that call): the reference's argument
+ * list has no room for them and stays as it is.
+ *  nan_report != 0: the reference's Python backward ends with seven `assert not torch.isnan(grad).any()` -- seven reductions and host
+ *   syncs (DGR/diff_gaussian_rasterization_rade/__init__.py:156-162).  The per-Gaussian kernel instead tests every element it writes of
+ *   dL_dmean2D, dL_dcolor, dL_dopacity, dL_dmean3D, dL_dsh, dL_dscale, dL_drot (not dL_dcov3D: the reference does not look at it either)
+ *   and posts one word into pinned host memory; igs_rast_nan_report_wait() blocks until that word has arrived and returns 1 (a NaN was
+ *   written), 0 (none) or a negative error code.  Bounded like the forward's status wait (IGS_RAST_WAIT_TIMEOUT_S).
+ *  clamp_grads > 0: dL_dmean3D, dL_dsh, dL_dopacity, dL_dscale, dL_drot are clamped to +-clamp_grads as they are written (what the clamp
+ *   package does with five torch.clamp calls afterwards, DGRC/diff_gaussian_rasterization_rade_clamp/__init__.py:156-162); a NaN stays
+ *   a NaN for the report, as it does through torch.clamp. */
+void igs_rast_next_backward_options(int nan_report, float clamp_grads);
+int igs_rast_nan_report_wait(void);
 int igs_rast_last_backward_instance(void);
 /* Test hook: overwrites the LDS of every CU with NaN bit patterns (a kernel that reads LDS it never wrote then fails small parity
  * tests instead of passing on a fresh device's zeros). */
@@ -367,6 +379,11 @@ int igs_depth_normal_loss_fwd_bwd(void* stream, int width, int height, float tan
  * sum |pred - gt| is accumulated into 64 shards loss_sum[16*s], s = 0..63 (1024 floats, zeroed by the caller, summed by
  * the caller: same-address atomics would serialise). */
 int igs_l1_loss_fwd_bwd(void* stream, size_t n, const float* pred, const float* gt, float* grad, float* loss_sum, float scale);
+/* The same with the VALUE finished on the device, in one launch: mean_out[0] = mean |pred - gt|, grad[i] = sign(pred[i] - gt[i]) / n.
+ * partials: 1024 floats of scratch; counter: one word that is zero on entry and zero again on exit (a buffer the caller zero-fills once
+ * and keeps; calls that share it must be ordered on one stream). */
+int igs_l1_mean_fwd_bwd(void* stream, size_t n, const float* pred, const float* gt, float* grad, float* mean_out, float* partials,
+                        unsigned* counter);
 
 /* Morton (Z-order) permutation of the Gaussians' positions (extension, no reference counterpart; used by the refine loop's store so
  * that consecutive Gaussians project to neighbouring tiles -- the binning stage then reserves instance slots once per (workgroup,

@@ -1,0 +1,208 @@
+"""The UNCHANGED-caller path: the compiled `_C` module, the autograd binding on top of it, the kernel-side NaN report and clamp, the
+one-launch L1 loss, the multi-tensor Adam -- and the caller's loop (tools/dropin_loop.py = infer_batch.py:279-324) against the
+library's own fused step."""
+import numpy as np
+import pytest
+import torch
+
+from igs_amd.scenes import cfg1_scene, activate
+
+pytestmark = pytest.mark.gpu
+E = torch.Tensor([])
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    return torch.device("cuda:0")
+
+
+def _settings(mod, cam, bg, debug=False):
+    return mod.GaussianRasterizationSettings(image_height=cam.height, image_width=cam.width, tanfovx=cam.tanfovx, tanfovy=cam.tanfovy,
+                                             kernel_size=0.0, bg=bg, scale_modifier=1.0, viewmatrix=cam.world_view_transform,
+                                             projmatrix=cam.full_proj_transform, sh_degree=3, campos=cam.camera_center,
+                                             prefiltered=False, require_depth=True, require_coord=True, debug=debug)
+
+
+def test_compiled_module_is_what_the_packages_bind(dev):
+    """`diff_gaussian_rasterization_rade._C` carries the four names of DGR/ext.cpp:15-20 and they are the compiled module's functions
+    (a built-in, not a Python def); its 12-tuple / 8-tuple orders are rasterize_points.cu:133 / :246."""
+    import types
+    import diff_gaussian_rasterization_rade as D
+    import diff_gaussian_rasterization_rade_clamp as DC
+    from igs_amd import _cabi
+    m = _cabi.ext()
+    assert m.__file__.endswith(".so")
+    for name in ("rasterize_gaussians", "rasterize_gaussians_backward", "mark_visible", "integrate_gaussians_to_points"):
+        f = getattr(D._C, name)
+        assert f is getattr(m, name) and isinstance(f, types.BuiltinFunctionType), name
+    assert DC._C is D._C
+    raw, cams, bg = cfg1_scene(P=700, size=64)
+    cam = cams[0].to(dev)
+    a = {k: v.to(dev) for k, v in activate(raw).items()}
+    out = D._C.rasterize_gaussians(bg.to(dev), a["means3D"], E, a["opacities"], a["scales"], a["rotations"], 1.0, E, cam.world_view_transform,
+                                   cam.full_proj_transform, cam.tanfovx, cam.tanfovy, 0.0, cam.height, cam.width, a["shs"], 3,
+                                   cam.camera_center, False, True, True, False)
+    assert len(out) == 12 and isinstance(out[0], int) and out[0] > 0
+    nr, color, coord, mcoord, alpha, normal, depth, mdepth, radii, gb, bb, ib = out
+    assert tuple(color.shape) == (3, 64, 64) and tuple(alpha.shape) == (1, 64, 64) and radii.dtype == torch.int32 and gb.dtype == torch.uint8
+    g = torch.ones_like(color)
+    grads = D._C.rasterize_gaussians_backward(bg.to(dev), a["means3D"], radii, E, a["scales"], a["rotations"], 1.0, E, cam.world_view_transform,
+                                              cam.full_proj_transform, cam.tanfovx, cam.tanfovy, 0.0, g, None, None, None, None, None, None,
+                                              normal, a["shs"], 3, cam.camera_center, gb, nr, bb, ib, alpha, True, True, False)
+    assert len(grads) == 8 and tuple(grads[5].shape) == (700, 16, 3) and tuple(grads[4].shape) == (700, 6)
+    with pytest.raises(RuntimeError, match="means3D must have dimensions"):
+        D._C.rasterize_gaussians(bg.to(dev), a["means3D"].reshape(-1), E, a["opacities"], a["scales"], a["rotations"], 1.0, E,
+                                 cam.world_view_transform, cam.full_proj_transform, cam.tanfovx, cam.tanfovy, 0.0, cam.height, cam.width,
+                                 a["shs"], 3, cam.camera_center, False, True, True, False)
+    with pytest.raises(NotImplementedError):
+        D._C.integrate_gaussians_to_points()
+    assert D._C.mark_visible(a["means3D"], cam.world_view_transform, cam.full_proj_transform).dtype == torch.bool
+
+
+def test_nan_report_from_the_kernel_and_kernel_side_clamp(dev):
+    """The reference's seven NaN asserts (__init__.py:156-162) as ONE word posted by the per-Gaussian kernel: a NaN in an upstream
+    gradient reaches the Gaussians it covers and trips the assert; clean gradients do not; with the checks off nothing is asserted.
+    The clamp package's five torch.clamp calls as part of the same kernel: equal to clamping the plain package's gradients."""
+    import diff_gaussian_rasterization_rade as D
+    import diff_gaussian_rasterization_rade_clamp as DC
+    from igs_amd import rasterizer
+    raw, cams, bg = cfg1_scene(P=1500, size=96)
+    cam = cams[0].to(dev)
+    bgd = bg.to(dev)
+
+    def run(mod, upstream_scale=1.0, poison=False, use=("color",)):
+        leaf = {k: v.to(dev).clone().requires_grad_(True) for k, v in raw.items()}
+        a = activate(leaf)
+        ras = mod.GaussianRasterizer(raster_settings=_settings(mod, cam, bgd))
+        m2d = torch.zeros_like(a["means3D"], requires_grad=True)
+        res = ras(means3D=a["means3D"], means2D=m2d, opacities=a["opacities"], shs=a["shs"], scales=a["scales"], rotations=a["rotations"])
+        g = torch.full_like(res[0], upstream_scale)
+        if poison:
+            g[0, 44:52, 44:52] = float("nan")
+        outs, gs = [res[0]], [g]
+        if "depth" in use:
+            outs.append(res[4]); gs.append(torch.full_like(res[4], 0.3 * upstream_scale))
+        raster_in = (a["means3D"], m2d, a["shs"], a["opacities"], a["scales"], a["rotations"])
+        return torch.autograd.grad(outs, raster_in, gs)
+
+    prev = rasterizer.NAN_CHECKS
+    try:
+        rasterizer.NAN_CHECKS = True
+        run(D)                                             # clean: no assert
+        with pytest.raises(AssertionError):
+            run(D, poison=True)
+        with pytest.raises(AssertionError):
+            run(DC, poison=True)                           # a NaN survives the clamp, as through torch.clamp
+        rasterizer.NAN_CHECKS = False
+        gp = run(D, poison=True)                           # checks off: the NaN simply arrives
+        assert any(bool(torch.isnan(t).any()) for t in gp)
+        # clamp: the kernel-side clamp == torch.clamp of the plain gradients, for the five tensors the clamp package touches
+        for use in (("color",), ("color", "depth")):
+            plain = run(D, upstream_scale=400.0, use=use)
+            clamped = run(DC, upstream_scale=400.0, use=use)
+            assert float(plain[0].abs().max()) > 15.0
+            for i, name in ((0, "means3D"), (2, "sh"), (3, "opacities"), (4, "scales"), (5, "rotations")):
+                want = torch.clamp(plain[i], -15, 15)
+                # float atomics in the blend backward: the two runs differ by rounding, the clamp itself is exact
+                d = float((clamped[i] - want).abs().max())
+                assert d <= 2e-3 * max(1.0, float(want.abs().max())), (name, use, d)
+                assert float(clamped[i].abs().max()) <= 15.0
+            torch.testing.assert_close(clamped[1], plain[1], rtol=2e-3, atol=1e-3 * float(plain[1].abs().max()))      # means2D is NOT clamped
+    finally:
+        rasterizer.NAN_CHECKS = prev
+
+
+@pytest.mark.parametrize("n", [5, 4096, 3 * 211 * 157])
+def test_one_launch_l1_loss_matches_torch(dev, n):
+    """igs_amd.losses.l1_loss (loss_utils.py:17-18) as one launch forward + one scale backward: value and gradient against PyTorch's
+    sub / abs / mean; deterministic (partials are added in index order)."""
+    from igs_amd.losses import l1_loss
+    g = torch.Generator().manual_seed(n)
+    a = torch.rand(n, generator=g).to(dev)
+    b = torch.rand(n, generator=g).to(dev)
+    b[:: 7] = a[:: 7]                                       # exact zeros: sign(0) = 0
+    x = a.clone().requires_grad_(True)
+    y = a.clone().requires_grad_(True)
+    l1 = l1_loss(x, b)
+    l2 = torch.abs(y - b).mean()
+    assert l1.shape == l2.shape == ()
+    torch.testing.assert_close(l1, l2, rtol=2e-6, atol=1e-8)
+    (3.0 * l1).backward(); (3.0 * l2).backward()
+    torch.testing.assert_close(x.grad, y.grad, rtol=1e-6, atol=0)
+    assert float(l1_loss(a, b)) == float(l1_loss(a, b))
+    # shapes PyTorch would broadcast, or CPU tensors: PyTorch's own ops on the caller's tensors
+    assert abs(float(l1_loss(a.cpu(), b.cpu())) - float(l2)) < 1e-6
+
+
+def test_multi_tensor_adam_matches_torch_adam(dev):
+    """igs_amd.optim.Adam (ONE launch for the five groups of gaussian_model.py:303-348) against torch.optim.Adam(lr=0, eps=1e-15) with
+    per-group learning rates: identical parameters and state over several steps, including a parameter that joins late (its own step
+    count) and one without a gradient."""
+    from igs_amd.optim import Adam
+    gen = torch.Generator().manual_seed(3)
+    shapes = [(1000, 3), (1000, 4), (1000, 16, 3), (1000, 1), (1000, 3), (7,)]
+    lrs = [1.6e-3, 1e-2, 2.5e-3, 5e-2, 5e-3, 1e-3]
+    init = [torch.randn(s, generator=gen) for s in shapes]
+
+    def make(cls):
+        ps = [torch.nn.Parameter(t.clone().to(dev)) for t in init]
+        return ps, cls([{"params": [p], "lr": lr, "name": str(i)} for i, (p, lr) in enumerate(zip(ps, lrs))], lr=0.0, eps=1e-15)
+    pa, oa = make(Adam)
+    pb, ob = make(torch.optim.Adam)
+    for step in range(6):
+        for i, (x, y) in enumerate(zip(pa, pb)):
+            if i == 5 and step < 2:
+                continue                                    # joins at step 2: its bias corrections run two steps behind
+            if i == 3 and step == 4:
+                x.grad = None; y.grad = None                # no gradient this step: untouched, step count not advanced
+                continue
+            g = torch.randn(x.shape, generator=gen).to(dev) * (10.0 ** (step - 3))
+            x.grad = g.clone(); y.grad = g.clone()
+        oa.step(); ob.step()
+        oa.zero_grad(set_to_none=True); ob.zero_grad(set_to_none=True)
+    for i, (x, y) in enumerate(zip(pa, pb)):
+        torch.testing.assert_close(x.detach(), y.detach(), rtol=2e-6, atol=2e-7), i
+        sa, sb = oa.state[x], ob.state[y]
+        assert int(sa["step"]) == int(sb["step"])
+        torch.testing.assert_close(sa["exp_avg"], sb["exp_avg"], rtol=1e-6, atol=1e-12)
+        torch.testing.assert_close(sa["exp_avg_sq"], sb["exp_avg_sq"], rtol=1e-6, atol=1e-20)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        p = torch.nn.Parameter(torch.zeros(3)); p.grad = torch.ones(3)
+        Adam([p], lr=1e-3).step()
+
+
+@pytest.mark.parametrize("loss", ["l1", "l1_ssim"])
+def test_unchanged_caller_loop_equals_the_fused_step(dev, loss):
+    """tools/dropin_loop.py drives the packages exactly as infer_batch.py:279-324 does (nn.Parameters, PyTorch activations,
+    GaussianRasterizer, l1_loss / ssim, loss.backward(), optimizer.step(), zero_grad(set_to_none=True)) -- with torch.optim.Adam and
+    with igs_amd.optim.Adam -- and must land where the library's own single-call step (igs_refine_step) lands from the same start."""
+    from igs_amd.refine import GaussianParams, Refiner, render, DEFAULT_LRS
+    from igs_amd.scenes import perturbed_copy
+    from tools.dropin_loop import CallerModel, refine_iteration, make_losses
+    raw, cams, bg = cfg1_scene(P=3000, size=128)
+    cams = [cams[0].to(dev)]
+    bgd = bg.to(dev)
+    gt_raw = {k: v.to(dev) for k, v in perturbed_copy(raw, sigma=0.03).items()}
+    with torch.no_grad():
+        gts = [render(activate(gt_raw), cams[0], bgd)["images_pred"].clone()]
+    steps = 4
+    pf = GaussianParams(raw, dev)
+    rf = Refiner(pf, cams, gts, bgd, loss=loss)
+    for _ in range(steps):
+        rf.step(view=0)
+    want = {k: v.detach().clone() for k, v in pf.leaves.items()}
+    lf = make_losses("igs")
+    for optimizer in ("torch", "fused"):
+        gs = CallerModel(raw, dev, DEFAULT_LRS, optimizer=optimizer)
+        for _ in range(steps):
+            pkg, total = refine_iteration(gs, cams[0], gts[0], bgd, loss=loss, losses=lf)
+        assert torch.isfinite(total) and pkg["viewspace_points"].grad is not None and tuple(pkg["viewspace_points"].grad.shape) == (3000, 3)
+        got = gs.raw()
+        for k in want:
+            # |dp| per step <= lr: compare against the distance travelled (a sign flip of a ~zero gradient moves a parameter by 2 lr)
+            d = (got[k] - want[k]).abs()
+            lr = DEFAULT_LRS[k]
+            assert float(torch.quantile(d.flatten()[:100000], 0.98)) < 0.02 * lr * steps, (optimizer, k, float(torch.quantile(d.flatten()[:100000], 0.98)))
+            assert float(d.max()) <= 2.05 * lr * steps, (optimizer, k, float(d.max()))

@@ -1782,7 +1782,7 @@ def test_self_cleaning_binning_counters_survive_a_broken_promise(dev, poison):
             r = rel(pa.leaves[k].grad.cpu().numpy(), want[k].cpu().numpy())
             assert np.quantile(r, 0.999) < 2e-3 and np.median(r) < 1e-5, (poison, k, np.quantile(r, 0.999), np.median(r))
     check()
-    img_scratch = ra._bufs.scratch[2].tensor
+    img_scratch = ra._bufs.scratch.img
     torch.cuda.synchronize()
     if poison == "small_words":          # every 32-bit word = 3: cursors start at 3, the shards add 192 to R
         img_scratch.view(torch.int32)[:] = 3

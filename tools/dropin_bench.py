@@ -1,0 +1,50 @@
+"""Times the UNCHANGED caller loop (tools/dropin_loop.py = infer_batch.py:279-324) on the bench scene, per variant.
+usage: python tools/dropin_bench.py [steps] [variant ...]      variant = <loss>:<optimizer>:<nan 0|1>[:<losses igs|torch>]"""
+import json, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+from igs_amd import rasterizer
+from igs_amd.refine import render, DEFAULT_LRS
+from igs_amd.scenes import sear_steak_like_scene, perturbed_copy, activate
+from tools.dropin_loop import CallerModel, refine_iteration, make_losses
+
+
+def setup(dev, P=200000):
+    raw, cams, bg = sear_steak_like_scene(P=P)
+    cams = [c.to(dev) for c in cams]; bg = bg.to(dev)
+    gt_raw = {k: v.to(dev) for k, v in perturbed_copy(raw).items()}
+    with torch.no_grad():
+        gts = [render(activate(gt_raw), c, bg)["images_pred"].clone() for c in cams]
+    return raw, cams, bg, gts
+
+
+def run_variant(raw, cams, bg, gts, dev, loss, optimizer, nan, losses="igs", steps=100, warm=20):
+    rasterizer.NAN_CHECKS = bool(nan)
+    gs = CallerModel(raw, dev, DEFAULT_LRS, optimizer=optimizer)
+    lf = make_losses(losses)
+    for i in range(warm):
+        refine_iteration(gs, cams[i % len(cams)], gts[i % len(cams)], bg, loss=loss, losses=lf)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        refine_iteration(gs, cams[i % len(cams)], gts[i % len(cams)], bg, loss=loss, losses=lf)
+    torch.cuda.synchronize()
+    return 1000 * (time.perf_counter() - t0) / steps
+
+
+def main():
+    dev = torch.device("cuda:0")
+    steps = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+    variants = sys.argv[2:] or ["l1:fused:0", "l1:fused:1", "l1_ssim:fused:0", "l1:torch_fused:0", "l1:torch:0", "l1:fused:0:torch", "l1_ssim:fused:1"]
+    raw, cams, bg, gts = setup(dev)
+    out = {}
+    for v in variants:
+        f = v.split(":")
+        out[v] = round(run_variant(raw, cams, bg, gts, dev, f[0], f[1], int(f[2]), f[3] if len(f) > 3 else "igs", steps=steps), 4)
+        print(v, out[v], flush=True)
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

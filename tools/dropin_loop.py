@@ -15,7 +15,7 @@ host, nothing the package under test sees) and moving the image to the GPU (`:29
 `optimizer`: "torch" = torch.optim.Adam as the reference constructs it; "fused" = igs_amd.optim.Adam, the one-line replacement
 that runs all groups in one HIP launch (same update rule).
 `losses`: "igs" = `from igs_amd.losses import l1_loss, ssim` (the one-line import change of INTEGRATION.md); "torch" = plain
-PyTorch l1 (abs/mean) and -- SSIM only on request, 7 ms -- the reference's conv2d SSIM restated in the test tree.
+PyTorch l1 (abs / mean) and whatever SSIM function the caller passes in.
 """
 import math
 
@@ -78,13 +78,13 @@ def forward_single_view(gs, cam, bg, sh_degree=3, package=None):
             "viewspace_points": screenspace_points, "mdepth": mdepth, "normal": normal, "alpha": alpha, "coord": coord, "mcoord": mcoord}
 
 
-def make_losses(kind):
+def make_losses(kind, ssim_fn=None):
+    """(l1_loss, ssim) pair: "igs" = igs_amd.losses (the one-line import change); "torch" = PyTorch's own abs / mean for L1 and
+    `ssim_fn` (a restatement of loss_utils.py:34-63 the caller supplies -- tests pass the one in oracle/torch_losses.py) for SSIM."""
     if kind == "igs":
         from igs_amd.losses import l1_loss, ssim
         return l1_loss, ssim
-    l1 = lambda a, b: torch.abs((a - b)).mean()
-    from tests.reference_restatements import ssim_torch
-    return l1, (lambda a, b, size_average=False: ssim_torch(a, b, 11, size_average))
+    return (lambda a, b: torch.abs((a - b)).mean()), ssim_fn
 
 
 def refine_iteration(gs, cam, gt_image, bg, loss="l1_ssim", lambda_l1=0.8, losses=None, package=None, psnr_line=True):
