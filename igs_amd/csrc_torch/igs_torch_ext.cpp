@@ -10,8 +10,10 @@
 //   rasterize_gaussians_backward(..., workspace=None, out_*=None)         any upstream gradient may be None (= zeros)
 //   rasterize_gaussians_backward_ex(...same..., nan_report=False, clamp=0.0) -> (8 gradients, nan flag)
 #include <torch/extension.h>
-#include <ATen/hip/HIPContext.h>
-#include <c10/hip/HIPGuard.h>
+// PyTorch-ROCm presents its HIP devices under the device type "cuda" (so that `device="cuda"` callers run unchanged): guards and
+// the current stream come from the classes that know about that
+#include <ATen/hip/impl/HIPGuardImplMasqueradingAsCUDA.h>
+#include <ATen/hip/impl/HIPStreamMasqueradingAsCUDA.h>
 #include <limits.h>
 
 #include "../../include/igs_rast.h"
@@ -95,7 +97,7 @@ FwdTuple rasterize_gaussians(
     if (means3D.dim() != 2 || means3D.size(1) != 3) throw RasterizerError("means3D must have dimensions (num_points, 3)");
     if (!means3D.is_cuda()) throw RasterizerError("igs_amd rasterizer: tensors must be on a GPU (no CPU fallback)");
     const c10::Device dev = means3D.device();
-    const c10::hip::HIPGuard guard(dev);
+    const c10::hip::HIPGuardMasqueradingAsCUDA guard(dev);
     const int64_t P = means3D.size(0), H = image_height, W = image_width;
     In m3(means3D, dev, "means3D"), col(colors, dev, "colors_precomp"), op(opacity, dev, "opacities"), sc(scales, dev, "scales"),
        rot(rotations, dev, "rotations"), cov(cov3D_precomp, dev, "cov3D_precomp"), shs(sh, dev, "shs"), bg(background, dev, "bg"),
@@ -110,7 +112,7 @@ FwdTuple rasterize_gaussians(
            mdepth = imgs.narrow(0, 10, 1), alpha = imgs.narrow(0, 11, 1), normal = imgs.narrow(0, 12, 3);
     int64_t rendered = 0;
     if (P != 0) {
-        hipStream_t stream = at::hip::getCurrentHIPStream(dev.index()).stream();
+        hipStream_t stream = c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(dev.index()).stream();
         auto fwd = mode == 1 ? igs_rast_forward_async : (mode == 2 ? igs_rast_forward_nowait : igs_rast_forward);
         if (scratch_clean) igs_rast_hint_scratch_clean(1);
         float* ib = imgs.data_ptr<float>();
@@ -142,7 +144,7 @@ std::pair<BwdTuple, int64_t> backward_body(
 {
     if (!means3D.is_cuda()) throw RasterizerError("igs_amd rasterizer: tensors must be on a GPU (no CPU fallback)");
     const c10::Device dev = means3D.device();
-    const c10::hip::HIPGuard guard(dev);
+    const c10::hip::HIPGuardMasqueradingAsCUDA guard(dev);
     const int64_t P = means3D.size(0);
     const int64_t H = alphas.size(-2), W = alphas.size(-1);
     In shs(sh, dev, "shs");
@@ -170,7 +172,7 @@ std::pair<BwdTuple, int64_t> backward_body(
         const int64_t need = (int64_t)igs_rast_backward_workspace_bytes((int)P);
         Tensor ws = (workspace.has_value() && workspace->numel() >= need) ? *workspace
                                                                            : at::empty({need}, at::TensorOptions().dtype(at::kByte).device(dev));
-        hipStream_t stream = at::hip::getCurrentHIPStream(dev.index()).stream();
+        hipStream_t stream = c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(dev.index()).stream();
         if (nan_report || clamp > 0.0) igs_rast_next_backward_options(nan_report ? 1 : 0, (float)clamp);
         auto bp = [](const Tensor& t) { return t.numel() ? (const char*)t.data_ptr() : nullptr; };
         const int rc = igs_rast_backward(
@@ -195,12 +197,12 @@ Tensor mark_visible(const Tensor& means3D, const Tensor& viewmatrix, const Tenso
 {
     if (!means3D.is_cuda()) throw RasterizerError("igs_amd rasterizer: tensors must be on a GPU (no CPU fallback)");
     const c10::Device dev = means3D.device();
-    const c10::hip::HIPGuard guard(dev);
+    const c10::hip::HIPGuardMasqueradingAsCUDA guard(dev);
     const int64_t P = means3D.size(0);
     Tensor present = at::zeros({P}, at::TensorOptions().dtype(at::kBool).device(dev));
     if (P != 0) {
         In m(means3D, dev, "means3D"), v(viewmatrix, dev, "viewmatrix"), p(projmatrix, dev, "projmatrix");
-        check(igs_rast_mark_visible(at::hip::getCurrentHIPStream(dev.index()).stream(), (int)P, m.p, v.p, p.p, (uint8_t*)present.data_ptr()),
+        check(igs_rast_mark_visible(c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(dev.index()).stream(), (int)P, m.p, v.p, p.p, (uint8_t*)present.data_ptr()),
               "igs_rast_mark_visible");
     }
     return present;
@@ -228,8 +230,8 @@ void adam_step_multi(const std::vector<Tensor>& params, const std::vector<Tensor
         p[k] = P_.data_ptr<float>(); g[k] = G.data_ptr<float>(); m[k] = exp_avgs[k].data_ptr<float>(); v[k] = exp_avg_sqs[k].data_ptr<float>();
         cnt[k] = (size_t)P_.numel(); lr[k] = (float)lrs[k]; b1c[k] = (float)bc1[k]; b2c[k] = (float)bc2_sqrt[k];
     }
-    const c10::hip::HIPGuard guard(dev);
-    const int rc = igs_adam_step_multi(at::hip::getCurrentHIPStream(dev.index()).stream(), (int)n, p, g, m, v, cnt, lr, b1c, b2c, (float)beta1,
+    const c10::hip::HIPGuardMasqueradingAsCUDA guard(dev);
+    const int rc = igs_adam_step_multi(c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(dev.index()).stream(), (int)n, p, g, m, v, cnt, lr, b1c, b2c, (float)beta1,
                                        (float)beta2, (float)eps);
     if (rc != 0) throw RasterizerError("igs_adam_step_multi failed: " + std::to_string(rc));
 }
