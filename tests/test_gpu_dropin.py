@@ -105,9 +105,12 @@ def test_nan_report_from_the_kernel_and_kernel_side_clamp(dev):
             assert float(plain[0].abs().max()) > 15.0
             for i, name in ((0, "means3D"), (2, "sh"), (3, "opacities"), (4, "scales"), (5, "rotations")):
                 want = torch.clamp(plain[i], -15, 15)
-                # float atomics in the blend backward: the two runs differ by rounding, the clamp itself is exact
-                d = float((clamped[i] - want).abs().max())
-                assert d <= 2e-3 * max(1.0, float(want.abs().max())), (name, use, d)
+                # two separate backward runs: float atomics in the blend backward make them differ by rounding RELATIVE TO THE UNCLAMPED
+                # magnitudes (hundreds here), so an element near +-15 may sit on the other side of the bound; the clamp itself is exact
+                d = (clamped[i] - want).abs()
+                scale = float(plain[i].abs().max())
+                assert float(d.max()) <= 2e-4 * scale, (name, use, float(d.max()), scale)
+                assert float((d > 1e-5 * scale).float().mean()) < 5e-3, (name, use)
                 assert float(clamped[i].abs().max()) <= 15.0
             torch.testing.assert_close(clamped[1], plain[1], rtol=2e-3, atol=1e-3 * float(plain[1].abs().max()))      # means2D is NOT clamped
     finally:
