@@ -564,10 +564,11 @@ extern "C" unsigned igs_rast_get_slab_hint(void) { return g_hint.slab; }
 // autograd backward functions on its own worker thread): bit 0 coord, 1 depth, 2 normal, 3 abs-gradient moment; -1 = none
 // (R == 0 / no backward yet).  Tests use it to prove that absent upstream gradients select the cheaper instance.
 static int g_last_bwd_instance = -1;
+extern "C" int igs_rast_last_backward_instance(void) { return __atomic_load_n(&g_last_bwd_instance, __ATOMIC_RELAXED); }
 
 // NaN report of the per-Gaussian backward kernel (replaces the reference's seven `assert not torch.isnan(g).any()` host syncs,
 // DGR/diff_gaussian_rasterization_rade/__init__.py:156-162, by one word the kernel posts into pinned host memory)
-// (64 pinned bytes per host thread and device, never freed: the thread that runs autograd backward functions may outlive the HIP runtime)
+// (2 KB of pinned memory per host thread and device, never freed: the thread that runs autograd backward functions may outlive the HIP runtime)
 struct NanSlot { uint32_t* pinned = nullptr; uint32_t* pinned_dev = nullptr; uint32_t seq = 0; bool requested = false; bool pending = false; hipStream_t stream = nullptr; };
 static thread_local float g_next_clamp = 0.f;     // one-shot: clamp of the NEXT igs_rast_backward of this thread (clamp package)
 static thread_local NanSlot g_nan[IGS_MAX_DEVICES];
@@ -579,26 +580,47 @@ extern "C" void igs_rast_next_backward_options(int nan_report, float clamp_grads
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= IGS_MAX_DEVICES) return;
     g_nan[dev].requested = nan_report != 0;
 }
-extern "C" int igs_rast_nan_report_wait(void)
+#define NAN_RING 256          // verdict words of the last NAN_RING reports of a thread stay readable (two renders in one backward pass, ...)
+static int nan_wait_at(const volatile uint32_t* word, uint32_t seq, hipStream_t stream, bool have_stream)
 {
-    if (g_nan_dev < 0 || !g_nan[g_nan_dev].pending) return fail(IGS_RAST_E_INVALID, "igs_rast_nan_report_wait: no backward with a NaN report pending on this thread");
-    NanSlot& n = g_nan[g_nan_dev];
-    n.pending = false;
-    volatile uint32_t* seq = (volatile uint32_t*)&n.pinned[1];
     double t0 = 0.0;
     for (long spins = 0;; spins++) {
-        if (__atomic_load_n(seq, __ATOMIC_ACQUIRE) == n.seq) return n.pinned[0] ? 1 : 0;
+        const uint32_t got = __atomic_load_n(word + 1, __ATOMIC_ACQUIRE);
+        if (got == seq) return word[0] ? 1 : 0;
         if ((spins & 0x3FFF) == 0x3FFF) {
-            const hipError_t q = hipStreamQuery(n.stream);
-            if (q != hipSuccess && q != hipErrorNotReady) return fail(IGS_RAST_E_HIP, "stream error while waiting for the NaN report", q);
-            if (q == hipSuccess && __atomic_load_n(seq, __ATOMIC_ACQUIRE) != n.seq) return fail(IGS_RAST_E_HIP, "the NaN report was never posted");
+            if (got != seq && got - seq < 0x80000000u && got - seq >= NAN_RING && ((got - seq) % NAN_RING) == 0)
+                return fail(IGS_RAST_E_INVALID, "the NaN report was overwritten by a later one before it was read");
+            if (have_stream) {
+                const hipError_t q = hipStreamQuery(stream);
+                if (q != hipSuccess && q != hipErrorNotReady) return fail(IGS_RAST_E_HIP, "stream error while waiting for the NaN report", q);
+                if (q == hipSuccess && __atomic_load_n(word + 1, __ATOMIC_ACQUIRE) != seq) return fail(IGS_RAST_E_HIP, "the NaN report was never posted");
+            }
             const double t = now_s();
             if (t0 == 0.0) t0 = t;
             else if (t - t0 > wait_limit_s()) return fail(IGS_RAST_E_HIP, "timed out waiting for the NaN report (IGS_RAST_WAIT_TIMEOUT_S)");
         }
     }
 }
-extern "C" int igs_rast_last_backward_instance(void) { return __atomic_load_n(&g_last_bwd_instance, __ATOMIC_RELAXED); }
+extern "C" int igs_rast_nan_report_wait(void)
+{
+    if (g_nan_dev < 0 || !g_nan[g_nan_dev].pending) return fail(IGS_RAST_E_INVALID, "igs_rast_nan_report_wait: no backward with a NaN report pending on this thread");
+    NanSlot& n = g_nan[g_nan_dev];
+    n.pending = false;
+    return nan_wait_at(n.pinned + 2 * (n.seq % NAN_RING), n.seq, n.stream, true);
+}
+extern "C" int igs_rast_nan_report_handle(const void** word, unsigned* seq)
+{
+    if (g_nan_dev < 0 || !g_nan[g_nan_dev].pending || !word || !seq) return fail(IGS_RAST_E_INVALID, "igs_rast_nan_report_handle: no backward with a NaN report pending on this thread");
+    NanSlot& n = g_nan[g_nan_dev];
+    n.pending = false;
+    *word = n.pinned + 2 * (n.seq % NAN_RING); *seq = n.seq;
+    return 0;
+}
+extern "C" int igs_rast_nan_report_wait_at(const void* word, unsigned seq)
+{
+    if (!word) return fail(IGS_RAST_E_INVALID, "igs_rast_nan_report_wait_at: NULL handle");
+    return nan_wait_at((const volatile uint32_t*)word, seq, nullptr, false);
+}
 
 // l1_gt != NULL: L1 loss fused into the blend backward (dL_dpix ignored); fuse != NULL: activation backward + Adam fused into
 // the per-Gaussian backward (no gradient outputs except the optional dL_dmean2D).
@@ -649,9 +671,9 @@ static int backward_impl(
             g_nan[dev].requested = false;
             NanSlot& n = g_nan[dev];
             if (!n.pinned) {
-                HIP_TRY(hipHostMalloc((void**)&n.pinned, 64, hipHostMallocDefault), "hipHostMalloc");
+                HIP_TRY(hipHostMalloc((void**)&n.pinned, NAN_RING * 8, hipHostMallocDefault), "hipHostMalloc");
                 HIP_TRY(hipHostGetDevicePointer((void**)&n.pinned_dev, n.pinned, 0), "hipHostGetDevicePointer");
-                n.pinned[0] = 0; n.pinned[1] = 0;
+                memset(n.pinned, 0, NAN_RING * 8);
             }
             nan = &n; g_nan_dev = dev;
         }
@@ -717,7 +739,7 @@ static int backward_impl(
         ga.clamp = clamp_next;
         if (nan) {
             nan->seq = nan->seq + 1 ? nan->seq + 1 : 1;
-            ga.nan_dev = nan_words; ga.nan_host = nan->pinned_dev; ga.nan_seq = nan->seq;
+            ga.nan_dev = nan_words; ga.nan_host = nan->pinned_dev + 2 * (nan->seq % NAN_RING); ga.nan_seq = nan->seq;
             nan->stream = s; nan->pending = true;
         }
         HIP_TRY(launch_geom_bwd(s, ga), "geom_bwd launch");

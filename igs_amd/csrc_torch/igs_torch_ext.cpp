@@ -8,7 +8,7 @@
 // Extensions over the reference's signatures are keyword-only extras with defaults (the positional lists are the reference's):
 //   rasterize_gaussians(..., scratch=None, out_images=None, out_radii=None, mode=0, scratch_clean=False)
 //   rasterize_gaussians_backward(..., workspace=None, out_*=None)         any upstream gradient may be None (= zeros)
-//   rasterize_gaussians_backward_ex(...same..., nan_report=False, clamp=0.0) -> (8 gradients, nan flag)
+//   rasterize_gaussians_backward_ex(...same..., nan_report=0|1|2, clamp=0.0) -> (8 gradients, nan flag, verdict word, sequence number)
 #include <torch/extension.h>
 // PyTorch-ROCm presents its HIP devices under the device type "cuda" (so that `device="cuda"` callers run unchanged): guards and
 // the current stream come from the classes that know about that
@@ -131,7 +131,8 @@ using BwdTuple = std::tuple<Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tens
 // Body of _C.rasterize_gaussians_backward (RasterizeGaussiansBackwardCUDA, DGR/rasterize_points.cu:135-246).  The seven small
 // gradients are carved from ONE [23 P] block (m2d 3 | colors 3 | opacity 1 | means3D 3 | scales 3 | rot 4 | cov3D 6); every element is
 // written by the kernels (no zero fills).  Returns the reference's 8-tuple and, with nan_report, whether a NaN was written.
-std::pair<BwdTuple, int64_t> backward_body(
+struct BwdResult { BwdTuple grads; int64_t nan = 0; int64_t nan_word = 0; int64_t nan_seq = 0; };
+BwdResult backward_body(
     const Tensor& background, const Tensor& means3D, const Tensor& radii, const Tensor& colors, const Tensor& scales, const Tensor& rotations,
     double scale_modifier, const Tensor& cov3D_precomp, const Tensor& viewmatrix, const Tensor& projmatrix, double tan_fovx, double tan_fovy,
     double kernel_size, const OptTensor& dL_dout_color, const OptTensor& dL_dout_coord, const OptTensor& dL_dout_mcoord,
@@ -140,7 +141,7 @@ std::pair<BwdTuple, int64_t> backward_body(
     const Tensor& binningBuffer, const Tensor& imageBuffer, const Tensor& alphas, bool require_coord, bool require_depth, bool debug,
     const OptTensor& workspace, const OptTensor& out_means2D, const OptTensor& out_colors, const OptTensor& out_opacity,
     const OptTensor& out_means3D, const OptTensor& out_cov3D, const OptTensor& out_sh, const OptTensor& out_scales,
-    const OptTensor& out_rotations, bool nan_report, double clamp)
+    const OptTensor& out_rotations, int64_t nan_report, double clamp)
 {
     if (!means3D.is_cuda()) throw RasterizerError("igs_amd rasterizer: tensors must be on a GPU (no CPU fallback)");
     const c10::Device dev = means3D.device();
@@ -161,7 +162,7 @@ std::pair<BwdTuple, int64_t> backward_body(
     Tensor dL_dmeans2D = carve(3, out_means2D), dL_dcolors = carve(3, out_colors), dL_dopacity = carve(1, out_opacity),
            dL_dmeans3D = carve(3, out_means3D), dL_dscales = carve(3, out_scales), dL_drotations = carve(4, out_rotations),
            dL_dcov3D = carve(6, out_cov3D);
-    int64_t nan = 0;
+    BwdResult res;
     if (P != 0) {
         In m3(means3D, dev, "means3D"), col(colors, dev, "colors_precomp"), sc(scales, dev, "scales"), rot(rotations, dev, "rotations"),
            cov(cov3D_precomp, dev, "cov3D_precomp"), bg(background, dev, "bg"), view(viewmatrix, dev, "viewmatrix"),
@@ -183,13 +184,18 @@ std::pair<BwdTuple, int64_t> backward_body(
             dL_dmeans3D.data_ptr<float>(), dL_dcov3D.data_ptr<float>(), M > 0 ? dL_dsh.data_ptr<float>() : nullptr,
             dL_dscales.data_ptr<float>(), dL_drotations.data_ptr<float>(), require_coord ? 1 : 0, require_depth ? 1 : 0, debug ? 1 : 0);
         check(rc, "igs_rast_backward");
-        if (nan_report) {
+        if (nan_report == 1) {                 // wait here (the reference's place for its asserts)
             const int v = igs_rast_nan_report_wait();
             check(v, "igs_rast_nan_report_wait");
-            nan = v;
+            res.nan = v;
+        } else if (nan_report == 2) {          // hand the verdict's address out: the caller waits once the whole backward pass is enqueued
+            const void* word = nullptr; unsigned seq = 0;
+            check(igs_rast_nan_report_handle(&word, &seq), "igs_rast_nan_report_handle");
+            res.nan_word = (int64_t)(uintptr_t)word; res.nan_seq = (int64_t)seq;
         }
     }
-    return { BwdTuple(dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations), nan };
+    res.grads = BwdTuple(dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations);
+    return res;
 }
 
 // _C.mark_visible (DGR/rasterize_points.cu:248-267)
@@ -282,7 +288,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
              const OptTensor& ws, const OptTensor& o0, const OptTensor& o1, const OptTensor& o2, const OptTensor& o3, const OptTensor& o4,
              const OptTensor& o5, const OptTensor& o6, const OptTensor& o7) {
               return backward_body(a0, a1, a2, a3, a4, a5, a6, a7, a8, a9, a10, a11, a12, a13, a14, a15, a16, a17, a18, a19, a20, a21, a22, a23,
-                                   a24, a25, a26, a27, a28, a29, a30, a31, ws, o0, o1, o2, o3, o4, o5, o6, o7, false, 0.0).first;
+                                   a24, a25, a26, a27, a28, a29, a30, a31, ws, o0, o1, o2, o3, o4, o5, o6, o7, 0, 0.0).grads;
           }, BWD_ARGS, py::call_guard<py::gil_scoped_release>());
     m.def("rasterize_gaussians_backward_ex",
           [](const Tensor& a0, const Tensor& a1, const Tensor& a2, const Tensor& a3, const Tensor& a4, const Tensor& a5, double a6, const Tensor& a7,
@@ -290,10 +296,17 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
              const OptTensor& a16, const OptTensor& a17, const OptTensor& a18, const OptTensor& a19, const Tensor& a20, const Tensor& a21, int64_t a22,
              const Tensor& a23, const Tensor& a24, int64_t a25, const Tensor& a26, const Tensor& a27, const Tensor& a28, bool a29, bool a30, bool a31,
              const OptTensor& ws, const OptTensor& o0, const OptTensor& o1, const OptTensor& o2, const OptTensor& o3, const OptTensor& o4,
-             const OptTensor& o5, const OptTensor& o6, const OptTensor& o7, bool nan_report, double clamp) {
-              return backward_body(a0, a1, a2, a3, a4, a5, a6, a7, a8, a9, a10, a11, a12, a13, a14, a15, a16, a17, a18, a19, a20, a21, a22, a23,
-                                   a24, a25, a26, a27, a28, a29, a30, a31, ws, o0, o1, o2, o3, o4, o5, o6, o7, nan_report, clamp);
-          }, BWD_ARGS, py::arg("nan_report") = false, py::arg("clamp") = 0.0, py::call_guard<py::gil_scoped_release>());
+             const OptTensor& o5, const OptTensor& o6, const OptTensor& o7, int64_t nan_report, double clamp) {
+              // nan_report: 0 none; 1 wait for the kernel's verdict here -> (grads, 0 / 1, 0, 0); 2 deferred -> (grads, 0, word, seq) for nan_report_wait
+              BwdResult r = backward_body(a0, a1, a2, a3, a4, a5, a6, a7, a8, a9, a10, a11, a12, a13, a14, a15, a16, a17, a18, a19, a20, a21, a22, a23,
+                                          a24, a25, a26, a27, a28, a29, a30, a31, ws, o0, o1, o2, o3, o4, o5, o6, o7, nan_report, clamp);
+              return std::make_tuple(r.grads, r.nan, r.nan_word, r.nan_seq);
+          }, BWD_ARGS, py::arg("nan_report") = 0, py::arg("clamp") = 0.0, py::call_guard<py::gil_scoped_release>());
+    m.def("nan_report_wait", [](int64_t word, int64_t seq) {
+        const int v = igs_rast_nan_report_wait_at((const void*)(uintptr_t)word, (unsigned)seq);
+        check(v, "igs_rast_nan_report_wait_at");
+        return v != 0;
+    }, py::arg("word"), py::arg("seq"), py::call_guard<py::gil_scoped_release>());
     m.def("mark_visible", &mark_visible, py::arg("means3D"), py::arg("viewmatrix"), py::arg("projmatrix"), py::call_guard<py::gil_scoped_release>());
     m.def("integrate_gaussians_to_points", [](const py::args&, const py::kwargs&) -> py::object {
         // GOF tetrahedra integration (DGR/rasterize_points.cu:269-387): mesh extraction only, never reached from IGS

@@ -249,20 +249,32 @@ def _make_function(clamp_grads):
             ws = lease.item.workspace(means3D.size(0)) if lease is not None else None
             # The reference asserts on seven gradient tensors with seven `.any()` reductions and host syncs (__init__.py:156-162); here
             # the per-Gaussian kernel tests what it writes and posts ONE word to the host (igs_rast_next_backward_options): no extra
-            # launch, one wait.  The clamp package's five torch.clamp calls are applied by that kernel as well.
-            nan_report = NAN_CHECKS and not (means3D.is_cuda and torch.cuda.is_current_stream_capturing())      # (a host-side assert cannot be captured)
+            # launch.  The assert is raised from the end of the SAME backward pass (an engine callback: `loss.backward()` still raises
+            # before the caller's optimizer.step()), when everything downstream of this node has been enqueued too -- waiting right
+            # here would stall the stream behind the host on every iteration.  The clamp package's five torch.clamp calls are applied by
+            # that kernel as well.
+            nan_report = 0
+            if NAN_CHECKS and not (means3D.is_cuda and torch.cuda.is_current_stream_capturing()):      # (a host-side assert cannot be captured)
+                nan_report = 2 if NAN_CHECKS_AT_END_OF_PASS else 1
             if rs.debug:
                 cpu_args = cpu_deep_copy_tuple(args)
                 try:
-                    out, has_nan = _C.rasterize_gaussians_backward_ex(*args, workspace=ws, nan_report=nan_report, clamp=clamp_value)
+                    out, has_nan, word, seq = _C.rasterize_gaussians_backward_ex(*args, workspace=ws, nan_report=nan_report, clamp=clamp_value)
                 except Exception as ex:
                     torch.save(cpu_args, "snapshot_bw.dump")
                     print("\nAn error occured in backward. Writing snapshot_bw.dump for debugging.\n")
                     raise ex
             else:
-                out, has_nan = _C.rasterize_gaussians_backward_ex(*args, workspace=ws, nan_report=nan_report, clamp=clamp_value)
+                out, has_nan, word, seq = _C.rasterize_gaussians_backward_ex(*args, workspace=ws, nan_report=nan_report, clamp=clamp_value)
             grad_means2D, grad_colors_precomp, grad_opacities, grad_means3D, grad_cov3Ds_precomp, grad_sh, grad_scales, grad_rotations = out
             assert not has_nan
+            if nan_report == 2 and word:
+                def _verdict(word=word, seq=seq):
+                    assert not _C.nan_report_wait(word, seq)
+                try:
+                    torch.autograd.Variable._execution_engine.queue_callback(_verdict)
+                except Exception:  # noqa: BLE001  (no engine pass to attach to: wait here, as the reference does)
+                    _verdict()
             # shapes autograd expects: the gradient of an absent (empty CPU) input is None
             return (grad_means3D, grad_means2D, grad_sh if sh.numel() else None, grad_colors_precomp if colors_precomp.numel() else None,
                     grad_opacities, grad_scales if scales.numel() else None, grad_rotations if rotations.numel() else None,
@@ -272,6 +284,7 @@ def _make_function(clamp_grads):
 
 
 NAN_CHECKS = True      # mirrors the reference's NaN asserts on every backward; the refine loop may turn them off
+NAN_CHECKS_AT_END_OF_PASS = True      # False: wait for the kernel's verdict inside the Function's backward, where the reference asserts
 _RasterizeGaussians = _make_function(False)
 _RasterizeGaussiansClamp = _make_function(True)
 

@@ -234,6 +234,13 @@ int igs_rast_debug_dump(void* stream, int P, int R, int width, int height,
  *   a NaN for the report, as it does through torch.clamp. */
 void igs_rast_next_backward_options(int nan_report, float clamp_grads);
 int igs_rast_nan_report_wait(void);
+/* The same wait from ANOTHER host thread or at a later time (PyTorch runs a Function's backward on its own worker thread and the
+ * assert is better raised once the whole backward pass has been enqueued): right after the igs_rast_backward that was asked for a report,
+ * on the thread that called it, igs_rast_nan_report_handle() returns where the verdict will appear (pinned host memory that stays valid
+ * for the life of the process; the last 256 reports of a thread stay readable) and its sequence number, instead of waiting;
+ * igs_rast_nan_report_wait_at(word, seq) then blocks (bounded by IGS_RAST_WAIT_TIMEOUT_S) and returns 1 / 0 / a negative code. */
+int igs_rast_nan_report_handle(const void** word, unsigned* seq);
+int igs_rast_nan_report_wait_at(const void* word, unsigned seq);
 int igs_rast_last_backward_instance(void);
 /* Test hook: overwrites the LDS of every CU with NaN bit patterns (a kernel that reads LDS it never wrote then fails small parity
  * tests instead of passing on a fresh device's zeros). */
