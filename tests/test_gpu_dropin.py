@@ -181,7 +181,7 @@ def test_multi_tensor_adam_matches_torch_adam(dev):
         oa.step(); ob.step()
         oa.zero_grad(set_to_none=True); ob.zero_grad(set_to_none=True)
     for i, (x, y) in enumerate(zip(pa, pb)):
-        torch.testing.assert_close(x.detach(), y.detach(), rtol=2e-6, atol=2e-7), i
+        torch.testing.assert_close(x.detach(), y.detach(), rtol=2e-6, atol=2e-4 * lrs[i])        # (a step moves a parameter by ~lr)
         sa, sb = oa.state[x], ob.state[y]
         assert int(sa["step"]) == int(sb["step"])
         # (torch forms exp_avg with lerp_, this kernel as b1 m + (1 - b1) g: last-bit differences where the two terms cancel)
