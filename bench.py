@@ -32,6 +32,7 @@ sample of this workload) and `psnr` (held-out camera before / after the refine s
 """
 import argparse
 import json
+import math
 import os
 import socket
 import statistics
@@ -44,6 +45,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+PMC_FILE = "r04_pmc.json"   # committed rocprofv3 counter summary of this workload (tools/profile_all.sh); used only when its build fingerprint matches
 ITERS_PER_FRAME = 50       # configs/demo.yaml refine_iterations
 
 
@@ -212,6 +214,11 @@ def main():
     ap.add_argument("--cpu-views", type=int, default=2, help="views timed on the scalar C oracle (0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="do not record per-stage HIP events")
+    ap.add_argument("--no-cold-leg", action="store_true", help="cfg3: skip the cold K steps run before everything else (ms_per_step_cold)")
+    ap.add_argument("--no-side-legs", action="store_true", help="cfg3: skip the cfg4 / cfg5 per-step side legs")
+    ap.add_argument("--side-steps", type=int, default=100)
+    ap.add_argument("--no-dropin-leg", action="store_true", help="cfg3: skip the unchanged-caller leg (tools/dropin_loop.py)")
+    ap.add_argument("--dropin-steps", type=int, default=60)
     ap.add_argument("--colour-only-forward", action="store_true",
                     help="NOT the reference configuration: render colour only (require_coord = require_depth = False)")
     ap.add_argument("--viewspace-grad", action="store_true", help="also produce dL/d(screen-space mean) (the densification statistic)")
@@ -321,13 +328,38 @@ def main():
             ref.want_viewspace_grad = args.viewspace_grad
             ref.exchange = args.exchange
             psnr_before = eval_psnr()
+
+            def scratch_refiner(seed, loss_=loss, ldn_=ldn, clamp_=clamp):
+                """The same step on a SCRATCH copy of the scene (the real parameters, optimiser state and view sequence stay untouched)."""
+                p_s = GaussianParams(raw, dev)
+                if not args.no_spatial_sort:
+                    p_s.spatial_sort()
+                r_s = Refiner(p_s, cams, gts, bg, loss=loss_, seed=seed, lambda_depth_normal=ldn_)
+                r_s.require_geometry, r_s.clamp, r_s.want_viewspace_grad = ref.require_geometry, clamp_, args.viewspace_grad
+                return r_s
+
+            def timed(r, n_warm, n_steps):
+                for _ in range(n_warm):
+                    r.step()
+                torch.cuda.synchronize()
+                t = time.perf_counter()
+                for _ in range(n_steps):
+                    r.step()
+                torch.cuda.synchronize()
+                return 1000.0 * (time.perf_counter() - t) / n_steps
+
+            if world == 1 and not args.no_cold_leg:
+                # FIRST GPU work of the refine loop in this process: W warm-up + K timed steps on a scratch copy, no spin-up before it --
+                # what a caller sees who times K steps right after start-up (the GPU's clocks are still ramping: DESIGN.md section 5)
+                r_cold = scratch_refiner(0)
+                out_extra["ms_per_step_cold"] = timed(r_cold, args.warmup, steps)
+                out_extra["cold_note"] = ("the same %d warm-up + %d timed steps run FIRST, on a scratch copy, without any spin-up before them; "
+                                          "`ms_per_step` is measured afterwards (and after --spinup-ms of further untimed work)" % (args.warmup, steps))
+                log("cold leg: %.4f ms per step" % out_extra["ms_per_step_cold"])
+                del r_cold
             if args.spinup_ms > 0:
                 # device spin-up on a scratch copy (no collectives, the real parameters and optimiser state stay as they are)
-                p_spin = GaussianParams(raw, dev)
-                if not args.no_spatial_sort:
-                    p_spin.spatial_sort()
-                r_spin = Refiner(p_spin, cams, gts, bg, loss=loss, seed=12345, lambda_depth_normal=ldn)
-                r_spin.require_geometry, r_spin.clamp, r_spin.want_viewspace_grad = ref.require_geometry, clamp, args.viewspace_grad
+                r_spin = scratch_refiner(12345)
                 t_spin, n_spin = time.perf_counter(), 0
                 while (time.perf_counter() - t_spin) * 1e3 < args.spinup_ms:
                     for _ in range(20):
@@ -337,8 +369,8 @@ def main():
                 out_extra["spinup"] = {"ms": args.spinup_ms, "steps_on_a_scratch_copy": n_spin,
                                        "note": "untimed, before the W warm-up steps, on a separate copy of the parameters: brings the GPU's clocks to "
                                                "their steady state (the same 20 steps: 0.277 ms each on an idle GPU, 0.244 after ~50 ms of work; "
-                                               "tools/experiments/spin_probe.py); --spinup-ms 0 turns it off"}
-                del r_spin, p_spin
+                                               "tools/experiments/spin_probe.py); --spinup-ms 0 turns it off; `ms_per_step_cold` is the figure without it"}
+                del r_spin
             for _ in range(args.warmup):
                 ref.step()
             torch.cuda.synchronize()
@@ -410,6 +442,59 @@ def main():
                                                      "through igs_rast_forward, 60 frames; `--config cfg2` is the full-length version"}
             except Exception as e:  # noqa: BLE001
                 out_extra["forward_only"] = {"error": str(e)}
+            if world == 1 and not args.no_side_legs:
+                # BASELINE configs[3] / configs[4] per-step workloads on THIS scene (scratch copies, 100 steps each after 20 warm-up): the
+                # reference's own loss 0.8 L1 + 0.2 (1 - SSIM), and + 0.05 depth-normal regulariser with the clamp variant's +-15 clamp
+                side = {}
+                for name, kw in (("cfg4", dict(loss_="l1_ssim", ldn_=0.0, clamp_=False)), ("cfg5", dict(loss_="l1_ssim", ldn_=0.05, clamp_=True))):
+                    try:
+                        r_s = scratch_refiner(7, **kw)
+                        ms_s = timed(r_s, 20, args.side_steps)
+                        side[name] = {"ms_per_step": ms_s, "steps": args.side_steps, "gaussians_per_s": params.P / (ms_s * 1e-3),
+                                      "loss": "0.8*L1+0.2*(1-SSIM)" + (" + 0.05*depth_normal, clamp +-15" if name == "cfg5" else "")}
+                        del r_s
+                    except Exception as e:  # noqa: BLE001
+                        side[name] = {"error": str(e)}
+                side["note"] = ("igs_refine_step on scratch copies of this scene after the timed region, one view per step: the per-step workload "
+                                "of BASELINE configs[3] / configs[4] (`--config cfg4|cfg5` runs the whole frame-by-frame streams)")
+                out_extra["side_legs"] = side
+                log("side legs: %s" % {k: (round(v["ms_per_step"], 4) if isinstance(v, dict) and "ms_per_step" in v else v) for k, v in side.items() if k != "note"})
+            if world == 1 and not args.no_dropin_leg:
+                # The UNCHANGED caller: tools/dropin_loop.py = the loop body of infer_batch.py:279-324 against the packages
+                # diff_gaussian_rasterization_rade(_clamp) -- nn.Parameters, PyTorch activations, GaussianRasterizer(settings)(...), loss,
+                # loss.backward(), optimizer.step(), zero_grad(set_to_none=True) -- same scene, fresh parameters, device-synchronised
+                try:
+                    from tools.dropin_loop import CallerModel, refine_iteration, make_losses
+                    from igs_amd.refine import DEFAULT_LRS
+                    lf = make_losses("igs")
+                    raw_sorted = {k: v.detach().clone() for k, v in scratch_refiner(0).params.leaves.items()}      # (Morton order, as the timed leg)
+
+                    def dropin(loss_, optimizer, nan, n_steps):
+                        rasterizer.NAN_CHECKS = bool(nan)
+                        gs = CallerModel(raw_sorted, dev, DEFAULT_LRS, optimizer=optimizer)
+                        for i in range(20):
+                            refine_iteration(gs, cams[i % len(cams)], gts[i % len(cams)], bg, loss=loss_, losses=lf)
+                        torch.cuda.synchronize()
+                        t = time.perf_counter()
+                        for i in range(n_steps):
+                            refine_iteration(gs, cams[i % len(cams)], gts[i % len(cams)], bg, loss=loss_, losses=lf)
+                        torch.cuda.synchronize()
+                        return 1000.0 * (time.perf_counter() - t) / n_steps
+                    n_d = args.dropin_steps
+                    d = {"l1_ms": dropin("l1", "fused", 0, n_d), "nan_checks_ms": dropin("l1", "fused", 1, n_d),
+                         "l1_ssim_ms": dropin("l1_ssim", "fused", 0, n_d), "l1_ssim_nan_checks_ms": dropin("l1_ssim", "fused", 1, n_d),
+                         "l1_torch_adam_ms": dropin("l1", "torch", 1, max(20, n_d // 3)), "steps": n_d}
+                    d["note"] = ("one refine iteration driven exactly as infer_batch.py:279-324 drives the reference's package (tools/dropin_loop.py), through "
+                                 "the compiled `_C` module; `igs_amd.losses` for l1_loss / ssim (one import line) and, except in l1_torch_adam_ms, "
+                                 "`igs_amd.optim.Adam` for torch.optim.Adam (one constructor); nan_checks = the reference's NaN asserts on "
+                                 "(one word from the per-Gaussian kernel, collected at the end of the backward pass).  The caller's own ~35 small "
+                                 "PyTorch kernels per iteration (activations and their backward, PSNR line, fills) bound this figure from the host side")
+                    out_extra["dropin"] = d
+                    log("drop-in leg: %s" % {k: round(v, 4) for k, v in d.items() if isinstance(v, float)})
+                except Exception as e:  # noqa: BLE001
+                    out_extra["dropin"] = {"error": "%s: %s" % (type(e).__name__, e)}
+                finally:
+                    rasterizer.NAN_CHECKS = False
         else:
             # cfg2: forward-only render through the drop-in entry point (one host wait per frame, like rasterizer_impl.cu:354)
             a = {k: v.detach() for k, v in params.activated().items()}
@@ -618,10 +703,16 @@ def main():
             strict = {"blend_fwd": R_avg * (100 if geo_fwd else 40) + HWp * ((60 if geo_fwd else 16) + (8 if not fused else 4)) + 8 * T_tiles,
                       "blend_bwd": R_avg * (64 if dn else 40) + HWp * ((68 if fused else 56) if dn else (40 if fused else 28)) + R_avg * (64 if dn else 40),
                       "blend_step": R_avg * ((100 if geo_fwd else 40) + 40 + 40) + HWp * ((60 if geo_fwd else 16) + 12) + 8 * T_tiles}
-            ach = ab[dom] / (per[dom] * 1e-3) / 1e9 if per[dom] > 0 else 0.0
+            # `achieved` / `frac`: the bytes this instance CANNOT avoid (strict) over the launch time -- what VERDICT r3 asked to lead with;
+            # SURVEY 8(d)'s formula (which charges per-pixel state the fused kernel never writes or re-reads, and 25 moments where the
+            # colour-only instance accumulates 10) is kept beside it as *_survey_bytes
+            ach_survey = ab[dom] / (per[dom] * 1e-3) / 1e9 if per[dom] > 0 else 0.0
+            ach = strict[dom] / (per[dom] * 1e-3) / 1e9 if per[dom] > 0 else 0.0
             roof = {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                    "bytes_per_launch": strict[dom],
+                    "achieved_survey_bytes": ach_survey, "frac_survey_bytes": ach_survey / HBM_PEAK_GBS,
                     "traffic": None,
-                    "traffic_note": "HBM bytes are not measured in this process; rocprofv3 PMC passes of the same command: profiles/r03_pmc.json",
+                    "traffic_note": "HBM bytes are not measured in this process; rocprofv3 PMC passes of the same command: profiles/%s" % PMC_FILE,
                     "algorithmic_bytes_per_launch": ab[dom], "avg_launch_ms": per[dom], "avg_launch_samples": nsamp.get(dom, 0),
                     "avg_launch_ms_sampled_in_timed_region": per_t.get(dom),
                     "stage_timing": ("HIP events on the kernels' own stream, every step of a separate %d-step pass right after the timed region"
@@ -633,8 +724,7 @@ def main():
                                  (("blend_bwd<depth, normal gradients%s>: R*64 + H*W*%d + R*100 bytes" % ((", L1 fused", 68) if fused else ("", 56)) if dn else
                                    "blend_bwd<colour-only gradients%s>: R*40 + H*W*%d + R*100 bytes" % ((", L1 fused", 40) if fused else ("", 28))) if dom == "blend_bwd"
                                   else "blend_fwd<coord,depth,normal>: R*100 + H*W*88 + 8*T bytes")),
-                    "strict": {"bytes_per_launch": strict[dom], "achieved": strict[dom] / (per[dom] * 1e-3) / 1e9 if per[dom] > 0 else 0.0,
-                               "frac": strict[dom] / (per[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS if per[dom] > 0 else 0.0,
+                    "strict": {"bytes_per_launch": strict[dom], "achieved": ach, "frac": ach / HBM_PEAK_GBS,
                                "note": "bytes this instance cannot avoid: gathers R*g, the images it writes, gt, and the accumulator rows it "
                                        "actually adds to (10 moments = 40 B for the colour-only backward, not SURVEY's 25 = 100 B); the lean forward "
                                        "stores no backward state and the fused kernel re-reads no per-pixel results"},
@@ -674,24 +764,30 @@ def main():
             # pass of this same workload (profiles/r03_pmc.json); the launch time is this run's
             try:
                 if cfg == "cfg3" and args.scene == "bench" and P == 200000 and (args.width, args.height) == (1352, 1014) and loss == "l1" and not dn:
-                    pm = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc.json")))
+                    pm = json.load(open(os.path.join(ROOT, "profiles", PMC_FILE)))
+                    from igs_amd import build as _hipbuild
+                    same_build = pm.get("_meta", {}).get("build_fingerprint") == _hipbuild._fingerprint()
+                    if not same_build:
+                        roof["traffic_note"] = ("profiles/%s was counted on ANOTHER build of the kernels (fingerprint mismatch): its HBM bytes and "
+                                                "instruction counts are not reported next to this run's launch time" % PMC_FILE)
                     vi = {}
-                    for k in (("blend_step",) if tile_fusion else ("blend_fwd", "blend_bwd")):
+                    for k in ((("blend_step",) if tile_fusion else ("blend_fwd", "blend_bwd")) if same_build else ()):
                         if k in pm and per.get(k, 0) > 0 and "SQ_INSTS_VALU" in pm[k]:
                             insts = sum(pm[k].get(c, 0.0) for c in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS"))
                             vi[k] = {"wave_insts_per_launch": insts, "valu": pm[k]["SQ_INSTS_VALU"], "salu": pm[k].get("SQ_INSTS_SALU"),
                                      "lds": pm[k].get("SQ_INSTS_LDS"), "issue_frac": insts * 2.5 / 1024.0 / (per[k] * 1e-3 * 2.4e9)}
-                    if dom in pm and pm[dom].get("hbm_bytes_per_launch"):
+                    if same_build and dom in pm and pm[dom].get("hbm_bytes_per_launch"):
                         # HBM bytes per launch of the dominant kernel: FETCH_SIZE + WRITE_SIZE passes of rocprofv3 on this same command,
                         # with the guide's unit and gfx950 corrections (tools/summarize_profile.py) -- the committed profile, not this process
                         roof["traffic"] = pm[dom]["hbm_bytes_per_launch"]
-                        roof["traffic_note"] = ("HBM bytes per launch from the committed rocprofv3 PMC passes of this same command (separate FETCH_SIZE / "
-                                                "WRITE_SIZE runs, corrected as MI355X_MICROARCH.md prescribes: profiles/r03_pmc.json, tools/profile_all.sh); "
-                                                "NOT counted in this process")
-                    roof["issue"] = dict(vi, note="vector + scalar + LDS wave-instructions per launch from profiles/r03_pmc.json (NOT counted in this "
-                                         "process) x 2.5 cycles per instruction and SIMD -- scalar instructions cost an issue slot like vector ones "
-                                         "(tools/ubench/scalar_cost, profiles/r03_ubench_scalar_cost.txt) -- / 1024 SIMDs / (this run's launch time x "
-                                         "2.4 GHz peak clock)")
+                        roof["traffic_note"] = ("HBM bytes per launch from the committed rocprofv3 PMC passes of this same command on this same build "
+                                                "(separate FETCH_SIZE / WRITE_SIZE runs, corrected as MI355X_MICROARCH.md prescribes: profiles/%s, "
+                                                "tools/profile_all.sh); NOT counted in this process" % PMC_FILE)
+                    if vi:
+                        roof["issue"] = dict(vi, note="vector + scalar + LDS wave-instructions per launch from profiles/%s (same build; NOT counted in this "
+                                             "process) x 2.5 cycles per instruction and SIMD -- scalar instructions cost an issue slot like vector ones "
+                                             "(tools/ubench/scalar_cost, profiles/r03_ubench_scalar_cost.txt) -- / 1024 SIMDs / (this run's launch time x "
+                                             "2.4 GHz peak clock)" % PMC_FILE)
             except Exception:  # noqa: BLE001
                 pass
             out["roofline"] = roof
@@ -708,6 +804,34 @@ def main():
                     cb["c_port"] = cpu_baseline_c_port(raw, [c.to("cpu") for c in cams], bg.cpu(), gts_cpu, args.cpu_views)
                 except Exception as e:  # noqa: BLE001
                     cb["c_port"] = {"value": None, "sample": "failed: %s" % e}
+            if not stream and cfg == "cfg3":
+                # PSNR against an INDEPENDENT image: the held-out camera of the REFINED parameters rendered by the scalar C oracle
+                # (oracle/rast_oracle.c, the checker) and by the HIP path; `psnr.before / after` above compare with this renderer's own target
+                try:
+                    from oracle import c_oracle as co
+                    import numpy as np
+                    co.set_precision("float32")
+                    leaves = {k: v.detach() for k, v in params.leaves.items()}
+                    with torch.no_grad():
+                        hip_img = render(activate(leaves), test_cam, bg)["images_pred"].cpu().numpy()
+                    a_c = {k: v.detach().cpu() for k, v in activate({k: v.cpu() for k, v in leaves.items()}).items()}
+                    import copy
+                    tc = copy.copy(cams_all[-1]).to("cpu")
+                    t_o = time.time()
+                    _, o_img, _ = co.rasterize_forward(bg.cpu(), a_c["means3D"], None, a_c["opacities"], a_c["scales"], a_c["rotations"], 1.0, None,
+                                                       tc.world_view_transform, tc.full_proj_transform, tc.tanfovx, tc.tanfovy, 0.0, tc.height,
+                                                       tc.width, a_c["shs"], 3, tc.camera_center)
+                    mse = float(np.mean((np.clip(hip_img, 0, 1).astype(np.float64) - np.clip(o_img["color"], 0, 1).astype(np.float64)) ** 2))
+                    gt_np = gt_test.cpu().numpy().astype(np.float64)
+                    out["psnr"]["vs_oracle_image"] = -10.0 * math.log10(max(mse, 1e-30))
+                    out["psnr"]["oracle_image_vs_target"] = -10.0 * math.log10(max(float(np.mean((np.clip(o_img["color"], 0, 1) - gt_np) ** 2)), 1e-30))
+                    out["psnr"]["max_abs_vs_oracle_image"] = float(np.abs(hip_img - o_img["color"]).max())
+                    out["psnr"]["vs_oracle_note"] = ("held-out camera of the refined parameters: HIP image against the scalar C oracle's image of the same "
+                                                     "parameters (%.1f s on one core); oracle_image_vs_target = the oracle's image against the target, to be "
+                                                     "compared with `after`" % (time.time() - t_o))
+                except Exception as e:  # noqa: BLE001
+                    out["psnr"]["vs_oracle_image"] = None
+                    out["psnr"]["vs_oracle_note"] = "failed: %s: %s" % (type(e).__name__, e)
             out["cpu_baseline"] = cb
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -69,11 +69,20 @@ def main():
             for c in sorted(cs):
                 for k, val in per_kernel(agg, c).items():
                     summary.setdefault(k, {})[c] = val
+    # which build of the kernels these counters belong to (bench.py reports them only next to launch times of the same build)
+    sys.path.insert(0, ROOT)
+    try:
+        from igs_amd import build as _b
+        summary["_meta"] = {"build_fingerprint": _b._fingerprint()}
+    except Exception as e:  # noqa: BLE001
+        summary["_meta"] = {"build_fingerprint": None, "error": str(e)}
     dst = os.path.join(ROOT, "profiles", "%s_pmc.json" % tag)
     json.dump(summary, open(dst, "w"), indent=1, sort_keys=True)
     json.dump(summary, open(os.path.join(ROOT, "profiles", "pmc_latest.json"), "w"), indent=1, sort_keys=True)
     print("wrote", dst)
     for k, v in summary.items():
+        if k == "_meta":
+            continue
         print(k, {a: (round(b, 1) if isinstance(b, float) else b) for a, b in v.items()})
 
 
