@@ -642,6 +642,12 @@ def main():
     else:
         total_gv = float(gauss_views)
 
+    if world > 1:
+        import torch.distributed as dist
+        bk = dist.get_backend()                        # the backend the process group actually runs on
+        backend_name = "RCCL (torch.distributed backend nccl)" if bk == "nccl" else "torch.distributed backend %s (NOT RCCL: a rehearsal)" % bk
+    else:
+        backend_name = None
     if rank == 0:
         P = args.points
         loss_txt = "L1" if loss == "l1" else "0.8*L1+0.2*(1-SSIM)"
@@ -667,10 +673,11 @@ def main():
             "config": {"workload": work, "name": cfg, "scene": args.scene, "points": P, "width": args.width, "height": args.height,
                        "views": args.cams, "loss": loss, "lambda_depth_normal": ldn, "clamp": bool(clamp),
                        "parallelism": ("one GPU: the whole step inside igs_refine_step, no exchange" if world == 1 else
-                                       ("views sharded over %d ranks, one view per rank and step; RCCL all-gather of the per-view colour "
-                                        "gradients + all-reduce of the 11 small-group gradients (DESIGN.md section 6)" % world
+                                       ("views sharded over %d ranks, one view per rank and step; %s all-gather of the per-view colour "
+                                        "gradients + all-reduce of the 11 small-group gradients (DESIGN.md section 6)" % (world, backend_name)
                                         if args.exchange == "colors" else
-                                        "views sharded over %d ranks, one view per rank and step; RCCL all-reduce of the flat 59*P-float gradient" % world))},
+                                        "views sharded over %d ranks, one view per rank and step; %s all-reduce of the flat 59*P-float gradient" % (world, backend_name))),
+                       "backend": backend_name if world > 1 else None},
             "ms_per_step_per_rank": [1000.0 * e / steps for e in per_rank],
         }
         out.update(out_extra)

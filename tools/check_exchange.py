@@ -105,6 +105,20 @@ def main():
         if rank == 0:
             print("%s: max |colors - gradients| = %.3g (scale %.3g), within tolerance: %.4f of the elements, replicas identical: %s" % (what, err, scale, close, same))
         ok = ok and close > 0.999 and same
+    if world == 1:
+        # one rank: the exchange step (gradients to HBM, collectives over a one-rank communicator, igs_adam_exchange_step) must land where
+        # the single-GPU fused step (igs_refine_step applying Adam itself) lands from the same start with the same views
+        p = GaussianParams(raw, dev)
+        r = Refiner(p, cams, gts, bg, loss=args.loss, seed=3)
+        r.clamp = args.clamp
+        for _ in range(3):
+            r.step()
+        torch.cuda.synchronize()
+        for i, what in ((1, "first moment"), (2, "parameters")):
+            A, B = results["colors"][i], (p.exp_avg, p.flat)[i - 1]
+            close = ((A - B).abs() <= 1e-5 * B.abs() + 1e-6 * float(B.abs().max())).float().mean().item()
+            print("%s: exchange step (backend %s, 1 rank) vs single-GPU fused step: within tolerance %.4f of the elements" % (what, args.backend, close))
+            ok = ok and close > 0.999
     if rank == 0:
         print("EXCHANGE_CHECK_OK" if ok else "EXCHANGE_CHECK_FAILED")
     if args.time:
