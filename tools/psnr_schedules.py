@@ -38,9 +38,10 @@ def single_view(raw, cams, bg, gts, dev, steps, loss="l1_ssim", seed=0):
     return p
 
 
-def n_view(raw, cams, bg, gts, dev, steps, N, loss="l1_ssim", seed=0, at=()):
+def n_view(raw, cams, bg, gts, dev, steps, N, loss="l1_ssim", seed=0, at=(), lr_scale=1.0):
     """`steps` optimiser steps, each on the averaged gradient of N views.  Returns the store and {k: callback result} for k in `at`."""
-    p = GaussianParams(raw, dev); p.spatial_sort()
+    from igs_amd.refine import DEFAULT_LRS
+    p = GaussianParams(raw, dev, lrs={k: v * lr_scale for k, v in DEFAULT_LRS.items()}); p.spatial_sort()
     r = Refiner(p, cams, gts, bg, loss=loss, world_size=N, rank=0, seed=seed)      # (world_size: the 1 / N loss scale and the N picks per step)
     acc = torch.zeros_like(p.grad)
     marks = {}
@@ -76,3 +77,10 @@ if __name__ == "__main__":
     res = schedules(torch.device("cuda:0"), N, S, ks=sorted({math.ceil(S / N), 10, 13, 17, 25, 35, S}))
     for k, v in res.items():
         print("%-28s held-out PSNR %.2f dB" % (k, v))
+    # learning rates scaled with the number of views per step (Adam: a step moves a parameter by ~lr whatever N is)
+    scene = build(torch.device("cuda:0"))
+    raw, cams, bg, gts, test_cam, gt_test = scene
+    for ls in (1.5, 2.0, 3.0):
+        ks = sorted({math.ceil(S / N), 10, 13, 17, 25})
+        _, marks = n_view(raw, cams, bg, gts, torch.device("cuda:0"), max(ks), N, at={k: (lambda p: held_out(p, test_cam, bg, gt_test)) for k in ks}, lr_scale=ls)
+        print("lr x %.1f: " % ls + ", ".join("%d steps %.2f dB" % (k, marks[k]) for k in ks))
