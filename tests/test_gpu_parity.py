@@ -151,6 +151,15 @@ def check_grads(gout, gr, bulk=0.96, p99=1e-2, worst=0.25):
         assert r.max() < worst, (n, r.max())
 
 
+def certify_grads(gout, a, cam, bg, grads, label, **kw):
+    """The every-element bar of the BASELINE-configuration tests (tests/certificate.py: each gradient element within 1e-3 rel of a float64
+    evaluation of the same formulas, or inside a bounded allowance where the float32 oracle itself is that far off) for the feature
+    branches too (`check_grads` let 4 % of the elements be anywhere).  Prints the allowance counts."""
+    import certificate as cert
+    ob = cert.oracle_all(a, cam, bg, grads, samples=12, exp_samples=2, **kw)
+    return cert.certify(gout, ob, label, max_allowance_frac=0.05, oracle_factor=2.0, allowance_floor=50)
+
+
 @pytest.mark.parametrize("req", [(True, True), (True, False), (False, True), (False, False)])
 def test_stages_and_images_match_oracle(dev, req):
     from igs_amd import rasterizer as R
@@ -192,6 +201,7 @@ def test_gradients_match_oracle(dev, req):
     gout = hip_backward(out, ad, mats, cam, bg, dev, grads, req)
     gr = oracle_backward(st, oo, a, cam, bg, grads)
     check_grads(gout, gr)
+    certify_grads(gout, a, cam, bg, grads, "4000 @160x160 req=%s" % (req,), req=req)
 
 
 def test_cfg1_full_size_10k_256(dev):
@@ -221,6 +231,7 @@ def test_lower_sh_degrees(dev, deg):
     gout = hip_backward(out, ad, mats, cam, bg, dev, grads, deg=deg)
     gr = oracle_backward(st, oo, a, cam, bg, grads, deg=deg)
     check_grads(gout, gr)
+    certify_grads(gout, a, cam, bg, grads, "SH degree %d" % deg, deg=deg)
     used = (deg + 1) ** 2
     assert float(gout[5][:, used:, :].abs().max()) == 0.0        # inactive SH bands get exactly zero gradient
 
@@ -245,6 +256,7 @@ def test_precomputed_colors_and_covariance(dev):
         A = gout[GNAMES.index(n)].cpu().numpy().reshape(gr[n].shape)
         r = rel(A, gr[n])
         assert (r <= 1e-3).mean() >= 0.96 and np.median(r) < 1e-4, (n, (r <= 1e-3).mean())
+    certify_grads(gout, a, cam, bg, grads, "colors_precomp + cov3D_precomp", colors=colors, cov=cov)
     assert float(gout[6].abs().max()) == 0.0 and float(gout[7].abs().max()) == 0.0      # no scale / rotation path
 
 
@@ -263,7 +275,9 @@ def test_ragged_image_size_and_background(dev):
     assert out[0] == nr_o and tuple(out[1].shape) == (3, 101, 157)
     check_images(out, oo)
     grads = rand_grads(oo, 4)
-    check_grads(hip_backward(out, ad, mats, cam, bg, dev, grads), oracle_backward(st, oo, a, cam, bg, grads))
+    gout = hip_backward(out, ad, mats, cam, bg, dev, grads)
+    check_grads(gout, oracle_backward(st, oo, a, cam, bg, grads))
+    certify_grads(gout, a, cam, bg, grads, "ragged 157x101, tilted camera, background")
 
 
 def test_kernel_size_nonzero(dev):
@@ -277,6 +291,7 @@ def test_kernel_size_nonzero(dev):
     gout = hip_backward(out, ad, mats, cam, bg, dev, grads, kernel_size=0.1)
     gr = oracle_backward(st, oo, a, cam, bg, grads)
     check_grads(gout, gr, bulk=0.95)
+    certify_grads(gout, a, cam, bg, grads, "kernel_size 0.1", kernel_size=0.1)
 
 
 def test_empty_culled_and_prefiltered(dev):
