@@ -618,68 +618,102 @@ class Refiner:
         self.adam_fn()
         return pkg
 
-    def step(self, view=None):
+    # ---- one refine iteration -------------------------------------------------------------------------------------------------
+    # `step()` picks the view and dispatches to ONE of five small methods; which one follows from how the Refiner was set up
+    # (`_mode()`), not from branches spread over the body:
+    #   densify    native path with densify-and-prune hooks around the step (infer_batch.py:308-321)
+    #   fused      one GPU, the library's optimiser: the whole iteration inside igs_refine_step
+    #   exchange   N > 1 ranks, an injected optimiser, or fused=False: the native launches end in the flat gradient, then the exchange
+    #              (colours / gradients / none) and Adam
+    #   direct     autograd path (the reference's Python API), gradients handed straight to the fused Adam (zero_grad(set_to_none) semantics)
+    #   autograd   autograd path accumulating into the flat gradient buffer (all-reduce for N > 1, injected render / optimiser functions)
+    def _native_ok(self):
+        return self.native and self.render_fn is render and (self.fused or self.lambda_depth_normal == 0.0)
+
+    def _mode(self):
         p = self.params
+        own_adam = self.adam_fn == p.adam_step
+        if self.densify is not None:
+            if not (self._native_ok() and own_adam):
+                raise NotImplementedError("densify-and-prune is implemented for the native path with the library's optimiser only "
+                                          "(native=True, no injected render_fn / adam_fn)")
+            return "densify"
+        if self._native_ok():
+            return "fused" if (self.fused and self.world_size == 1 and own_adam) else "exchange"
+        if (self.world_size == 1 and own_adam and self.render_fn is render and p.flat.is_cuda and getattr(self, "direct_adam", False)):
+            return "direct"          # opt-in: tests and callers that read `.grad` keep the flat buffer
+        return "autograd"
+
+    def step(self, view=None):
         explicit_view = view
         if view is None:
             view = self._next_view()
         cam, gt = self.cams[view], self.gt[view]
         self._view = view
-        native_ok = self.native and self.render_fn is render and (self.fused or self.lambda_depth_normal == 0.0)
-        if self.densify is not None and not (native_ok and self.adam_fn == p.adam_step):
-            raise NotImplementedError("densify-and-prune is implemented for the native path with the library's optimiser only "
-                                      "(native=True, no injected render_fn / adam_fn)")
-        if self.densify is not None:
-            # the reference updates the statistics after every backward and, on a densification iteration, rebuilds the
-            # Gaussians BEFORE optimizer.step() -- which then finds no gradients and does nothing (infer_batch.py:308-324).
-            # N > 1: every rank adds the statistics of its own view; they are reduced over ranks right before the decision
-            # (densify.reduce_state), which every rank then takes identically.
-            if self._densify_due():
-                pkg = self._fused_step(cam, gt, grads_only=True) if self.fused else self._native_step(cam, gt)    # gradients only, no Adam
-                self._densify_hooks(pkg, did_adam=False)
-            else:
-                if self.world_size == 1:
-                    pkg = self._fused_step(cam, gt) if self.fused else self._native_then_adam(cam, gt)
-                else:
-                    pkg = self._exchange_step(cam, gt, explicit_view)
-                self._densify_hooks(pkg, did_adam=True) if self.iteration < self.densify.until_iter else None
+        mode = self._mode()
+        if mode == "densify":
+            pkg = self._step_densify(cam, gt, explicit_view)      # (its hooks read the iteration number BEFORE it is advanced, as the reference's loop does)
             self.iteration += 1
             return pkg
         self.iteration += 1
-        if (native_ok and self.fused and self.world_size == 1 and self.adam_fn == p.adam_step):
+        if mode == "fused":
             return self._fused_step(cam, gt)
-        if native_ok:
+        if mode == "exchange":
             return self._exchange_step(cam, gt, explicit_view)
-        # the reference's own loop: `optimizer.zero_grad(set_to_none=True)` (infer_batch.py:324) -- gradients are handed over by
-        # autograd, never zero-filled and accumulated.  With the library's optimiser on one GPU the same here: torch.autograd.grad
-        # returns the five gradient tensors and one fused Adam launch per group consumes them (no 47 MB zero fill, no 47 MB
-        # accumulate into the flat gradient buffer); every other case keeps the flat buffer (all-reduce, injected optimisers, tests
-        # that read `.grad`).
-        direct = (self.world_size == 1 and self.adam_fn == p.adam_step and self.render_fn is render and p.flat.is_cuda
-                  and getattr(self, "direct_adam", False))      # opt-in: tests and callers that read `.grad` keep the flat buffer
+        return self._step_autograd(cam, gt, direct=(mode == "direct"))
+
+    def _step_densify(self, cam, gt, explicit_view):
+        """The reference updates the statistics after every backward and, on a densification iteration, rebuilds the Gaussians BEFORE
+        optimizer.step() -- which then finds no gradients and does nothing (infer_batch.py:308-324).  N > 1: every rank adds the
+        statistics of its own view; they are reduced over ranks right before the decision (densify.reduce_state), which every rank
+        then takes identically."""
+        if self._densify_due():
+            pkg = self._fused_step(cam, gt, grads_only=True) if self.fused else self._native_step(cam, gt)    # gradients only, no Adam
+            self._densify_hooks(pkg, did_adam=False)
+            return pkg
+        if self.world_size == 1:
+            pkg = self._fused_step(cam, gt) if self.fused else self._native_then_adam(cam, gt)
+        else:
+            pkg = self._exchange_step(cam, gt, explicit_view)
+        if self.iteration < self.densify.until_iter:
+            self._densify_hooks(pkg, did_adam=True)
+        return pkg
+
+    def _autograd_loss(self, pkg, cam, gt):
+        """The loss of the autograd path as a differentiable scalar: L1 (+ D-SSIM) (+ depth-normal regulariser), infer_batch.py:300-306."""
+        img = pkg["images_pred"]
+        loss = torch.abs(img - gt).mean()
+        if self.loss != "l1":
+            loss = self.lambda_l1 * loss + (1.0 - self.lambda_l1) * (1.0 - self._ssim_value(img, gt))
+        if self.lambda_depth_normal > 0.0:
+            self.last_depth_normal_loss = self._depth_normal_value(pkg, cam)
+            loss = loss + self.lambda_depth_normal * self.last_depth_normal_loss
+        return loss * getattr(self, "loss_scale", 1.0)
+
+    def _step_autograd(self, cam, gt, direct):
+        """The reference's own loop through the autograd Function.  `direct`: `optimizer.zero_grad(set_to_none=True)` semantics
+        (infer_batch.py:324) -- torch.autograd.grad returns the five gradient tensors and one fused Adam launch per group consumes them
+        (no 47 MB zero fill, no 47 MB accumulate into the flat gradient buffer); otherwise the gradients accumulate into the flat
+        buffer (all-reduce for N > 1, injected optimisers, tests that read `.grad`)."""
+        p = self.params
         if not direct:
             p.zero_grad()
         act = p.activated(fused=getattr(self, "fused_activations", False) and self.render_fn is render and p.flat.is_cuda)
-        pkg = self.render_fn(act, cam, self.bg, clamp=True) if (getattr(self, "clamp", False) and self.render_fn is render) else self.render_fn(act, cam, self.bg)
+        if getattr(self, "clamp", False) and self.render_fn is render:
+            pkg = self.render_fn(act, cam, self.bg, clamp=True)
+        else:
+            pkg = self.render_fn(act, cam, self.bg)
         img = pkg["images_pred"]
+        pure_l1 = self.loss == "l1" and self.lambda_depth_normal == 0.0
+        if pure_l1:         # fused L1 forward + gradient in one launch, handed to autograd as the upstream gradient of the image
+            if self.grad_img is None or self.grad_img.shape != img.shape:
+                self.grad_img = torch.empty_like(img)
+            self.l1(img, gt, self.grad_img, weight=1.0 if direct else 1.0 / self.world_size)      # (gradients are averaged over the views of a step)
         if direct:
             names = [n for n, _ in GROUPS]
             leaves = [p.leaves[n] for n in names]
-            if self.loss == "l1" and self.lambda_depth_normal == 0.0:
-                if self.grad_img is None or self.grad_img.shape != img.shape:
-                    self.grad_img = torch.empty_like(img)
-                self.l1(img, gt, self.grad_img, weight=1.0)
-                grads = torch.autograd.grad([img], leaves, [self.grad_img])
-            else:
-                Ll1 = torch.abs(img - gt).mean()
-                if self.loss == "l1":
-                    loss = Ll1
-                else:
-                    loss = self.lambda_l1 * Ll1 + (1.0 - self.lambda_l1) * (1.0 - self._ssim_value(img, gt))
-                if self.lambda_depth_normal > 0.0:
-                    self.last_depth_normal_loss = self._depth_normal_value(pkg, cam)
-                    loss = loss + self.lambda_depth_normal * self.last_depth_normal_loss
-                grads = torch.autograd.grad([loss * getattr(self, "loss_scale", 1.0)], leaves)
+            grads = (torch.autograd.grad([img], leaves, [self.grad_img]) if pure_l1
+                     else torch.autograd.grad([self._autograd_loss(pkg, cam, gt)], leaves))
             L = _cabi.lib()
             p.step_count += 1
             b1, b2 = p.betas
@@ -693,22 +727,10 @@ class Refiner:
                 if rc != 0:
                     raise RuntimeError("igs_adam_step failed: %d" % rc)
             return pkg
-        if self.loss == "l1" and self.lambda_depth_normal == 0.0:
-            if self.grad_img is None or self.grad_img.shape != img.shape:
-                self.grad_img = torch.empty_like(img)
-            scale = 1.0 / self.world_size           # gradients are averaged over the views of a step
-            self.l1(img, gt, self.grad_img, weight=scale)
+        if pure_l1:
             img.backward(gradient=self.grad_img)
         else:
-            Ll1 = torch.abs(img - gt).mean()
-            if self.loss == "l1":
-                loss = Ll1
-            else:       # infer_batch.py:302, with the drop-in fused SSIM (igs_amd/losses.py) unless the caller asked for torch's
-                loss = self.lambda_l1 * Ll1 + (1.0 - self.lambda_l1) * (1.0 - self._ssim_value(img, gt))
-            if self.lambda_depth_normal > 0.0:
-                self.last_depth_normal_loss = self._depth_normal_value(pkg, cam)
-                loss = loss + self.lambda_depth_normal * self.last_depth_normal_loss
-            (loss * getattr(self, "loss_scale", 1.0) / self.world_size).backward()
+            (self._autograd_loss(pkg, cam, gt) / self.world_size).backward()
         if self.world_size > 1:
             import torch.distributed as dist
             dist.all_reduce(p.grad, op=dist.ReduceOp.SUM)      # one flat 59*P-float buffer over RCCL / xGMI
