@@ -326,7 +326,12 @@ static inline uint32_t tile_grid_blocks(uint32_t gx, uint32_t gy) { return 8u * 
 // The fused blend kernel's dispatch order (sort.hip: build_step_order): usable when tile_sort's one-wave-per-tile kernel runs (slabs
 // of at most 1024 slots) and an XCD group has at most 64 * STEP_ORDER_CHUNKS workgroups.
 #define STEP_ORDER_CHUNKS 16
-static inline bool step_order_usable(uint32_t gx, uint32_t gy, uint32_t slab) { return slab <= 1024u && ((gy + 7u) / 8u) * gx <= 64u * STEP_ORDER_CHUNKS; }
+// slabs up to this size: every tile is sorted by one wave in registers and no second launch follows (sort.hip: launch_tile_sort) -- the
+// only configuration in which the tile sort also writes the fused blend kernel's dispatch order, so both places read THIS constant
+#ifndef TILE_SORT_WAVE_ALONE
+#define TILE_SORT_WAVE_ALONE 1024
+#endif
+static inline bool step_order_usable(uint32_t gx, uint32_t gy, uint32_t slab) { return slab <= (uint32_t)TILE_SORT_WAVE_ALONE && ((gy + 7u) / 8u) * gx <= 64u * STEP_ORDER_CHUNKS; }
 
 // Longest-first dispatch of the BACKWARD blend.  A tile's blend time is proportional to its instance count, which ranges from 0 to
 // several times the mean; workgroups are dispatched in block order, and with ~2.7 generations of resident workgroups a heavy tile

@@ -714,9 +714,7 @@ tile_sort_one_kernel(uint32_t T, uint32_t* __restrict__ tile_count, const uint64
     STL(4, wall_clock64());
 }
 
-#ifndef TILE_SORT_WAVE_ALONE
-#define TILE_SORT_WAVE_ALONE 1024         // slabs up to this size: every tile by one wave in registers, no second launch
-#endif
+// (TILE_SORT_WAVE_ALONE: common.h -- slabs up to this size: every tile by one wave in registers, no second launch)
 #ifndef TILE_SORT_WAVE_WITH_MID
 #define TILE_SORT_WAVE_WITH_MID 1024      // ... larger slabs: the register sort keeps the tiles up to this size, the LDS kernel takes the rest
 #endif                                    // (256 / 512 measured: no better on the dense scene, and a second launch for nothing on the bench scene's 1024-slot slabs)
@@ -737,6 +735,7 @@ hipError_t launch_tile_sort(hipStream_t s, uint32_t T, uint32_t* tile_count, con
     // with a step order wanted (fused refine step, step_order_usable): one extra workgroup builds it from the fill cursors, and these stay
     // as they are -- the fused blend kernel zeroes them (BlendFwdArgs::reset_cursors)
     const bool ord = step_order != nullptr && !mid;
+    if (step_order != nullptr && mid) return hipErrorInvalidValue;      // (api.hip asks step_order_usable() first: a dispatch order nobody writes must never be read)
     hipLaunchKernelGGL(tile_sort_kernel, dim3((T + 3) / 4 + (ord ? 2 : 0)), dim3(256), 0, s, T, tile_count, pairs, point_list, ranges, slab, stats, counters,
                        id_max, (mid || ord) ? 0 : 1, wave_max, ord ? step_order : nullptr, gx, gy);
     if (mid) hipLaunchKernelGGL(tile_sort_mid_kernel, dim3(T), dim3(256), 0, s, tile_count, pairs, point_list, slab, id_max, big ? 0 : 1, wave_max);

@@ -203,10 +203,12 @@ class GtStatsCache:
         self.entries = {}          # view -> [buffer, identity of the gt it holds, pool key]
 
     def get(self, view, gt):
+        """(pointer, valid) for `gt` as view `view`'s ground truth.  The entry keeps a REFERENCE to the tensor it was filled from (the
+        allocator cannot hand its address to another image while the entry lives) and its version counter; a first visit returns valid = 0
+        and the entry only counts as filled once `confirm(view)` has been called after the launch that fills it succeeded."""
         H, W = int(gt.shape[-2]), int(gt.shape[-1])
-        ident = (gt.data_ptr(), gt._version, H, W)
         e = self.entries.get(view)
-        if e is not None and e[1] == ident:
+        if e is not None and e[1] is not None and e[1][0] is gt and e[1][1] == gt._version and e[3]:
             return e[0].data_ptr(), 1
         if e is None or e[2] != (H, W, str(self.device)):
             if e is not None:
@@ -214,9 +216,15 @@ class GtStatsCache:
             pk = (H, W, str(self.device))
             free = GtStatsCache._pool.setdefault(pk, [])
             buf = free.pop() if free else torch.empty(_cabi.lib().igs_ssim_gt_stats_bytes(W, H) // 4, dtype=torch.float32, device=self.device)
-            e = self.entries[view] = [buf, None, pk]
-        e[1] = ident
+            e = self.entries[view] = [buf, None, pk, False]
+        e[1], e[3] = (gt, gt._version), False
         return e[0].data_ptr(), 0
+
+    def confirm(self, view):
+        """The launch that fills view `view`'s buffer has been enqueued successfully: later visits may read it."""
+        e = self.entries.get(view)
+        if e is not None:
+            e[3] = True
 
     @staticmethod
     def _give_back(e):
@@ -376,6 +384,7 @@ class Refiner:
                 self.grad_img = torch.empty_like(color)
             if self.gt_stats is not None and self.cache_gt_stats and getattr(self, "_view", None) is not None:
                 self.l1(color, gt, self.grad_img, weight=1.0 / self.world_size, gt_stats=self.gt_stats.get(self._view, gt))
+                self.gt_stats.confirm(self._view)          # (l1 raises when the launch fails)
             else:
                 self.l1(color, gt, self.grad_img, weight=1.0 / self.world_size)      # L1 or L1 + D-SSIM, fused fwd + bwd
             G = p.grad
@@ -467,6 +476,8 @@ class Refiner:
         with torch.cuda.device(dev):
             nr = L.igs_refine_step(C.byref(a))
         _rast._check(nr, "igs_refine_step")
+        if a.gt_stats:
+            self.gt_stats.confirm(self._view)              # filled (or read) by a call that succeeded
         if not grads_only:
             p.step_count += 1
         self.last_num_rendered = nr

@@ -327,7 +327,9 @@ typedef struct igs_refine_step_args {
     void* color_ready_event;                  /* optional hipEvent_t (with grad_out and color_grad_out, multi-GPU): color_grad_out is then written
                                                  right after the blend backward -- one kernel before the step ends -- and this event is recorded on
                                                  `stream` behind it, so that the caller can start the all-gather of the colour gradients on another
-                                                 stream underneath the per-Gaussian kernel.  NULL: written by the last kernel of the step */
+                                                 stream underneath the per-Gaussian kernel.  NULL: written by the last kernel of the step.
+                                                 Queue the wait on the event only AFTER igs_refine_step has returned: in the rare frame that is
+                                                 redone with larger slabs the event is recorded twice, and only the second record is behind valid data */
 } igs_refine_step_args;
 int igs_refine_step(const igs_refine_step_args* args);
 size_t igs_refine_step_args_size(void);       /* sizeof(igs_refine_step_args) of the loaded library: bindings check it before the first call */
