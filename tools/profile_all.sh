@@ -8,7 +8,7 @@ cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/prof_$TAG
 rm -rf $O && mkdir -p $O
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $R/bench.py --steps 50 --warmup 10 --no-cpu-baseline "$@" > $O/bench_under_rocprof.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $R/bench.py --steps 50 --warmup 10 --no-cpu-baseline --no-cold-leg --no-side-legs --no-dropin-leg "$@" > $O/bench_under_rocprof.log 2>&1
 echo stats done
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/fetch -- python3 $R/tools/prof_run.py 12 > $O/fetch.log 2>&1
 echo fetch done

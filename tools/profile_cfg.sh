@@ -6,7 +6,7 @@ cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/prof_$TAG
 rm -rf $O && mkdir -p $O
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $R/bench.py --no-cpu-baseline "$@" > $O/bench_under_rocprof.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $R/bench.py --no-cpu-baseline --no-cold-leg --no-side-legs --no-dropin-leg "$@" > $O/bench_under_rocprof.log 2>&1
 mkdir -p $R/gpurun_out/profiles_$TAG
 cp $(find $O/stats -name "*kernel_stats.csv" | head -1) $R/gpurun_out/profiles_$TAG/${TAG}_kernel_stats.csv
 find $O -name "*.db" -delete; find $O -name "*kernel_trace.csv" -delete
