@@ -51,9 +51,15 @@ ssim_stats_kernel(const SsimWin win, int W, int H, const float* __restrict__ x, 
                   float* __restrict__ maps, float* __restrict__ ssim_sum, float* __restrict__ ystats)
 {
     constexpr int NST = GT == GT_CACHED ? 3 : 5;          // blurred planes: x, (y), x x, (y y), x y
-    constexpr int PX = 0, PY = 1, PXX = GT == GT_CACHED ? 1 : 2, PYY = 3, PXY = GT == GT_CACHED ? 2 : 4;
+    // LDS: the halo of x and y, and the horizontally blurred planes.  IN PLACE (round 4): blur(x) of a halo row goes back into the row it
+    // came from (columns 0..31 of sx[r]), blur(y) -- or, with the ground-truth statistics cached, blur(x y) -- into sy[r]; only the
+    // remaining planes have arrays of their own.  Every thread first computes its eight outputs of every plane from the rows in
+    // registers, then ONE more barrier, then the stores: 20.8 KB per workgroup instead of 32.9 (cached) / 32.9 instead of 45 --
+    // the kernel is bound by the latency of its phases at 3-4 workgroups per CU, not by arithmetic, and LDS was what
+    // capped the workgroups per CU.
+    constexpr int NEXTRA = NST - 2;                       // planes with storage of their own: x x (cached) | x x, y y, x y
     __shared__ __attribute__((aligned(16))) float sx[SSIM_H][SSIM_HS], sy[SSIM_H][SSIM_HS];
-    __shared__ __attribute__((aligned(16))) float hb[NST][SSIM_H][SSIM_BS];
+    __shared__ __attribute__((aligned(16))) float hbx[NEXTRA][SSIM_H][SSIM_BS];
     const int tid = threadIdx.x, c = blockIdx.z;
     const int x0 = blockIdx.x * SSIM_T - SSIM_R, y0 = blockIdx.y * SSIM_T - SSIM_R;
     const size_t HW = (size_t)W * H;
@@ -82,36 +88,43 @@ ssim_stats_kernel(const SsimWin win, int W, int H, const float* __restrict__ x, 
     __syncthreads();
     // horizontal: work item = (halo row r, group of 8 output columns): 42 x 4 = 168 items, one pass of the 256 threads;
     // consecutive lanes = consecutive rows
-    if (tid < SSIM_H * (SSIM_T / 8)) {
-        const int qg = tid / SSIM_H, r = tid - qg * SSIM_H, q = qg * 8;
+    const bool hitem = tid < SSIM_H * (SSIM_T / 8);
+    const int hqg = tid / SSIM_H, hr = hitem ? tid - hqg * SSIM_H : 0, hq = hitem ? hqg * 8 : 0;
+    float o0[8], o1[8], o2[8], o3[8], o4[8];              // blur of x, y, x x, y y, x y at the item's eight columns
+    if (hitem) {
         float u[20], v[20], uu[18], vv[18], uv[18];
 #pragma unroll
         for (int k = 0; k < 5; k++) {
-            const float4 a = *(const float4*)&sx[r][q + 4 * k], b = *(const float4*)&sy[r][q + 4 * k];
+            const float4 a = *(const float4*)&sx[hr][hq + 4 * k], b = *(const float4*)&sy[hr][hq + 4 * k];
             u[4 * k] = a.x; u[4 * k + 1] = a.y; u[4 * k + 2] = a.z; u[4 * k + 3] = a.w;
             v[4 * k] = b.x; v[4 * k + 1] = b.y; v[4 * k + 2] = b.z; v[4 * k + 3] = b.w;
         }
 #pragma unroll
         for (int k = 0; k < 18; k++) { uu[k] = u[k] * u[k]; vv[k] = v[k] * v[k]; uv[k] = u[k] * v[k]; }
 #pragma unroll
-        for (int h = 0; h < 2; h++) {
-            float a0[4], a1[4], a2[4], a3[4], a4[4];
+        for (int o = 0; o < 8; o++) {
+            o0[o] = 0.f; o1[o] = 0.f; o2[o] = 0.f; o3[o] = 0.f; o4[o] = 0.f;
 #pragma unroll
-            for (int o = 0; o < 4; o++) {
-                a0[o] = 0.f; a1[o] = 0.f; a2[o] = 0.f; a3[o] = 0.f; a4[o] = 0.f;
-#pragma unroll
-                for (int k = 0; k <= 2 * SSIM_R; k++) {
-                    const float w = win.g[k]; const int j = 4 * h + o + k;
-                    a0[o] += w * u[j]; a2[o] += w * uu[j]; a4[o] += w * uv[j];
-                    if constexpr (GT != GT_CACHED) { a1[o] += w * v[j]; a3[o] += w * vv[j]; }
-                }
+            for (int k = 0; k <= 2 * SSIM_R; k++) {
+                const float w = win.g[k]; const int j = o + k;
+                o0[o] += w * u[j]; o2[o] += w * uu[j]; o4[o] += w * uv[j];
+                if constexpr (GT != GT_CACHED) { o1[o] += w * v[j]; o3[o] += w * vv[j]; }
             }
-            *(float4*)&hb[PX][r][q + 4 * h] = make_float4(a0[0], a0[1], a0[2], a0[3]);
-            *(float4*)&hb[PXX][r][q + 4 * h] = make_float4(a2[0], a2[1], a2[2], a2[3]);
-            *(float4*)&hb[PXY][r][q + 4 * h] = make_float4(a4[0], a4[1], a4[2], a4[3]);
-            if constexpr (GT != GT_CACHED) {
-                *(float4*)&hb[PY][r][q + 4 * h] = make_float4(a1[0], a1[1], a1[2], a1[3]);
-                *(float4*)&hb[PYY][r][q + 4 * h] = make_float4(a3[0], a3[1], a3[2], a3[3]);
+        }
+    }
+    __syncthreads();                                      // every thread has its rows in registers: the halo rows may be overwritten
+    // plane -> storage: blur(x) in sx; cached: blur(x y) in sy, blur(x x) in hbx[0]; otherwise blur(y) in sy, x x / y y / x y in hbx[0..2]
+    if (hitem) {
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            *(float4*)&sx[hr][hq + 4 * h] = make_float4(o0[4 * h], o0[4 * h + 1], o0[4 * h + 2], o0[4 * h + 3]);
+            *(float4*)&hbx[0][hr][hq + 4 * h] = make_float4(o2[4 * h], o2[4 * h + 1], o2[4 * h + 2], o2[4 * h + 3]);
+            if constexpr (GT == GT_CACHED) {
+                *(float4*)&sy[hr][hq + 4 * h] = make_float4(o4[4 * h], o4[4 * h + 1], o4[4 * h + 2], o4[4 * h + 3]);
+            } else {
+                *(float4*)&sy[hr][hq + 4 * h] = make_float4(o1[4 * h], o1[4 * h + 1], o1[4 * h + 2], o1[4 * h + 3]);
+                *(float4*)&hbx[1][hr][hq + 4 * h] = make_float4(o3[4 * h], o3[4 * h + 1], o3[4 * h + 2], o3[4 * h + 3]);
+                *(float4*)&hbx[2][hr][hq + 4 * h] = make_float4(o4[4 * h], o4[4 * h + 1], o4[4 * h + 2], o4[4 * h + 3]);
             }
         }
     }
@@ -123,9 +136,10 @@ ssim_stats_kernel(const SsimWin win, int W, int H, const float* __restrict__ x, 
     float m1[4] = { 0, 0, 0, 0 }, m2[4] = { 0, 0, 0, 0 }, e1[4] = { 0, 0, 0, 0 }, e2[4] = { 0, 0, 0, 0 }, e12[4] = { 0, 0, 0, 0 };
 #pragma unroll
     for (int k = 0; k < 14; k++) {
-        const float h0 = hb[PX][ly + k][lx], h2 = hb[PXX][ly + k][lx], h4 = hb[PXY][ly + k][lx];
-        float h1 = 0.f, h3 = 0.f;
-        if constexpr (GT != GT_CACHED) { h1 = hb[PY][ly + k][lx]; h3 = hb[PYY][ly + k][lx]; }
+        const float h0 = sx[ly + k][lx], h2 = hbx[0][ly + k][lx];
+        float h1 = 0.f, h3 = 0.f, h4;
+        if constexpr (GT != GT_CACHED) { h1 = sy[ly + k][lx]; h3 = hbx[1][ly + k][lx]; h4 = hbx[2][ly + k][lx]; }
+        else h4 = sy[ly + k][lx];
 #pragma unroll
         for (int o = 0; o < 4; o++) {
             if (k - o >= 0 && k - o <= 2 * SSIM_R) {
@@ -165,8 +179,9 @@ __global__ void __launch_bounds__(256)
 ssim_grad_kernel(const SsimWin win, int W, int H, const float* __restrict__ x, const float* __restrict__ y,
                  const float* __restrict__ maps, float c_ssim, float c_l1, float* __restrict__ grad, float* __restrict__ l1_sum)
 {
+    // (in place, as ssim_stats_kernel: the horizontally blurred row replaces columns 0..31 of the halo row it was computed from, behind
+    //  one extra barrier: 22 KB of LDS per workgroup instead of 40 -- six workgroups per CU instead of three)
     __shared__ __attribute__((aligned(16))) float sm[3][SSIM_H][SSIM_HS];
-    __shared__ __attribute__((aligned(16))) float hb[3][SSIM_H][SSIM_BS];
     const int tid = threadIdx.x, c = blockIdx.z;
     const int x0 = blockIdx.x * SSIM_T - SSIM_R, y0 = blockIdx.y * SSIM_T - SSIM_R;
     const size_t HW = (size_t)W * H;
@@ -191,28 +206,33 @@ ssim_grad_kernel(const SsimWin win, int W, int H, const float* __restrict__ x, c
         }
     }
     __syncthreads();
-    if (tid < SSIM_H * (SSIM_T / 8)) {
-        const int qg = tid / SSIM_H, r = tid - qg * SSIM_H, q = qg * 8;
+    const bool hitem = tid < SSIM_H * (SSIM_T / 8);
+    const int hqg = tid / SSIM_H, hr = hitem ? tid - hqg * SSIM_H : 0, hq = hitem ? hqg * 8 : 0;
+    float hacc[3][8];
+    if (hitem) {
 #pragma unroll
         for (int m = 0; m < 3; m++) {
             float u[20];
 #pragma unroll
             for (int k = 0; k < 5; k++) {
-                const float4 a = *(const float4*)&sm[m][r][q + 4 * k];
+                const float4 a = *(const float4*)&sm[m][hr][hq + 4 * k];
                 u[4 * k] = a.x; u[4 * k + 1] = a.y; u[4 * k + 2] = a.z; u[4 * k + 3] = a.w;
             }
 #pragma unroll
-            for (int h = 0; h < 2; h++) {
-                float acc[4];
+            for (int o = 0; o < 8; o++) {
+                hacc[m][o] = 0.f;
 #pragma unroll
-                for (int o = 0; o < 4; o++) {
-                    acc[o] = 0.f;
-#pragma unroll
-                    for (int k = 0; k <= 2 * SSIM_R; k++) acc[o] += win.g[k] * u[4 * h + o + k];
-                }
-                *(float4*)&hb[m][r][q + 4 * h] = make_float4(acc[0], acc[1], acc[2], acc[3]);
+                for (int k = 0; k <= 2 * SSIM_R; k++) hacc[m][o] += win.g[k] * u[o + k];
             }
         }
+    }
+    __syncthreads();                                      // all reads of the halo rows are done: overwrite them
+    if (hitem) {
+#pragma unroll
+        for (int m = 0; m < 3; m++)
+#pragma unroll
+            for (int h = 0; h < 2; h++)
+                *(float4*)&sm[m][hr][hq + 4 * h] = make_float4(hacc[m][4 * h], hacc[m][4 * h + 1], hacc[m][4 * h + 2], hacc[m][4 * h + 3]);
     }
     __syncthreads();
     const int lx = tid & 31, ly = (tid >> 5) * 4;
@@ -220,7 +240,7 @@ ssim_grad_kernel(const SsimWin win, int W, int H, const float* __restrict__ x, c
     float b0[4] = { 0, 0, 0, 0 }, b1[4] = { 0, 0, 0, 0 }, b2[4] = { 0, 0, 0, 0 };
 #pragma unroll
     for (int k = 0; k < 14; k++) {
-        const float h0 = hb[0][ly + k][lx], h1 = hb[1][ly + k][lx], h2 = hb[2][ly + k][lx];
+        const float h0 = sm[0][ly + k][lx], h1 = sm[1][ly + k][lx], h2 = sm[2][ly + k][lx];
 #pragma unroll
         for (int o = 0; o < 4; o++) {
             if (k - o >= 0 && k - o <= 2 * SSIM_R) { const float w = win.g[k - o]; b0[o] += w * h0; b1[o] += w * h1; b2[o] += w * h2; }
