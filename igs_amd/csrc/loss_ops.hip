@@ -29,6 +29,23 @@
 
 struct SsimWin { float g[2 * SSIM_R + 1]; };
 
+// XCD-aware tile assignment of the image-space loss kernels.  Workgroups are dealt round-robin over the 8 XCDs (b % 8), each with its
+// own L2; a tile's halo is the interior of its neighbours, so neighbours should run on the SAME L2: XCD x takes a contiguous BAND of tile
+// rows (rows [x * rpb, (x + 1) * rpb) of every plane), row-major inside the band.  Launched as a 1-D grid of 8 * planes * rpb * gx
+// workgroups; the few that map past the last row exit at once (whole workgroups, before any barrier).  Speed only, never correctness.
+__device__ __forceinline__ bool band_tile(unsigned b, unsigned gx, unsigned gy, unsigned planes, unsigned& col, unsigned& row, unsigned& plane)
+{
+    const unsigned rpb = (gy + 7u) / 8u;
+    const unsigned xcd = b & 7u, k = b >> 3;
+    const unsigned per = rpb * gx;
+    plane = k / per;
+    const unsigned rem = k - plane * per;
+    row = xcd * rpb + rem / gx;
+    col = rem % gx;
+    return plane < planes && row < gy;
+}
+static inline unsigned band_grid(unsigned gx, unsigned gy, unsigned planes) { return 8u * planes * ((gy + 7u) / 8u) * gx; }
+
 static SsimWin make_window()
 {
     // loss_utils.py:21-24: gauss = Tensor([exp(-(x - 5)^2 / (2 * 1.5^2))]) ; gauss / gauss.sum()   (float32 tensor arithmetic)
@@ -60,8 +77,10 @@ ssim_stats_kernel(const SsimWin win, int W, int H, const float* __restrict__ x, 
     constexpr int NEXTRA = NST - 2;                       // planes with storage of their own: x x (cached) | x x, y y, x y
     __shared__ __attribute__((aligned(16))) float sx[SSIM_H][SSIM_HS], sy[SSIM_H][SSIM_HS];
     __shared__ __attribute__((aligned(16))) float hbx[NEXTRA][SSIM_H][SSIM_BS];
-    const int tid = threadIdx.x, c = blockIdx.z;
-    const int x0 = blockIdx.x * SSIM_T - SSIM_R, y0 = blockIdx.y * SSIM_T - SSIM_R;
+    unsigned bx, by, bz;
+    if (!band_tile(blockIdx.x, (unsigned)(W + SSIM_T - 1) / SSIM_T, (unsigned)(H + SSIM_T - 1) / SSIM_T, 3u, bx, by, bz)) return;
+    const int tid = threadIdx.x, c = (int)bz;
+    const int x0 = (int)bx * SSIM_T - SSIM_R, y0 = (int)by * SSIM_T - SSIM_R;
     const size_t HW = (size_t)W * H;
     const float* xc = x + c * HW; const float* yc = y + c * HW;
     {
@@ -131,7 +150,7 @@ ssim_stats_kernel(const SsimWin win, int W, int H, const float* __restrict__ x, 
     __syncthreads();
     // vertical: work item = (column lx, group of 4 output rows)
     const int lx = tid & 31, ly = (tid >> 5) * 4;
-    const int px = blockIdx.x * SSIM_T + lx;
+    const int px = (int)bx * SSIM_T + lx;
     float val = 0.f;
     float m1[4] = { 0, 0, 0, 0 }, m2[4] = { 0, 0, 0, 0 }, e1[4] = { 0, 0, 0, 0 }, e2[4] = { 0, 0, 0, 0 }, e12[4] = { 0, 0, 0, 0 };
 #pragma unroll
@@ -153,7 +172,7 @@ ssim_stats_kernel(const SsimWin win, int W, int H, const float* __restrict__ x, 
     float* ys = ystats ? ystats + (size_t)c * HW : nullptr;      // blur(y) of channel c; blur(y y) at + 3 HW
 #pragma unroll
     for (int o = 0; o < 4; o++) {
-        const int py = blockIdx.y * SSIM_T + ly + o;
+        const int py = (int)by * SSIM_T + ly + o;
         if (px < W && py < H) {
             if constexpr (GT == GT_CACHED) { m2[o] = ys[(size_t)py * W + px]; e2[o] = ys[3 * HW + (size_t)py * W + px]; }
             if constexpr (GT == GT_FILL) { ys[(size_t)py * W + px] = m2[o]; ys[3 * HW + (size_t)py * W + px] = e2[o]; }
@@ -172,7 +191,7 @@ ssim_stats_kernel(const SsimWin win, int W, int H, const float* __restrict__ x, 
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) val += __shfl_down(val, off, 64);
     if ((tid & 63) == 0 && val != 0.f)
-        atomicAdd(&ssim_sum[16 * ((blockIdx.x + blockIdx.y * gridDim.x + (tid >> 6) + 7 * c) & 63)], val);
+        atomicAdd(&ssim_sum[16 * ((blockIdx.x * 4u + (unsigned)(tid >> 6)) & 63u)], val);
 }
 
 __global__ void __launch_bounds__(256)
@@ -182,8 +201,10 @@ ssim_grad_kernel(const SsimWin win, int W, int H, const float* __restrict__ x, c
     // (in place, as ssim_stats_kernel: the horizontally blurred row replaces columns 0..31 of the halo row it was computed from, behind
     //  one extra barrier: 22 KB of LDS per workgroup instead of 40 -- six workgroups per CU instead of three)
     __shared__ __attribute__((aligned(16))) float sm[3][SSIM_H][SSIM_HS];
-    const int tid = threadIdx.x, c = blockIdx.z;
-    const int x0 = blockIdx.x * SSIM_T - SSIM_R, y0 = blockIdx.y * SSIM_T - SSIM_R;
+    unsigned bx, by, bz;
+    if (!band_tile(blockIdx.x, (unsigned)(W + SSIM_T - 1) / SSIM_T, (unsigned)(H + SSIM_T - 1) / SSIM_T, 3u, bx, by, bz)) return;
+    const int tid = threadIdx.x, c = (int)bz;
+    const int x0 = (int)bx * SSIM_T - SSIM_R, y0 = (int)by * SSIM_T - SSIM_R;
     const size_t HW = (size_t)W * H;
     const float* mc = maps + (size_t)c * 3 * HW;
     {
@@ -236,7 +257,7 @@ ssim_grad_kernel(const SsimWin win, int W, int H, const float* __restrict__ x, c
     }
     __syncthreads();
     const int lx = tid & 31, ly = (tid >> 5) * 4;
-    const int px = blockIdx.x * SSIM_T + lx;
+    const int px = (int)bx * SSIM_T + lx;
     float b0[4] = { 0, 0, 0, 0 }, b1[4] = { 0, 0, 0, 0 }, b2[4] = { 0, 0, 0, 0 };
 #pragma unroll
     for (int k = 0; k < 14; k++) {
@@ -249,7 +270,7 @@ ssim_grad_kernel(const SsimWin win, int W, int H, const float* __restrict__ x, c
     float l1 = 0.f;
 #pragma unroll
     for (int o = 0; o < 4; o++) {
-        const int py = blockIdx.y * SSIM_T + ly + o;
+        const int py = (int)by * SSIM_T + ly + o;
         if (px < W && py < H) {
             const size_t off = (size_t)c * HW + (size_t)py * W + px;
             const float xv = x[off], yv = y[off], d = xv - yv;
@@ -261,7 +282,7 @@ ssim_grad_kernel(const SsimWin win, int W, int H, const float* __restrict__ x, c
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) l1 += __shfl_down(l1, off, 64);
     if ((tid & 63) == 0 && l1 != 0.f)
-        atomicAdd(&l1_sum[16 * ((blockIdx.x + blockIdx.y * gridDim.x + (tid >> 6) + 7 * c) & 63)], l1);
+        atomicAdd(&l1_sum[16 * ((blockIdx.x * 4u + (unsigned)(tid >> 6)) & 63u)], l1);
 }
 
 // scratch = { maps [3 channels][3][H][W] | 64 SSIM-sum shards | 64 L1-sum shards } (shards 16 floats apart)
@@ -286,7 +307,7 @@ hipError_t launch_ssim_l1(hipStream_t s, int W, int H, const float* pred, const 
         const hipError_t e = zero_fill_async(s, shards, 2 * 4096);
         if (e != hipSuccess) return e;
     }
-    const dim3 grid((W + SSIM_T - 1) / SSIM_T, (H + SSIM_T - 1) / SSIM_T, 3), block(256);
+    const dim3 grid(band_grid((unsigned)(W + SSIM_T - 1) / SSIM_T, (unsigned)(H + SSIM_T - 1) / SSIM_T, 3u)), block(256);
     const float n = 3.f * (float)W * (float)H;
     if (!gt_stats) hipLaunchKernelGGL(ssim_stats_kernel<GT_INLINE>, grid, block, 0, s, win, W, H, pred, gt, maps, shards, (float*)nullptr);
     else if (!gt_stats_valid) hipLaunchKernelGGL(ssim_stats_kernel<GT_FILL>, grid, block, 0, s, win, W, H, pred, gt, maps, shards, gt_stats);
@@ -347,8 +368,10 @@ depth_normal_kernel(const DnArgs a)
     __shared__ float dep[2][20][21];
     __shared__ float rn[3][18][19];
     __shared__ float G[2][18][18][6];
+    unsigned bx, by, bz;
+    if (!band_tile(blockIdx.x, (unsigned)(a.W + 15) / 16u, (unsigned)(a.H + 15) / 16u, 1u, bx, by, bz)) return;
     const int tid = threadIdx.x;
-    const int tx0 = blockIdx.x * 16, ty0 = blockIdx.y * 16;
+    const int tx0 = (int)bx * 16, ty0 = (int)by * 16;
     const size_t HW = (size_t)a.W * a.H;
     for (int i = tid; i < 400; i += 256) {
         const int r = i / 20, c = i - r * 20;
@@ -433,7 +456,7 @@ depth_normal_kernel(const DnArgs a)
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) lsum += __shfl_down(lsum, off, 64);
-    if ((tid & 63) == 0 && lsum != 0.f) atomicAdd(&a.loss_sum[16 * ((blockIdx.x + blockIdx.y * gridDim.x + (tid >> 6)) & 63)], lsum);
+    if ((tid & 63) == 0 && lsum != 0.f) atomicAdd(&a.loss_sum[16 * ((blockIdx.x * 4u + (unsigned)(tid >> 6)) & 63u)], lsum);
 }
 
 hipError_t launch_depth_normal(hipStream_t s, int W, int H, float fx, float fy, const float* depth, const float* mdepth, const float* normal,
@@ -444,7 +467,7 @@ hipError_t launch_depth_normal(hipStream_t s, int W, int H, float fx, float fy, 
     const float n = (float)W * (float)H;
     a.s0 = weight * (1.f - depth_ratio) / n; a.s1 = weight * depth_ratio / n;
     a.g_depth = g_depth; a.g_mdepth = g_mdepth; a.g_normal = g_normal; a.loss_sum = loss_shards;
-    hipLaunchKernelGGL(depth_normal_kernel, dim3((W + 15) / 16, (H + 15) / 16), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(depth_normal_kernel, dim3(band_grid((unsigned)(W + 15) / 16u, (unsigned)(H + 15) / 16u, 1u)), dim3(256), 0, s, a);
     return hipGetLastError();
 }
 
