@@ -352,38 +352,43 @@ extern "C" int igs_ssim_l1_loss_fwd_bwd_cached(void* stream, int width, int heig
 //   points_m(p) = depth_m(p) * ray(p),  ray = ((x + 0.5 - W/2) / fx, (y + 0.5 - H/2) / fy, 1)        m = expected, median depth
 //   n_m(p) = normalize(cross(points_m(p + row) - points_m(p - row), points_m(p + col) - points_m(p - col)))   interior p, else 0
 //   loss = (1 - ratio) * mean_p(1 - rendered_normal . n_0) + ratio * mean_p(1 - rendered_normal . n_1),  ratio = 0.6
-// One workgroup per 16x16 tile: the two depth maps with a 2-pixel halo in LDS, the gradients w.r.t. the two difference
+// One workgroup per DN_T x DN_T tile (14 x 14): the two depth maps with a 2-pixel halo in LDS, the gradients w.r.t. the two difference
 // vectors of every pixel of the tile + 1 ring in LDS, then each pixel GATHERS what its four neighbours owe it:
 //   dL/dpoints(q) = ga(q - row) - ga(q + row) + gb(q - col) - gb(q + col),   dL/ddepth(q) = ray(q) . dL/dpoints(q).
 struct DnArgs {
-    int W, H; float fx, fy;
+    int W, H; float fx, fy, inv_fx, inv_fy;
     const float *depth, *mdepth, *normal;          // [H][W], [H][W], [3][H][W]
     float s0, s1;                                   // weight * lambda * (1 - ratio) / (H W), weight * lambda * ratio / (H W)
     float *g_depth, *g_mdepth, *g_normal;           // outputs
     float* loss_sum;                                // 64 shards, 16 floats apart: sum of s_m * (1 - rn . n_m)
 };
+// Tile = 14 x 14 pixels (round 4; was 16 x 16): the gradient stage works on the tile + 1 ring = 16 x 16 = exactly the 256 threads of the
+// workgroup in ONE pass (18 x 18 = 324 items took two passes of the whole body with 68 threads in the second), the ray components are
+// multiplied by 1 / fx, 1 / fy instead of divided, and the normalisation uses v_rsq_f32 (1 ulp) -- the kernel issued ~600 instructions
+// per wave for 20 bytes per pixel each way.
+#define DN_T 14
 __global__ void __launch_bounds__(256)
 depth_normal_kernel(const DnArgs a)
 {
-    __shared__ float dep[2][20][21];
-    __shared__ float rn[3][18][19];
-    __shared__ float G[2][18][18][6];
+    __shared__ float dep[2][DN_T + 4][DN_T + 5];
+    __shared__ float rn[3][DN_T + 2][DN_T + 3];
+    __shared__ float G[2][DN_T + 2][DN_T + 2][6];
     unsigned bx, by, bz;
-    if (!band_tile(blockIdx.x, (unsigned)(a.W + 15) / 16u, (unsigned)(a.H + 15) / 16u, 1u, bx, by, bz)) return;
+    if (!band_tile(blockIdx.x, (unsigned)(a.W + DN_T - 1) / DN_T, (unsigned)(a.H + DN_T - 1) / DN_T, 1u, bx, by, bz)) return;
     const int tid = threadIdx.x;
-    const int tx0 = (int)bx * 16, ty0 = (int)by * 16;
+    const int tx0 = (int)bx * DN_T, ty0 = (int)by * DN_T;
     const size_t HW = (size_t)a.W * a.H;
-    for (int i = tid; i < 400; i += 256) {
-        const int r = i / 20, c = i - r * 20;
+    for (int i = tid; i < (DN_T + 4) * (DN_T + 4); i += 256) {
+        const int r = i / (DN_T + 4), c = i - r * (DN_T + 4);
         const int gx = tx0 - 2 + c, gy = ty0 - 2 + r;
         const bool in = gx >= 0 && gx < a.W && gy >= 0 && gy < a.H;
         const size_t o = in ? (size_t)gy * a.W + gx : 0;
         const float d0 = a.depth[o], d1 = a.mdepth[o];
         dep[0][r][c] = in ? d0 : 0.f; dep[1][r][c] = in ? d1 : 0.f;
     }
-    for (int i = tid; i < 324; i += 256) {
-        const int r = i / 18, c = i - r * 18;
-        const int gx = tx0 - 1 + c, gy = ty0 - 1 + r;
+    const int r = tid >> 4, c = tid & 15;                      // this thread's pixel of the tile + 1 ring: (ty0 - 1 + r, tx0 - 1 + c)
+    const int gx = tx0 - 1 + c, gy = ty0 - 1 + r;
+    {
         const bool in = gx >= 0 && gx < a.W && gy >= 0 && gy < a.H;
         const size_t o = in ? (size_t)gy * a.W + gx : 0;
         const float n0 = a.normal[o], n1 = a.normal[HW + o], n2 = a.normal[2 * HW + o];
@@ -391,14 +396,13 @@ depth_normal_kernel(const DnArgs a)
     }
     __syncthreads();
     float lsum = 0.f;
-    for (int i = tid; i < 324; i += 256) {
-        const int r = i / 18, c = i - r * 18;                  // p = (ty0 - 1 + r, tx0 - 1 + c); dep index = (r + 1, c + 1)
-        const int gx = tx0 - 1 + c, gy = ty0 - 1 + r;
+    {
         const bool interior = gx >= 1 && gx <= a.W - 2 && gy >= 1 && gy <= a.H - 2;
-        const bool mine = r >= 1 && r <= 16 && c >= 1 && c <= 16 && gx < a.W && gy < a.H;      // p belongs to this tile
-        const float rxm = ((float)gx + 0.5f - a.W * 0.5f) / a.fx, rym = ((float)gy + 0.5f - a.H * 0.5f) / a.fy;
-        const float rxl = ((float)(gx - 1) + 0.5f - a.W * 0.5f) / a.fx, rxr = ((float)(gx + 1) + 0.5f - a.W * 0.5f) / a.fx;
-        const float ryu = ((float)(gy - 1) + 0.5f - a.H * 0.5f) / a.fy, ryd = ((float)(gy + 1) + 0.5f - a.H * 0.5f) / a.fy;
+        const bool mine = r >= 1 && r <= DN_T && c >= 1 && c <= DN_T && gx < a.W && gy < a.H;      // p belongs to this tile
+        const float cx = 0.5f - a.W * 0.5f, cy = 0.5f - a.H * 0.5f;
+        const float rxm = ((float)gx + cx) * a.inv_fx, rym = ((float)gy + cy) * a.inv_fy;
+        const float rxl = ((float)(gx - 1) + cx) * a.inv_fx, rxr = ((float)(gx + 1) + cx) * a.inv_fx;
+        const float ryu = ((float)(gy - 1) + cy) * a.inv_fy, ryd = ((float)(gy + 1) + cy) * a.inv_fy;
         const float q0 = rn[0][r][c], q1 = rn[1][r][c], q2 = rn[2][r][c];
         float gn0 = 0.f, gn1 = 0.f, gn2 = 0.f;
 #pragma unroll
@@ -410,20 +414,21 @@ depth_normal_kernel(const DnArgs a)
                 const float dd = dep[m][r + 2][c + 1], du = dep[m][r][c + 1], dr = dep[m][r + 1][c + 2], dl = dep[m][r + 1][c];
                 // dx = P(row + 1) - P(row - 1), dy = P(col + 1) - P(col - 1)
                 const float ax = (dd - du) * rxm, ay = dd * ryd - du * ryu, az = dd - du;
-                const float bx = dr * rxr - dl * rxl, by = (dr - dl) * rym, bz = dr - dl;
-                const float c0 = ay * bz - az * by, c1 = az * bx - ax * bz, c2 = ax * by - ay * bx;
-                const float len = sqrtf(c0 * c0 + c1 * c1 + c2 * c2);
-                const float inv = 1.0f / fmaxf(len, 1e-12f);                     // F.normalize eps
+                const float bx_ = dr * rxr - dl * rxl, by_ = (dr - dl) * rym, bz_ = dr - dl;
+                const float c0 = ay * bz_ - az * by_, c1 = az * bx_ - ax * bz_, c2 = ax * by_ - ay * bx_;
+                const float len2 = c0 * c0 + c1 * c1 + c2 * c2;
+                const bool tiny = !(len2 > 1e-24f);                                  // len <= 1e-12: F.normalize divides by its eps
+                const float inv = tiny ? 1e12f : __builtin_amdgcn_rsqf(len2);
                 const float n0 = c0 * inv, n1 = c1 * inv, n2 = c2 * inv;
                 dotn = q0 * n0 + q1 * n1 + q2 * n2;
                 if (mine) { gn0 -= s * n0; gn1 -= s * n1; gn2 -= s * n2; }
                 // backward of normalize (for len > eps) and of the cross product; dL/dn = -s * rendered_normal
                 const float h0 = -s * q0, h1 = -s * q1, h2 = -s * q2;
                 const float hn = h0 * n0 + h1 * n1 + h2 * n2;
-                const float k = len > 1e-12f ? inv : 0.f;
+                const float k = tiny ? 0.f : inv;
                 const float e0 = (h0 - n0 * hn) * k, e1 = (h1 - n1 * hn) * k, e2 = (h2 - n2 * hn) * k;
-                ga0 = by * e2 - bz * e1; ga1 = bz * e0 - bx * e2; ga2 = bx * e1 - by * e0;        // b x e
-                gb0 = e1 * az - e2 * ay; gb1 = e2 * ax - e0 * az; gb2 = e0 * ay - e1 * ax;        // e x a
+                ga0 = by_ * e2 - bz_ * e1; ga1 = bz_ * e0 - bx_ * e2; ga2 = bx_ * e1 - by_ * e0;        // b x e
+                gb0 = e1 * az - e2 * ay; gb1 = e2 * ax - e0 * az; gb2 = e0 * ay - e1 * ax;              // e x a
             }
             g[0] = ga0; g[1] = ga1; g[2] = ga2; g[3] = gb0; g[4] = gb1; g[5] = gb2;
             if (mine) lsum += s * (1.0f - dotn);
@@ -434,23 +439,23 @@ depth_normal_kernel(const DnArgs a)
         }
     }
     __syncthreads();
-    {
-        const int lx = tid & 15, ly = tid >> 4;
-        const int gx = tx0 + lx, gy = ty0 + ly;
-        if (gx < a.W && gy < a.H) {
-            const int r = ly + 1, c = lx + 1;                    // q in the 18x18 array
-            const float rx = ((float)gx + 0.5f - a.W * 0.5f) / a.fx, ry = ((float)gy + 0.5f - a.H * 0.5f) / a.fy;
+    if (tid < DN_T * DN_T) {
+        const int ly = tid / DN_T, lx = tid - ly * DN_T;
+        const int qx = tx0 + lx, qy = ty0 + ly;
+        if (qx < a.W && qy < a.H) {
+            const int rr = ly + 1, cc = lx + 1;                  // q in the (DN_T + 2)^2 array
+            const float rx = ((float)qx + 0.5f - a.W * 0.5f) * a.inv_fx, ry = ((float)qy + 0.5f - a.H * 0.5f) * a.inv_fy;
             float out[2];
 #pragma unroll
             for (int m = 0; m < 2; m++) {
-                const float* up = G[m][r - 1][c]; const float* dn = G[m][r + 1][c];
-                const float* lf = G[m][r][c - 1]; const float* rt = G[m][r][c + 1];
+                const float* up = G[m][rr - 1][cc]; const float* dn = G[m][rr + 1][cc];
+                const float* lf = G[m][rr][cc - 1]; const float* rt = G[m][rr][cc + 1];
                 const float p0 = up[0] - dn[0] + lf[3] - rt[3];
                 const float p1 = up[1] - dn[1] + lf[4] - rt[4];
                 const float p2 = up[2] - dn[2] + lf[5] - rt[5];
                 out[m] = rx * p0 + ry * p1 + p2;
             }
-            const size_t o = (size_t)gy * a.W + gx;
+            const size_t o = (size_t)qy * a.W + qx;
             a.g_depth[o] = out[0]; a.g_mdepth[o] = out[1];
         }
     }
@@ -463,11 +468,11 @@ hipError_t launch_depth_normal(hipStream_t s, int W, int H, float fx, float fy, 
                                float weight, float depth_ratio, float* g_depth, float* g_mdepth, float* g_normal, float* loss_shards)
 {
     DnArgs a;
-    a.W = W; a.H = H; a.fx = fx; a.fy = fy; a.depth = depth; a.mdepth = mdepth; a.normal = normal;
+    a.W = W; a.H = H; a.fx = fx; a.fy = fy; a.inv_fx = 1.0f / fx; a.inv_fy = 1.0f / fy; a.depth = depth; a.mdepth = mdepth; a.normal = normal;
     const float n = (float)W * (float)H;
     a.s0 = weight * (1.f - depth_ratio) / n; a.s1 = weight * depth_ratio / n;
     a.g_depth = g_depth; a.g_mdepth = g_mdepth; a.g_normal = g_normal; a.loss_sum = loss_shards;
-    hipLaunchKernelGGL(depth_normal_kernel, dim3(band_grid((unsigned)(W + 15) / 16u, (unsigned)(H + 15) / 16u, 1u)), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(depth_normal_kernel, dim3(band_grid((unsigned)(W + DN_T - 1) / DN_T, (unsigned)(H + DN_T - 1) / DN_T, 1u)), dim3(256), 0, s, a);
     return hipGetLastError();
 }
 
