@@ -62,8 +62,13 @@ static SsimWin make_window()
 //   GT_CACHED  read them from `ystats` (3 blurs: x, x x, x y; two fifths of the multiply-adds of both passes and 12 KB of LDS less,
 //              4 workgroups per CU instead of 3).  The stored values are the ones GT_INLINE computes (same code, same order).
 enum { GT_INLINE = 0, GT_FILL = 1, GT_CACHED = 2 };
+#ifdef SSIM_WPE
+#define SSIM_WPE_ATTR __attribute__((amdgpu_waves_per_eu(SSIM_WPE)))
+#else
+#define SSIM_WPE_ATTR
+#endif
 template <int GT>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256) SSIM_WPE_ATTR
 ssim_stats_kernel(const SsimWin win, int W, int H, const float* __restrict__ x, const float* __restrict__ y,
                   float* __restrict__ maps, float* __restrict__ ssim_sum, float* __restrict__ ystats)
 {
