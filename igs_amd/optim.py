@@ -23,38 +23,63 @@ class Adam(torch.optim.Optimizer):
         if lr < 0.0 or eps < 0.0 or not (0.0 <= betas[0] < 1.0) or not (0.0 <= betas[1] < 1.0):
             raise ValueError("igs_amd.optim.Adam: invalid hyper-parameter")
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
+        self._ext = _cabi.ext()
+        # torch.optim.Optimizer wraps the class's `step` in a profiler / hook trampoline that costs ~35 us of host time per call -- more than
+        # the launch it guards, in a loop whose iteration is bound by host time (tools/profile_dropin_loop_host.py).  Instances call the
+        # plain method unless somebody has registered step hooks.
+        self._wrapped_step = super(Adam, self).__getattribute__("step")
+        self.step = self._step_dispatch
+
+    def _step_dispatch(self, closure=None):
+        if self._optimizer_step_pre_hooks or self._optimizer_step_post_hooks:
+            return self._wrapped_step(closure)
+        return self._step_impl(closure)
+
+    def zero_grad(self, set_to_none=True):
+        """torch.optim.Optimizer.zero_grad without its per-call bookkeeping (profiler range, foreach grouping): ~2 us instead of ~20."""
+        for group in self.param_groups:
+            for p in group["params"]:
+                if p.grad is not None:
+                    if set_to_none:
+                        p.grad = None
+                    else:
+                        p.grad.detach_().zero_()
+
+    def step(self, closure=None):
+        return self._step_impl(closure)
 
     @torch.no_grad()
-    def step(self, closure=None):
+    def _step_impl(self, closure=None):
         loss = None
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
-        Cx = _cabi.ext()
+        Cx = self._ext
         # batches of up to 8 tensors that share (device, betas, eps): one launch each
         batches = {}
         for group in self.param_groups:
             b1, b2 = group["betas"]
+            lr, eps = group["lr"], group["eps"]
             for p in group["params"]:
-                if p.grad is None:
+                g = p.grad
+                if g is None:
                     continue
-                if not p.is_cuda or p.dtype != torch.float32 or p.grad.is_sparse:
-                    raise RuntimeError("igs_amd.optim.Adam: parameters must be dense float32 GPU tensors (no CPU fallback)")
                 st = self.state[p]
                 if len(st) == 0:
+                    if not p.is_cuda or p.dtype != torch.float32 or g.is_sparse or not p.is_contiguous():
+                        raise RuntimeError("igs_amd.optim.Adam: parameters must be dense, contiguous float32 GPU tensors (no CPU fallback)")
                     st["step"] = 0
                     st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                     st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
-                st["step"] = int(st["step"]) + 1
-                t = st["step"]
-                g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
-                if not (p.is_contiguous() and st["exp_avg"].is_contiguous() and st["exp_avg_sq"].is_contiguous()):
-                    raise RuntimeError("igs_amd.optim.Adam: parameters and their state must be contiguous")
-                batches.setdefault((p.device, b1, b2, group["eps"]), []).append(
-                    (p, g, st["exp_avg"], st["exp_avg_sq"], group["lr"], 1.0 - b1 ** t, math.sqrt(1.0 - b2 ** t)))
-        for (dev, b1, b2, eps), items in batches.items():
-            for i in range(0, len(items), 8):
-                chunk = items[i:i + 8]
-                col = lambda j: [c[j] for c in chunk]
-                Cx.adam_step_multi(col(0), col(1), col(2), col(3), col(4), col(5), col(6), b1, b2, eps)
+                t = st["step"] = int(st["step"]) + 1
+                key = (p.device, b1, b2, eps)
+                b = batches.get(key)
+                if b is None:
+                    b = batches[key] = ([], [], [], [], [], [], [])
+                b[0].append(p); b[1].append(g); b[2].append(st["exp_avg"]); b[3].append(st["exp_avg_sq"])
+                b[4].append(lr); b[5].append(1.0 - b1 ** t); b[6].append(math.sqrt(1.0 - b2 ** t))
+        for (dev, b1, b2, eps), b in batches.items():
+            for i in range(0, len(b[0]), 8):
+                Cx.adam_step_multi(b[0][i:i + 8], b[1][i:i + 8], b[2][i:i + 8], b[3][i:i + 8], b[4][i:i + 8], b[5][i:i + 8], b[6][i:i + 8],
+                                   b1, b2, eps)
         return loss
