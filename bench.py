@@ -481,9 +481,14 @@ def main():
                         torch.cuda.synchronize()
                         return 1000.0 * (time.perf_counter() - t) / n_steps
                     n_d = args.dropin_steps
-                    d = {"l1_ms": dropin("l1", "fused", 0, n_d), "nan_checks_ms": dropin("l1", "fused", 1, n_d),
-                         "l1_ssim_ms": dropin("l1_ssim", "fused", 0, n_d), "l1_ssim_nan_checks_ms": dropin("l1_ssim", "fused", 1, n_d),
-                         "l1_torch_adam_ms": dropin("l1", "torch", 1, max(20, n_d // 3)), "steps": n_d}
+                    # host-bound timing is noisy (the first variant of a process runs 10-20 % slower than the same variant later): two
+                    # interleaved passes over the variants, the faster of the two is reported, both are kept
+                    variants = (("l1_ms", "l1", "fused", 0, n_d), ("nan_checks_ms", "l1", "fused", 1, n_d), ("l1_ssim_ms", "l1_ssim", "fused", 0, n_d),
+                                ("l1_ssim_nan_checks_ms", "l1_ssim", "fused", 1, n_d), ("l1_torch_adam_ms", "l1", "torch", 1, max(20, n_d // 3)))
+                    passes = [{k: dropin(ls, opt, nan, n) for k, ls, opt, nan, n in variants} for _ in range(2)]
+                    d = {k: min(passes[0][k], passes[1][k]) for k in passes[0]}
+                    d["steps"] = n_d
+                    d["both_passes"] = passes
                     d["note"] = ("one refine iteration driven exactly as infer_batch.py:279-324 drives the reference's package (tools/dropin_loop.py), through "
                                  "the compiled `_C` module; `igs_amd.losses` for l1_loss / ssim (one import line) and, except in l1_torch_adam_ms, "
                                  "`igs_amd.optim.Adam` for torch.optim.Adam (one constructor); nan_checks = the reference's NaN asserts on "
