@@ -567,12 +567,16 @@ static int g_last_bwd_instance = -1;
 extern "C" int igs_rast_last_backward_instance(void) { return __atomic_load_n(&g_last_bwd_instance, __ATOMIC_RELAXED); }
 
 // NaN report of the per-Gaussian backward kernel (replaces the reference's seven `assert not torch.isnan(g).any()` host syncs,
-// DGR/diff_gaussian_rasterization_rade/__init__.py:156-162, by one word the kernel posts into pinned host memory)
-// (2 KB of pinned memory per host thread and device, never freed: the thread that runs autograd backward functions may outlive the HIP runtime)
-struct NanSlot { uint32_t* pinned = nullptr; uint32_t* pinned_dev = nullptr; uint32_t seq = 0; bool requested = false; bool pending = false; hipStream_t stream = nullptr; };
-static thread_local float g_next_clamp = 0.f;     // one-shot: clamp of the NEXT igs_rast_backward of this thread (clamp package)
+// DGR/diff_gaussian_rasterization_rade/__init__.py:156-162): a thread that writes a NaN stores the report's sequence number into a word
+// of pinned host memory; an event recorded behind the kernel tells the host when the word is final.  One TICKET per report, a ring of
+// NAN_RING per host thread and device (two renders in one backward pass, ...): memory and events are never freed -- the thread that
+// runs autograd backward functions may outlive the HIP runtime.
+#define NAN_RING 256
+struct NanTicket { volatile uint32_t* word = nullptr; hipEvent_t ev = nullptr; uint32_t seq = 0; };
+struct NanSlot { uint32_t* pinned = nullptr; uint32_t* pinned_dev = nullptr; NanTicket* tickets = nullptr; uint32_t seq = 0; bool requested = false; bool pending = false; };
 static thread_local NanSlot g_nan[IGS_MAX_DEVICES];
 static thread_local int g_nan_dev = -1;          // device of the last backward that was asked for a report
+static thread_local float g_next_clamp = 0.f;     // one-shot: clamp of the NEXT igs_rast_backward of this thread (clamp package)
 extern "C" void igs_rast_next_backward_options(int nan_report, float clamp_grads)
 {
     g_next_clamp = clamp_grads > 0.f ? clamp_grads : 0.f;
@@ -580,24 +584,19 @@ extern "C" void igs_rast_next_backward_options(int nan_report, float clamp_grads
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= IGS_MAX_DEVICES) return;
     g_nan[dev].requested = nan_report != 0;
 }
-#define NAN_RING 256          // verdict words of the last NAN_RING reports of a thread stay readable (two renders in one backward pass, ...)
-static int nan_wait_at(const volatile uint32_t* word, uint32_t seq, hipStream_t stream, bool have_stream)
+static int nan_wait_ticket(const NanTicket* t, uint32_t seq)
 {
+    if (!t || !t->ev) return fail(IGS_RAST_E_INVALID, "NaN report: bad ticket");
     double t0 = 0.0;
     for (long spins = 0;; spins++) {
-        const uint32_t got = __atomic_load_n(word + 1, __ATOMIC_ACQUIRE);
-        if (got == seq) return word[0] ? 1 : 0;
-        if ((spins & 0x3FFF) == 0x3FFF) {
-            if (got != seq && got - seq < 0x80000000u && got - seq >= NAN_RING && ((got - seq) % NAN_RING) == 0)
-                return fail(IGS_RAST_E_INVALID, "the NaN report was overwritten by a later one before it was read");
-            if (have_stream) {
-                const hipError_t q = hipStreamQuery(stream);
-                if (q != hipSuccess && q != hipErrorNotReady) return fail(IGS_RAST_E_HIP, "stream error while waiting for the NaN report", q);
-                if (q == hipSuccess && __atomic_load_n(word + 1, __ATOMIC_ACQUIRE) != seq) return fail(IGS_RAST_E_HIP, "the NaN report was never posted");
-            }
-            const double t = now_s();
-            if (t0 == 0.0) t0 = t;
-            else if (t - t0 > wait_limit_s()) return fail(IGS_RAST_E_HIP, "timed out waiting for the NaN report (IGS_RAST_WAIT_TIMEOUT_S)");
+        if (t->seq != seq) return fail(IGS_RAST_E_INVALID, "the NaN report was overwritten by a later one before it was read");
+        const hipError_t q = hipEventQuery(t->ev);
+        if (q == hipSuccess) return (__atomic_load_n(t->word, __ATOMIC_ACQUIRE) == seq) ? 1 : 0;
+        if (q != hipErrorNotReady) return fail(IGS_RAST_E_HIP, "error while waiting for the NaN report", q);
+        if ((spins & 0xFF) == 0xFF) {
+            const double now = now_s();
+            if (t0 == 0.0) t0 = now;
+            else if (now - t0 > wait_limit_s()) return fail(IGS_RAST_E_HIP, "timed out waiting for the NaN report (IGS_RAST_WAIT_TIMEOUT_S)");
         }
     }
 }
@@ -606,20 +605,20 @@ extern "C" int igs_rast_nan_report_wait(void)
     if (g_nan_dev < 0 || !g_nan[g_nan_dev].pending) return fail(IGS_RAST_E_INVALID, "igs_rast_nan_report_wait: no backward with a NaN report pending on this thread");
     NanSlot& n = g_nan[g_nan_dev];
     n.pending = false;
-    return nan_wait_at(n.pinned + 2 * (n.seq % NAN_RING), n.seq, n.stream, true);
+    return nan_wait_ticket(&n.tickets[n.seq % NAN_RING], n.seq);
 }
-extern "C" int igs_rast_nan_report_handle(const void** word, unsigned* seq)
+extern "C" int igs_rast_nan_report_handle(const void** ticket, unsigned* seq)
 {
-    if (g_nan_dev < 0 || !g_nan[g_nan_dev].pending || !word || !seq) return fail(IGS_RAST_E_INVALID, "igs_rast_nan_report_handle: no backward with a NaN report pending on this thread");
+    if (g_nan_dev < 0 || !g_nan[g_nan_dev].pending || !ticket || !seq) return fail(IGS_RAST_E_INVALID, "igs_rast_nan_report_handle: no backward with a NaN report pending on this thread");
     NanSlot& n = g_nan[g_nan_dev];
     n.pending = false;
-    *word = n.pinned + 2 * (n.seq % NAN_RING); *seq = n.seq;
+    *ticket = &n.tickets[n.seq % NAN_RING]; *seq = n.seq;
     return 0;
 }
-extern "C" int igs_rast_nan_report_wait_at(const void* word, unsigned seq)
+extern "C" int igs_rast_nan_report_wait_at(const void* ticket, unsigned seq)
 {
-    if (!word) return fail(IGS_RAST_E_INVALID, "igs_rast_nan_report_wait_at: NULL handle");
-    return nan_wait_at((const volatile uint32_t*)word, seq, nullptr, false);
+    if (!ticket) return fail(IGS_RAST_E_INVALID, "igs_rast_nan_report_wait_at: NULL handle");
+    return nan_wait_ticket((const NanTicket*)ticket, seq);
 }
 
 // l1_gt != NULL: L1 loss fused into the blend backward (dL_dpix ignored); fuse != NULL: activation backward + Adam fused into
@@ -671,21 +670,21 @@ static int backward_impl(
             g_nan[dev].requested = false;
             NanSlot& n = g_nan[dev];
             if (!n.pinned) {
-                HIP_TRY(hipHostMalloc((void**)&n.pinned, NAN_RING * 8, hipHostMallocDefault), "hipHostMalloc");
+                HIP_TRY(hipHostMalloc((void**)&n.pinned, NAN_RING * 4, hipHostMallocDefault), "hipHostMalloc");
                 HIP_TRY(hipHostGetDevicePointer((void**)&n.pinned_dev, n.pinned, 0), "hipHostGetDevicePointer");
-                memset(n.pinned, 0, NAN_RING * 8);
+                memset(n.pinned, 0, NAN_RING * 4);
+                n.tickets = new NanTicket[NAN_RING];
             }
             nan = &n; g_nan_dev = dev;
         }
     }
     prof_mark(s, ST_GAP);
     float* loss_shards = (float*)((char*)gacc + ws_gacc_bytes(P));
-    uint32_t* nan_words = (uint32_t*)((char*)loss_shards + WS_LOSS_BYTES);      // {flag, workgroups done}: inside the workspace's spare tail
     // which blend instance will run (launch_blend_bwd decides the same way): the colour-only one packs its moments into 64-byte rows
     const bool will_compact = !(require_coord && (dL_dpix_coord || dL_dpix_mcoord)) && !(require_depth && (dL_dpix_depth || dL_dpix_mdepth))
                               && !((require_coord || require_depth) && dL_dpixel_normals);
     if (!(fuse && fuse->prezeroed)) {              // (igs_refine_step: the forward's preprocess kernel zero-filled the accumulators)
-        HIP_TRY(zero_fill_async(s, gacc, (size_t)P * (will_compact ? GACC_COMPACT_F : GACC_F) * 4, nan ? nan_words : nullptr, nan ? 2 : 0), "zero gacc");
+        HIP_TRY(zero_fill_async(s, gacc, (size_t)P * (will_compact ? GACC_COMPACT_F : GACC_F) * 4), "zero gacc");
         if (l1_gt) HIP_TRY(zero_fill_async(s, loss_shards, WS_LOSS_BYTES), "zero loss shards");
     }
     prof_mark(s, ST_MEMSET);
@@ -737,12 +736,16 @@ static int backward_impl(
         HIP_TRY(launch_geom_bwd_adam(s, ga, f), "geom_bwd_adam launch");
     } else {
         ga.clamp = clamp_next;
+        NanTicket* ticket = nullptr;
         if (nan) {
             nan->seq = nan->seq + 1 ? nan->seq + 1 : 1;
-            ga.nan_dev = nan_words; ga.nan_host = nan->pinned_dev + 2 * (nan->seq % NAN_RING); ga.nan_seq = nan->seq;
-            nan->stream = s; nan->pending = true;
+            ticket = &nan->tickets[nan->seq % NAN_RING];
+            if (!ticket->ev) HIP_TRY(hipEventCreateWithFlags(&ticket->ev, hipEventDisableTiming), "hipEventCreate");
+            ticket->word = nan->pinned + (nan->seq % NAN_RING); ticket->seq = nan->seq;
+            ga.nan_host = nan->pinned_dev + (nan->seq % NAN_RING); ga.nan_seq = nan->seq;
         }
         HIP_TRY(launch_geom_bwd(s, ga), "geom_bwd launch");
+        if (ticket) { HIP_TRY(hipEventRecord(ticket->ev, s), "record NaN-report event"); nan->pending = true; }
     }
     DBG_SYNC("geom_bwd");
     prof_mark(s, ST_GEOM_BWD);

@@ -188,9 +188,9 @@ struct GeomBwdArgs {
     const float* rec; const float* gacc;
     int gacc_compact;                       // gacc rows hold {colour 3, Q0, Qx, Qy, Qxx, Qxy, Qyy, Z} in slots 0..9 (colour-only blend instance)
     float *dL_dmean2D, *dL_dcolor, *dL_dopacity, *dL_dmean3D, *dL_dcov3D, *dL_dsh, *dL_dscale, *dL_drot;
-    // NaN report (igs_rast_request_nan_report): nan_dev = {flag, workgroups done} in device memory, both zero at launch and left zero;
-    // the last workgroup posts {flag, nan_seq} into nan_host (pinned host memory).  NULL = no report.
-    uint32_t* nan_dev = nullptr; uint32_t* nan_host = nullptr; uint32_t nan_seq = 0;
+    // NaN report (igs_rast_next_backward_options): a thread that writes a NaN stores nan_seq into *nan_host (pinned host memory, device
+    // address); the host looks at the word after an event recorded behind the kernel.  NULL = no report.
+    uint32_t* nan_host = nullptr; uint32_t nan_seq = 0;
     float clamp = 0.f;          // > 0 (unfused kernel): dL/d(means3D, sh, opacity, scale, rotation) clamped to +-clamp as they are written (clamp package)
 };
 hipError_t launch_geom_bwd(hipStream_t s, const GeomBwdArgs& a);

@@ -227,8 +227,8 @@ int igs_rast_debug_dump(void* stream, int P, int R, int width, int height,
  *  nan_report != 0: the reference's Python backward ends with seven `assert not torch.isnan(grad).any()` -- seven reductions and host
  *   syncs (DGR/diff_gaussian_rasterization_rade/__init__.py:156-162).  The per-Gaussian kernel instead tests every element it writes of
  *   dL_dmean2D, dL_dcolor, dL_dopacity, dL_dmean3D, dL_dsh, dL_dscale, dL_drot (not dL_dcov3D: the reference does not look at it either)
- *   and posts one word into pinned host memory; igs_rast_nan_report_wait() blocks until that word has arrived and returns 1 (a NaN was
- *   written), 0 (none) or a negative error code.  Bounded like the forward's status wait (IGS_RAST_WAIT_TIMEOUT_S).
+ *   and, if it wrote a NaN, says so in one word of pinned host memory; an event is recorded behind the kernel.  igs_rast_nan_report_wait()
+ *   blocks until that event has completed and returns 1 (a NaN was written), 0 (none) or a negative error code.  Bounded like the forward's status wait (IGS_RAST_WAIT_TIMEOUT_S).
  *  clamp_grads > 0: dL_dmean3D, dL_dsh, dL_dopacity, dL_dscale, dL_drot are clamped to +-clamp_grads as they are written (what the clamp
  *   package does with five torch.clamp calls afterwards, DGRC/diff_gaussian_rasterization_rade_clamp/__init__.py:156-162); a NaN stays
  *   a NaN for the report, as it does through torch.clamp. */
@@ -236,11 +236,11 @@ void igs_rast_next_backward_options(int nan_report, float clamp_grads);
 int igs_rast_nan_report_wait(void);
 /* The same wait from ANOTHER host thread or at a later time (PyTorch runs a Function's backward on its own worker thread and the
  * assert is better raised once the whole backward pass has been enqueued): right after the igs_rast_backward that was asked for a report,
- * on the thread that called it, igs_rast_nan_report_handle() returns where the verdict will appear (pinned host memory that stays valid
- * for the life of the process; the last 256 reports of a thread stay readable) and its sequence number, instead of waiting;
+ * on the thread that called it, igs_rast_nan_report_handle() returns a ticket for the verdict (valid for the life of the process; the
+ * last 256 reports of a thread stay readable) and its sequence number, instead of waiting;
  * igs_rast_nan_report_wait_at(word, seq) then blocks (bounded by IGS_RAST_WAIT_TIMEOUT_S) and returns 1 / 0 / a negative code. */
-int igs_rast_nan_report_handle(const void** word, unsigned* seq);
-int igs_rast_nan_report_wait_at(const void* word, unsigned seq);
+int igs_rast_nan_report_handle(const void** ticket, unsigned* seq);
+int igs_rast_nan_report_wait_at(const void* ticket, unsigned seq);
 int igs_rast_last_backward_instance(void);
 /* Test hook: overwrites the LDS of every CU with NaN bit patterns (a kernel that reads LDS it never wrote then fails small parity
  * tests instead of passing on a fresh device's zeros). */
