@@ -837,10 +837,12 @@ def main():
                     gt_np = gt_test.cpu().numpy().astype(np.float64)
                     out["psnr"]["vs_oracle_image"] = -10.0 * math.log10(max(mse, 1e-30))
                     out["psnr"]["oracle_image_vs_target"] = -10.0 * math.log10(max(float(np.mean((np.clip(o_img["color"], 0, 1) - gt_np) ** 2)), 1e-30))
+                    out["psnr"]["hip_image_vs_target_same_parameters"] = -10.0 * math.log10(max(float(np.mean((np.clip(hip_img, 0, 1) - gt_np) ** 2)), 1e-30))
                     out["psnr"]["max_abs_vs_oracle_image"] = float(np.abs(hip_img - o_img["color"]).max())
                     out["psnr"]["vs_oracle_note"] = ("held-out camera of the refined parameters: HIP image against the scalar C oracle's image of the same "
-                                                     "parameters (%.1f s on one core); oracle_image_vs_target = the oracle's image against the target, to be "
-                                                     "compared with `after`" % (time.time() - t_o))
+                                                     "parameters (%.1f s on one core), at the END of the run (the profiled pass and the side legs have refined "
+                                                     "the parameters further since `after` was taken); oracle_image_vs_target and "
+                                                     "hip_image_vs_target_same_parameters are the two renderers against the target at those same parameters" % (time.time() - t_o))
                 except Exception as e:  # noqa: BLE001
                     out["psnr"]["vs_oracle_image"] = None
                     out["psnr"]["vs_oracle_note"] = "failed: %s: %s" % (type(e).__name__, e)
