@@ -1,5 +1,5 @@
 """Times the UNCHANGED caller loop (tools/dropin_loop.py = infer_batch.py:279-324) on the bench scene, per variant.
-usage: python tools/dropin_bench.py [steps] [variant ...]      variant = <loss>:<optimizer>:<nan 0|1>[:<losses igs|torch>]"""
+usage: python tools/dropin_bench.py [steps] [variant ...]      variant = <loss>:<optimizer>:<nan 0|1>[:<losses igs|torch>[:<flags: fa (fused activations), np (no PSNR line)>]]"""
 import json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -19,16 +19,18 @@ def setup(dev, P=200000):
     return raw, cams, bg, gts
 
 
-def run_variant(raw, cams, bg, gts, dev, loss, optimizer, nan, losses="igs", steps=100, warm=20):
+def run_variant(raw, cams, bg, gts, dev, loss, optimizer, nan, losses="igs", steps=100, warm=20, flags=""):
+    """flags: "fa" = the caller uses igs_amd.activations.activate in its three activation properties, "np" = no per-iteration PSNR line."""
     rasterizer.NAN_CHECKS = bool(nan)
-    gs = CallerModel(raw, dev, DEFAULT_LRS, optimizer=optimizer)
+    gs = CallerModel(raw, dev, DEFAULT_LRS, optimizer=optimizer, fused_activations="fa" in flags)
     lf = make_losses(losses)
+    kw = dict(loss=loss, losses=lf, psnr_line="np" not in flags)
     for i in range(warm):
-        refine_iteration(gs, cams[i % len(cams)], gts[i % len(cams)], bg, loss=loss, losses=lf)
+        refine_iteration(gs, cams[i % len(cams)], gts[i % len(cams)], bg, **kw)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(steps):
-        refine_iteration(gs, cams[i % len(cams)], gts[i % len(cams)], bg, loss=loss, losses=lf)
+        refine_iteration(gs, cams[i % len(cams)], gts[i % len(cams)], bg, **kw)
     torch.cuda.synchronize()
     return 1000 * (time.perf_counter() - t0) / steps
 
@@ -41,7 +43,8 @@ def main():
     out = {}
     for v in variants:
         f = v.split(":")
-        out[v] = round(run_variant(raw, cams, bg, gts, dev, f[0], f[1], int(f[2]), f[3] if len(f) > 3 else "igs", steps=steps), 4)
+        out[v] = round(run_variant(raw, cams, bg, gts, dev, f[0], f[1], int(f[2]), f[3] if len(f) > 3 else "igs", steps=steps,
+                                   flags=f[4] if len(f) > 4 else ""), 4)
         print(v, out[v], flush=True)
     print(json.dumps(out))
 

@@ -26,7 +26,8 @@ import torch.nn as nn
 class CallerModel:
     """Refine-time parameter container in the shape of `GaussianModel.load_fromstream` (gaussian_model.py:265-348)."""
 
-    def __init__(self, raw, device, lrs, optimizer="torch"):
+    def __init__(self, raw, device, lrs, optimizer="torch", fused_activations=False):
+        self.fused_activations = fused_activations      # a caller who changes the three activation properties to igs_amd.activations.activate
         mk = lambda t: nn.Parameter(t.detach().clone().to(device).contiguous().requires_grad_(True))
         self._xyz, self._shs = mk(raw["xyz"]), mk(raw["shs"])
         self._opacity, self._scaling, self._rotation = mk(raw["opacity"]), mk(raw["scaling"]), mk(raw["rotation"])
@@ -45,9 +46,20 @@ class CallerModel:
 
     get_xyz = property(lambda self: self._xyz)
     get_features = property(lambda self: self._shs)
-    get_opacity = property(lambda self: torch.sigmoid(self._opacity))
-    get_scaling = property(lambda self: torch.exp(self._scaling))
-    get_rotation = property(lambda self: torch.nn.functional.normalize(self._rotation))
+    def _act(self, i):
+        if not self.fused_activations:
+            return (torch.sigmoid(self._opacity), torch.exp(self._scaling), torch.nn.functional.normalize(self._rotation))[i]
+        cur = getattr(self, "_act_cache", None)          # one fused launch serves the three getters of an iteration
+        key = (self._opacity._version, self._scaling._version, self._rotation._version)
+        if cur is None or cur[0] != key or cur[2] >= 3:
+            from igs_amd.activations import activate
+            cur = self._act_cache = [key, activate(self._opacity, self._scaling, self._rotation), 0]
+        cur[2] += 1
+        return cur[1][i]
+
+    get_opacity = property(lambda self: self._act(0))
+    get_scaling = property(lambda self: self._act(1))
+    get_rotation = property(lambda self: self._act(2))
 
     def raw(self):
         return dict(xyz=self._xyz.detach(), shs=self._shs.detach(), opacity=self._opacity.detach(), scaling=self._scaling.detach(),
