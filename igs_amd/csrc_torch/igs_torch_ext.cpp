@@ -76,6 +76,14 @@ struct In {
     }
 };
 
+// a caller-provided destination tensor: right device, dtype, size, and contiguous (the kernels write raw pointers)
+void check_out(const Tensor& t, int64_t numel, at::ScalarType dt, const c10::Device& dev, const char* what)
+{
+    if (!t.defined() || t.device() != dev || t.scalar_type() != dt || t.numel() != numel || !t.is_contiguous())
+        throw RasterizerError(std::string(what) + ": must be a contiguous " + c10::toString(dt) + " tensor of " + std::to_string(numel) +
+                              " elements on " + dev.str());
+}
+
 void check(int rc, const char* what)
 {
     if (rc < 0) throw RasterizerError(std::string(what) + " failed (" + std::to_string(rc) + "): " + igs_rast_last_error());
@@ -105,8 +113,12 @@ FwdTuple rasterize_gaussians(
     const int64_t M = shs.p ? shs.keep.size(1) : 0;
     auto fopt = at::TensorOptions().dtype(at::kFloat).device(dev);
     // one allocation for the seven images; every pixel is written by the kernels when P > 0
+    if (H <= 0 || W <= 0) throw RasterizerError("image_height and image_width must be positive");
+    if (out_images.has_value()) check_out(*out_images, 15 * H * W, at::kFloat, dev, "out_images");
+    if (out_radii.has_value()) check_out(*out_radii, P, at::kInt, dev, "out_radii");
     Tensor imgs = out_images.has_value() ? *out_images : (P > 0 ? at::empty({15, H, W}, fopt) : at::zeros({15, H, W}, fopt));
     Tensor radii = out_radii.has_value() ? *out_radii : (P > 0 ? at::empty({P}, fopt.dtype(at::kInt)) : at::zeros({0}, fopt.dtype(at::kInt)));
+    if (scratch && scratch->device != dev) throw RasterizerError("scratch set lives on " + scratch->device.str() + ", the tensors on " + dev.str());
     std::shared_ptr<ScratchSet> ss = scratch ? scratch : std::make_shared<ScratchSet>(dev, false);
     Tensor color = imgs.narrow(0, 0, 3), coord = imgs.narrow(0, 3, 3), mcoord = imgs.narrow(0, 6, 3), depth = imgs.narrow(0, 9, 1),
            mdepth = imgs.narrow(0, 10, 1), alpha = imgs.narrow(0, 11, 1), normal = imgs.narrow(0, 12, 3);
@@ -154,7 +166,9 @@ BwdResult backward_body(
     Tensor dL_dsh = out_sh.has_value() ? *out_sh : (P > 0 ? at::empty({P, M, 3}, fopt) : at::zeros({P, M, 3}, fopt));
     Tensor block = P > 0 ? at::empty({23 * P}, fopt) : at::zeros({0}, fopt);
     int64_t o = 0;
+    if (out_sh.has_value()) check_out(*out_sh, P * M * 3, at::kFloat, dev, "out_sh");
     auto carve = [&](int64_t k, const OptTensor& given) {
+        if (given.has_value()) check_out(*given, k * P, at::kFloat, dev, "gradient destination");
         Tensor t = given.has_value() ? *given : block.narrow(0, o, k * P).view({P, k});
         o += k * P;
         return t;
