@@ -15,6 +15,8 @@
 #include <ATen/hip/impl/HIPGuardImplMasqueradingAsCUDA.h>
 #include <ATen/hip/impl/HIPStreamMasqueradingAsCUDA.h>
 #include <limits.h>
+#include <map>
+#include <mutex>
 
 #include "../../include/igs_rast.h"
 
@@ -256,6 +258,59 @@ void adam_step_multi(const std::vector<Tensor>& params, const std::vector<Tensor
     if (rc != 0) throw RasterizerError("igs_adam_step_multi failed: " + std::to_string(rc));
 }
 
+// ---- the two image losses of the refine loop as single calls (igs_amd/losses.py wraps them in autograd Functions) ----
+// small per-(device, stream) scratch kept for the life of the process
+struct LossScratch { Tensor l1; Tensor ssim; int64_t ssim_w = 0, ssim_h = 0; };
+LossScratch& loss_scratch(const c10::Device& dev, hipStream_t stream)
+{
+    static std::mutex mu;
+    static std::map<std::pair<int, void*>, LossScratch> table;
+    std::lock_guard<std::mutex> lock(mu);
+    return table[{ (int)dev.index(), (void*)stream }];
+}
+
+// mean |a - b| and sign(a - b) / n in one launch (igs_l1_mean_fwd_bwd; loss_utils.py:17-18)
+std::tuple<Tensor, Tensor> l1_mean(const Tensor& a, const Tensor& b)
+{
+    if (!a.is_cuda() || !b.is_cuda() || a.numel() == 0 || a.numel() != b.numel()) throw RasterizerError("l1_mean: two GPU tensors of the same, non-zero size (no CPU fallback)");
+    const c10::Device dev = a.device();
+    const c10::hip::HIPGuardMasqueradingAsCUDA guard(dev);
+    In x(a, dev, "a"), y(b, dev, "b");
+    hipStream_t stream = c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(dev.index()).stream();
+    LossScratch& sc = loss_scratch(dev, stream);
+    auto fopt = at::TensorOptions().dtype(at::kFloat).device(dev);
+    if (!sc.l1.defined()) sc.l1 = at::zeros({1025}, fopt);            // 1024 partial sums | the self-resetting counter word
+    Tensor grad = at::empty_like(x.keep), out = at::empty({}, fopt);
+    const int rc = igs_l1_mean_fwd_bwd(stream, (size_t)x.keep.numel(), x.p, y.p, grad.data_ptr<float>(), out.data_ptr<float>(),
+                                       sc.l1.data_ptr<float>(), (unsigned*)(sc.l1.data_ptr<float>() + 1024));
+    if (rc != 0) throw RasterizerError("igs_l1_mean_fwd_bwd failed: " + std::to_string(rc));
+    return { out, grad };
+}
+
+// mean SSIM(a, b) over all elements and d(mean SSIM)/da in two launches (igs_ssim_l1_loss_fwd_bwd with lambda = 1: its gradient is that
+// of 1 - mean SSIM; loss_utils.py:34-63 with the 11x11 window).  a, b: [3, H, W] (or anything that reshapes to it)
+std::tuple<Tensor, Tensor> ssim_mean(const Tensor& a, const Tensor& b)
+{
+    if (!a.is_cuda() || !b.is_cuda() || a.dim() < 3 || a.numel() != b.numel()) throw RasterizerError("ssim_mean: two GPU images of the same size (no CPU fallback)");
+    const c10::Device dev = a.device();
+    const c10::hip::HIPGuardMasqueradingAsCUDA guard(dev);
+    In x(a, dev, "a"), y(b, dev, "b");
+    const int64_t H = a.size(-2), W = a.size(-1);
+    if (a.numel() != 3 * H * W) throw RasterizerError("ssim_mean: one 3-channel image per side");
+    hipStream_t stream = c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(dev.index()).stream();
+    LossScratch& sc = loss_scratch(dev, stream);
+    if (!sc.ssim.defined() || sc.ssim_w != W || sc.ssim_h != H) {
+        sc.ssim = at::empty({(int64_t)igs_ssim_l1_scratch_bytes((int)W, (int)H)}, at::TensorOptions().dtype(at::kByte).device(dev));
+        sc.ssim_w = W; sc.ssim_h = H;
+    }
+    auto fopt = at::TensorOptions().dtype(at::kFloat).device(dev);
+    Tensor grad = at::empty_like(x.keep), sums = at::empty({2048}, fopt);
+    const int rc = igs_ssim_l1_loss_fwd_bwd(stream, (int)W, (int)H, x.p, y.p, 1.0f, 1.0f, sc.ssim.data_ptr(), grad.data_ptr<float>(), sums.data_ptr<float>());
+    if (rc != 0) throw RasterizerError("igs_ssim_l1_loss_fwd_bwd failed: " + std::to_string(rc));
+    Tensor mean = sums.narrow(0, 0, 1024).sum() / (double)x.keep.numel();
+    return { mean, grad };               // grad = d(1 - mean SSIM)/da: the caller negates
+}
+
 }      // namespace
 
 PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
@@ -334,5 +389,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
         return py::int_(rc);
     });
     m.def("adam_step_multi", &adam_step_multi, py::call_guard<py::gil_scoped_release>());
+    m.def("l1_mean", &l1_mean, py::arg("a"), py::arg("b"), py::call_guard<py::gil_scoped_release>());
+    m.def("ssim_mean", &ssim_mean, py::arg("a"), py::arg("b"), py::call_guard<py::gil_scoped_release>());
     m.def("abi_version", []() { return igs_rast_version(); });
 }

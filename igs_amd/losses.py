@@ -13,26 +13,13 @@ from . import _cabi
 
 
 class _L1Mean(torch.autograd.Function):
-    """mean |a - b| and d/da in ONE launch (igs_l1_mean_fwd_bwd: the value is finished on the device by the workgroup that ends last);
-    backward is one scale of the stored sign / n map.  PyTorch's own sub / abs / mean take three launches forward and three backward."""
-    _scratch = {}          # (device, stream) -> [1024 partial sums | counter word], zero-filled once
+    """mean |a - b| and d/da in ONE launch (igs_l1_mean_fwd_bwd through the compiled module: the value is finished on the device by the
+    workgroup that ends last); backward is one scale of the stored sign / n map.  PyTorch's own sub / abs / mean take three launches
+    forward and three backward."""
 
     @staticmethod
     def forward(ctx, a, b):
-        L = _cabi.lib()
-        dev = a.device
-        x, y = a.contiguous().float(), b.contiguous().float()
-        with torch.cuda.device(dev):
-            stream = torch.cuda.current_stream(dev).cuda_stream
-            sc = _L1Mean._scratch.get((dev, stream))
-            if sc is None:
-                sc = _L1Mean._scratch[(dev, stream)] = torch.zeros(1025, dtype=torch.float32, device=dev)
-            grad = torch.empty_like(x)
-            out = torch.empty((), dtype=torch.float32, device=dev)
-            rc = L.igs_l1_mean_fwd_bwd(stream, x.numel(), x.data_ptr(), y.data_ptr(), grad.data_ptr(), out.data_ptr(), sc.data_ptr(),
-                                       sc.data_ptr() + 4096)
-        if rc != 0:
-            raise RuntimeError("igs_l1_mean_fwd_bwd failed: %d" % rc)
+        out, grad = _cabi.ext().l1_mean(a, b)
         ctx.save_for_backward(grad)
         ctx.needs = (ctx.needs_input_grad[0], ctx.needs_input_grad[1])
         ctx.shapes = (a.shape, b.shape)
@@ -56,27 +43,15 @@ def l1_loss(network_output, gt):
 
 
 class _FusedSsimMean(torch.autograd.Function):
-    """mean SSIM(img1, img2) over all elements; d/d img1 from the same two launches (igs_ssim_l1_loss_fwd_bwd with lambda = 1:
-    loss = 1 - mean SSIM, so d meanSSIM / d img1 = -grad)."""
+    """mean SSIM(img1, img2) over all elements; d/d img1 from the same two launches (igs_ssim_l1_loss_fwd_bwd with lambda = 1 through the
+    compiled module: loss = 1 - mean SSIM, so d meanSSIM / d img1 = -grad)."""
 
     @staticmethod
     def forward(ctx, img1, img2):
-        L = _cabi.lib()
-        dev = img1.device
-        x = img1.reshape(img1.shape[-3:]).contiguous().float()
-        y = img2.reshape(img2.shape[-3:]).contiguous().float()
-        H, W = int(x.shape[-2]), int(x.shape[-1])
-        with torch.cuda.device(dev):
-            scratch = torch.empty(L.igs_ssim_l1_scratch_bytes(W, H), dtype=torch.uint8, device=dev)
-            grad = torch.empty_like(x)
-            sums = torch.empty(2048, dtype=torch.float32, device=dev)
-            rc = L.igs_ssim_l1_loss_fwd_bwd(torch.cuda.current_stream(dev).cuda_stream, W, H, x.data_ptr(), y.data_ptr(), 1.0, 1.0,
-                                            scratch.data_ptr(), grad.data_ptr(), sums.data_ptr())
-        if rc != 0:
-            raise RuntimeError("igs_ssim_l1_loss_fwd_bwd failed: %d" % rc)
+        mean, grad = _cabi.ext().ssim_mean(img1, img2)
         ctx.save_for_backward(grad)
         ctx.in_shape = img1.shape
-        return sums[:1024].sum() / x.numel()
+        return mean
 
     @staticmethod
     def backward(ctx, g):
