@@ -1,5 +1,5 @@
 """The UNCHANGED caller: one refine iteration exactly as `infer_batch.py:279-324` drives the rasterizer package -- used by bench.py's
-`dropin` leg, tools/trace_dropin.sh and the GPU tests; caller-side code, not part of the product package.
+`dropin` leg, tools/trace_dropin_loop.sh / dropin_bench.py / profile_dropin_loop_host.py and the GPU tests; caller-side code, not part of the product package.
 
 What is kept from the reference's loop, statement for statement in behaviour (not in text):
   * the model's parameters are five `nn.Parameter`s (xyz, shs, opacity logit, log-scale, rotation) in a `torch.optim.Adam(l, lr=0.0,
