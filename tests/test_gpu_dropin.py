@@ -225,3 +225,91 @@ def test_unchanged_caller_loop_equals_the_fused_step(dev, loss):
             lr = DEFAULT_LRS[k]
             assert float(torch.quantile(d.flatten()[:100000], 0.98)) < 0.02 * lr * steps, (optimizer, k, float(torch.quantile(d.flatten()[:100000], 0.98)))
             assert float(d.max()) <= 2.05 * lr * steps, (optimizer, k, float(d.max()))
+
+
+def test_inputs_are_converted_and_errors_are_loud(dev):
+    """The compiled glue accepts what the reference's does -- non-contiguous and float64 inputs are made contiguous float32
+    (rasterize_points.cu:98-130 calls .contiguous().data<float>()) -- and refuses what it cannot serve with a RasterizerError."""
+    import diff_gaussian_rasterization_rade as D
+    from igs_amd.rasterizer import RasterizerError
+    raw, cams, bg = cfg1_scene(P=900, size=80)
+    cam = cams[0].to(dev)
+    a = {k: v.to(dev) for k, v in activate(raw).items()}
+    st = _settings(D, cam, bg.to(dev))
+    ras = D.GaussianRasterizer(raster_settings=st)
+    m2d = torch.zeros_like(a["means3D"])
+    ref = ras(means3D=a["means3D"], means2D=m2d, opacities=a["opacities"], shs=a["shs"], scales=a["scales"], rotations=a["rotations"])
+    # float64 positions, a transposed (non-contiguous) SH tensor, a strided opacity column
+    shs_nc = a["shs"].transpose(1, 2).contiguous().transpose(1, 2)
+    op_nc = torch.stack([a["opacities"][:, 0], a["opacities"][:, 0]], dim=1)[:, :1]
+    assert not shs_nc.is_contiguous() and not op_nc.is_contiguous()
+    got = ras(means3D=a["means3D"].double(), means2D=m2d, opacities=op_nc, shs=shs_nc, scales=a["scales"], rotations=a["rotations"])
+    for x, y in zip(ref, got):
+        assert torch.equal(x, y)
+    # tensors on the wrong device / no GPU tensor at all
+    with pytest.raises(RasterizerError, match="must live on"):
+        ras(means3D=a["means3D"], means2D=m2d, opacities=a["opacities"].cpu(), shs=a["shs"], scales=a["scales"], rotations=a["rotations"])
+    with pytest.raises(RasterizerError, match="no CPU fallback"):
+        ras(means3D=a["means3D"].cpu(), means2D=m2d.cpu(), opacities=a["opacities"].cpu(), shs=a["shs"].cpu(), scales=a["scales"].cpu(),
+            rotations=a["rotations"].cpu())
+    # a destination tensor of the wrong size is refused before anything is launched
+    from igs_amd import _cabi
+    m = _cabi.ext()
+    with pytest.raises(RasterizerError, match="out_images"):
+        m.rasterize_gaussians(bg.to(dev), a["means3D"], E, a["opacities"], a["scales"], a["rotations"], 1.0, E, cam.world_view_transform,
+                              cam.full_proj_transform, cam.tanfovx, cam.tanfovy, 0.0, cam.height, cam.width, a["shs"], 3, cam.camera_center,
+                              False, True, True, False, out_images=torch.zeros(15, 8, 8, device=dev))
+
+
+def test_two_host_threads_render_and_differentiate_concurrently(dev):
+    """include/igs_rast.h: "the library keeps a little state PER HOST THREAD ... calls from different threads do not interfere".  Two Python
+    threads, each on its own stream, run render -> loss -> backward (NaN report on) for different cameras at the same time -- the compiled
+    module releases the GIL, the scratch pool and the NaN tickets are shared process state -- and must reproduce what one thread computes."""
+    import threading
+    import diff_gaussian_rasterization_rade as D
+    from igs_amd import rasterizer
+    from igs_amd.scenes import sear_steak_like_scene
+    raw, cams, bg = sear_steak_like_scene(P=20000, n_cams=4, width=400, height=300, focal=220.0)
+    cams = [c.to(dev) for c in cams]
+    bgd = bg.to(dev)
+    leaves0 = {k: v.to(dev) for k, v in raw.items()}
+
+    def one(cam, scale):
+        leaf = {k: v.clone().requires_grad_(True) for k, v in leaves0.items()}
+        a = activate(leaf)
+        ras = D.GaussianRasterizer(raster_settings=_settings(D, cam, bgd))
+        out = ras(means3D=a["means3D"], means2D=torch.zeros_like(a["means3D"], requires_grad=True), opacities=a["opacities"], shs=a["shs"],
+                  scales=a["scales"], rotations=a["rotations"])
+        (scale * out[0].sum() + out[4].sum()).backward()
+        return out[0].detach().clone(), {k: v.grad.clone() for k, v in leaf.items()}
+
+    prev = rasterizer.NAN_CHECKS
+    rasterizer.NAN_CHECKS = True
+    try:
+        want = [one(cams[i], 1.0 + i) for i in range(4)]
+        torch.cuda.synchronize()
+        results, errors = {}, []
+
+        def worker(tid):
+            try:
+                s = torch.cuda.Stream(device=dev)
+                s.wait_stream(torch.cuda.default_stream(dev))
+                with torch.cuda.stream(s):
+                    for rep in range(6):
+                        for i in (tid, tid + 2):
+                            results[(tid, rep, i)] = one(cams[i], 1.0 + i)
+                s.synchronize()
+            except Exception as e:  # noqa: BLE001
+                errors.append(repr(e))
+        ts = [threading.Thread(target=worker, args=(t,)) for t in range(2)]
+        [t.start() for t in ts]
+        [t.join() for t in ts]
+        assert not errors, errors
+        assert len(results) == 24
+        for (tid, rep, i), (img, grads) in results.items():
+            assert torch.allclose(img, want[i][0], rtol=0, atol=1e-6), (tid, rep, i)
+            for k in grads:
+                d = float((grads[k] - want[i][1][k]).abs().max()); sc = float(want[i][1][k].abs().max())
+                assert d <= 2e-4 * sc + 1e-12, (tid, rep, i, k, d, sc)      # (float atomics: two runs differ by rounding)
+    finally:
+        rasterizer.NAN_CHECKS = prev
