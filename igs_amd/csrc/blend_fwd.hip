@@ -18,7 +18,7 @@ blend_fwd_kernel(const BlendFwdArgs a)
 {
     constexpr bool GEO = COORD || DEPTH || NORMAL;
     __shared__ float4 chunk[FWD_CHUNK * (GEO ? 6 : 3)];
-    __shared__ uint64_t quad_bits[4][FWD_NSW];              // [quad][staging wave]
+    __shared__ uint64_t quad_bits[FWD_NLIST][FWD_NSW];      // [quad or half-quad][staging wave]
     __shared__ int wave_done[4];
     __shared__ uint32_t order_hist[2 * LOAD_CLASSES];
 

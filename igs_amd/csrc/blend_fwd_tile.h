@@ -9,6 +9,12 @@
 // loop) the fuller machine hides more of a row's dependency chain: 64.4 -> 61.0 us on the bench scene (same-box A/B, round 2)
 #define FWD_CHUNK 192
 #define FWD_NSW (FWD_CHUNK / 64)     // staging waves
+// EXPERIMENT (round 4; default off): the two 8x4 halves of a quad walk their OWN splat lists -- lanes 0..31 and 32..63 of
+// a wave blend DIFFERENT splats in one row while both lists have entries, then the longer list's tail runs with half the lanes masked.
+#ifndef FWD_HALF2
+#define FWD_HALF2 0
+#endif
+#define FWD_NLIST (FWD_HALF2 ? 8 : 4)     // to-do lists per tile: quads, or half-quads
 
 // what a pixel's lane knows when the forward of its tile is done (the fused kernel hands it straight to the backward)
 struct FwdPix {
@@ -27,7 +33,7 @@ struct FwdPix {
 // `chunk`: FWD_CHUNK * (GEO ? 6 : 3) float4 of LDS; quad_bits [4][FWD_NSW]; wave_done [4].  Every thread of the workgroup calls it.
 template <bool COORD, bool DEPTH, bool NORMAL, bool LEAN, bool KEEP_N>
 __device__ __forceinline__ void blend_fwd_tile(const BlendFwdArgs& a, const uint32_t tile, float4* __restrict__ chunk,
-                                               uint64_t (*quad_bits)[FWD_NSW], int* wave_done, FwdPix& px_out)
+                                               uint64_t (*quad_bits)[FWD_NSW], int* wave_done, FwdPix& px_out)      // quad_bits: [FWD_NLIST][FWD_NSW]
 {
     constexpr bool GEO = COORD || DEPTH || NORMAL;
     constexpr int NQ = GEO ? 6 : 3;                     // float4 per staged record
@@ -65,28 +71,19 @@ __device__ __forceinline__ void blend_fwd_tile(const BlendFwdArgs& a, const uint
             }
             chunk[tid * NQ + 0] = q0; chunk[tid * NQ + 1] = q1; chunk[tid * NQ + 2] = q2;
             if constexpr (GEO) { chunk[tid * NQ + 3] = src[3]; chunk[tid * NQ + 4] = src[4]; chunk[tid * NQ + 5] = src[5]; }
-            qmask = quad_reach_mask(q0, q1, tile_x0, tile_y0);
+            qmask = FWD_HALF2 ? half_reach_mask(q0, q1, tile_x0, tile_y0) : quad_reach_mask(q0, q1, tile_x0, tile_y0);
         }
         if (wid < FWD_NSW) {
 #pragma unroll
-            for (int q = 0; q < 4; q++) {
+            for (int q = 0; q < FWD_NLIST; q++) {
                 const uint64_t b = __ballot((qmask >> q) & 1u);
                 if (lane == 0) quad_bits[q][wid] = b;
             }
         }
         tile_barrier();
-        if (__ballot(Tl != 0.0f) != 0ull) {
-            bool wave_finished = false;
-            for (int sw = 0; sw < FWD_NSW && !wave_finished; sw++) {
-                uint64_t bits = uniform64(quad_bits[wid][sw]);     // wave-uniform
-                while (bits != 0ull) {
-                    const int jj = __builtin_ctzll(bits);
-                    asm("s_bitset0_b64 %0, %1" : "+s"(bits) : "s"(jj));      // (one scalar instruction instead of the three of bits &= bits - 1)
-                    const int j = sw * 64 + jj;
-                    uint32_t addr;                                           // LDS byte offset of the record: ONE vector multiply (s_mul + v_mov otherwise)
-                    if constexpr (NQ * 16 <= 64) asm("v_mul_u32_u24 %0, %1, %2" : "=v"(addr) : "s"(j), "n"(NQ * 16));
-                    else asm("v_mul_u32_u24 %0, %1, %2" : "=v"(addr) : "s"(j), "v"(NQ * 16));
-                    const float4* r = (const float4*)((const char*)chunk + addr);
+        // one (wave, splat) row; `r`: the staged record(s) the lanes read (wave-uniform address, or one per half), `slot`: its position
+        // in the chunk (scalar or per-lane)
+        auto blend_row = [&](const float4* r, const auto slot) {
                     const float4 q0 = r[0], q1 = r[1], q2 = r[2];
                     const float dx = q0.x - pixfx, dy = q0.y - pixfy;
                     const float power = gauss_power(q0.z, q0.w, q1.x, dx, dy);
@@ -103,7 +100,7 @@ __device__ __forceinline__ void blend_fwd_tile(const BlendFwdArgs& a, const uint
                     const bool alive = !(test_T < 0.0001f);
                     const float aT = alive ? alpha_e * Tl : 0.0f;
                     const bool contrib = aT > 0.0f;
-                    const uint32_t contributor = (uint32_t)(i * FWD_CHUNK + j + 1);
+                    const uint32_t contributor = (uint32_t)(i * FWD_CHUNK + 1) + (uint32_t)slot;
                     C0 += q1.z * aT; C1 += q1.w * aT; C2 += q2.x * aT;
                     if constexpr (GEO) {
                         const float4 q3 = r[3];                            // view_point, n.x
@@ -128,12 +125,60 @@ __device__ __forceinline__ void blend_fwd_tile(const BlendFwdArgs& a, const uint
                     T = alive ? test_T : T;                 // (skipped splat: test_T = Tl = T; finished pixel: T keeps its last value)
                     Tl = alive ? test_T : 0.0f;
                     last_contributor = contrib ? contributor : last_contributor;
+        };
+        if (__ballot(Tl != 0.0f) != 0ull) {
+            bool wave_finished = false;
+#if FWD_HALF2
+            const bool upper = lane >= 32;                       // rows 4..7 of the quad
+            for (int sw = 0; sw < FWD_NSW && !wave_finished; sw++) {
+                uint64_t bitsA = uniform64(quad_bits[2 * wid][sw]), bitsB = uniform64(quad_bits[2 * wid + 1][sw]);
+                while (bitsA != 0ull && bitsB != 0ull) {         // both halves have a splat: one row serves two splats
+                    const int ja = __builtin_ctzll(bitsA), jb = __builtin_ctzll(bitsB);
+                    asm("s_bitset0_b64 %0, %1" : "+s"(bitsA) : "s"(ja));
+                    asm("s_bitset0_b64 %0, %1" : "+s"(bitsB) : "s"(jb));
+                    const uint32_t jl = (uint32_t)(sw * 64) + (uint32_t)(upper ? jb : ja);
+                    blend_row((const float4*)((const char*)chunk + jl * (uint32_t)(NQ * 16)), jl);
+                }
+                // the longer list's tail: the other half of the wave sits these rows out (EXEC-masked; wave-uniform record address)
+                if (bitsA != 0ull) {
+                    if (!upper) {
+                        while (bitsA != 0ull) {
+                            const int jj = __builtin_ctzll(bitsA);
+                            asm("s_bitset0_b64 %0, %1" : "+s"(bitsA) : "s"(jj));
+                            const int j = sw * 64 + jj;
+                            blend_row((const float4*)((const char*)chunk + (uint32_t)j * (uint32_t)(NQ * 16)), (uint32_t)j);
+                        }
+                    }
+                } else if (bitsB != 0ull) {
+                    if (upper) {
+                        while (bitsB != 0ull) {
+                            const int jj = __builtin_ctzll(bitsB);
+                            asm("s_bitset0_b64 %0, %1" : "+s"(bitsB) : "s"(jj));
+                            const int j = sw * 64 + jj;
+                            blend_row((const float4*)((const char*)chunk + (uint32_t)j * (uint32_t)(NQ * 16)), (uint32_t)j);
+                        }
+                    }
+                }
+                if (__ballot(Tl != 0.0f) == 0ull) wave_finished = true;
+            }
+#else
+            for (int sw = 0; sw < FWD_NSW && !wave_finished; sw++) {
+                uint64_t bits = uniform64(quad_bits[wid][sw]);     // wave-uniform
+                while (bits != 0ull) {
+                    const int jj = __builtin_ctzll(bits);
+                    asm("s_bitset0_b64 %0, %1" : "+s"(bits) : "s"(jj));      // (one scalar instruction instead of the three of bits &= bits - 1)
+                    const int j = sw * 64 + jj;
+                    uint32_t addr;                                           // LDS byte offset of the record: ONE vector multiply (s_mul + v_mov otherwise)
+                    if constexpr (NQ * 16 <= 64) asm("v_mul_u32_u24 %0, %1, %2" : "=v"(addr) : "s"(j), "n"(NQ * 16));
+                    else asm("v_mul_u32_u24 %0, %1, %2" : "=v"(addr) : "s"(j), "v"(NQ * 16));
+                    blend_row((const float4*)((const char*)chunk + addr), (uint32_t)j);
                 }
                 // "has every pixel of the quad saturated?" is asked once per 64 staged splats, not per row: the ballot
                 // costs two VALU ops and a branch in the middle of the row (measured: 71.5 -> 65 us); at most the
                 // rest of one 64-splat word is blended into lanes that no longer take anything
                 if (__ballot(Tl != 0.0f) == 0ull) wave_finished = true;
             }
+#endif
         }
         const bool all_done = __ballot(Tl != 0.0f) == 0ull;       // (the ballot must be taken by the whole wave)
         if (lane == 0) wave_done[wid] = all_done ? 1 : 0;

@@ -37,7 +37,7 @@ blend_step_kernel(const BlendFwdArgs f, const BlendBwdArgs b)
     constexpr size_t BWD_BYTES = BWD_CHUNK_BYTES + (size_t)Cfg::RED_FLOATS * 4;
     // the two passes use the same LDS one after the other
     __shared__ __attribute__((aligned(16))) char smem[FWD_BYTES > BWD_BYTES ? FWD_BYTES : BWD_BYTES];
-    __shared__ uint64_t quad_bits_f[4][FWD_NSW];
+    __shared__ uint64_t quad_bits_f[FWD_NLIST][FWD_NSW];
     __shared__ uint64_t quad_bits_b[4][Cfg::NSW];
     __shared__ int wave_done[4];
     __shared__ int wave_max[4];
