@@ -13,7 +13,7 @@ LIB = os.path.join(LIBDIR, "libigs_rast.so")
 # files whose inner loops are independent FMA streams: let the SLP vectorizer form v_pk_fma_f32 (2 FMAs per lane and instruction);
 # everywhere else packing only added register moves
 SLP_OK = {"loss_ops.hip"} | set(os.environ.get("IGS_SLP_FILES", "").split())
-SOURCES = ["api.hip", "preprocess.hip", "sort.hip", "blend_fwd.hip", "blend_bwd.hip", "blend_step.hip", "geom_bwd.hip", "refine_ops.hip", "loss_ops.hip"]
+SOURCES = ["api.hip", "preprocess.hip", "sort.hip", "blend_fwd.hip", "blend_bwd.hip", "blend_step.hip", "geom_bwd.hip", "refine_ops.hip", "loss_ops.hip", "io_ops.hip"]
 # -fno-slp-vectorize: on gfx950 v_pk_*_f32 runs at the scalar-f32 rate per element, so SLP packing only adds v_mov shuffles
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-Wno-unused-variable",
          "-fno-slp-vectorize", "-Wno-inline-asm"]      # (-Wno-inline-asm: the column-write statements clobber m0 on purpose)

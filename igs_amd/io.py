@@ -129,6 +129,77 @@ def load_start_gaussians(path, max_sh_degree=3):
     return dict(xyz=t(xyz), rotation=t(rots), shs=shs, opacity=logit, scaling=log_scale)
 
 
+def _ply_columns(names, K):
+    """Column indices, in the order igs_ply_to_params wants them (include/igs_rast.h)."""
+    idx = {n: i for i, n in enumerate(names)}
+    by_num = lambda prefix: sorted((n for n in names if n.startswith(prefix)), key=lambda x: int(x.split("_")[-1]))
+    rest, scales, rots = by_num("f_rest_"), by_num("scale_"), by_num("rot")
+    if len(rest) != 3 * K - 3 or len(scales) != 3 or len(rots) != 4:
+        raise ValueError("PLY columns do not describe SH degree %d Gaussians (%d f_rest, %d scale, %d rot columns)"
+                         % (int(round(K ** 0.5)) - 1, len(rest), len(scales), len(rots)))
+    cols = ["x", "y", "z", "f_dc_0", "f_dc_1", "f_dc_2"] + rest + ["opacity"] + scales + rots
+    return [idx[c] for c in cols] + [idx.get("filter_3D", -1)]
+
+
+def load_start_gaussians_gpu(path, device, max_sh_degree=3):
+    """`load_start_gaussians` with the per-Gaussian work on the GPU: the host only parses the header and hands the vertex table over as it
+    lies in the file; column gathering, the channel-major -> [P, K, 3] SH re-layout and the `filter_3D` fold (gs.py:400-462, 480-490) are
+    ONE launch (igs_ply_to_params).  Tables whose properties are all float32 (what the reference writes); anything else raises.
+    Returns the raw leaves on `device`."""
+    import ctypes as C
+    from . import _cabi
+    device = torch.device(device)
+    if device.type != "cuda":
+        raise RuntimeError("load_start_gaussians_gpu: needs a GPU device (the host-only reader is load_start_gaussians)")
+    v = read_ply_vertices(path)
+    names = v.dtype.names
+    if any(v.dtype[n] != np.dtype("f4") for n in names):
+        raise ValueError("%s: non-float32 vertex properties; use load_start_gaussians" % path)
+    P, stride = v.shape[0], len(names)
+    K = (max_sh_degree + 1) ** 2
+    cols = _ply_columns(names, K)
+    table = torch.from_numpy(np.ascontiguousarray(v).view(np.float32).reshape(P, stride)).to(device)
+    f = dict(dtype=torch.float32, device=device)
+    out = dict(xyz=torch.empty((P, 3), **f), rotation=torch.empty((P, 4), **f), shs=torch.empty((P, K, 3), **f),
+               opacity=torch.empty((P, 1), **f), scaling=torch.empty((P, 3), **f))
+    with torch.cuda.device(device):
+        rc = _cabi.lib().igs_ply_to_params(torch.cuda.current_stream(device).cuda_stream, P, table.data_ptr(), stride, (C.c_int * len(cols))(*cols),
+                                           len(cols), K, out["xyz"].data_ptr(), out["rotation"].data_ptr(), out["shs"].data_ptr(),
+                                           out["opacity"].data_ptr(), out["scaling"].data_ptr())
+    if rc != 0:
+        raise RuntimeError("igs_ply_to_params failed: %d" % rc)
+    return out
+
+
+def write_gaussian_ply_gpu(path, raw):
+    """`write_gaussian_ply` for leaves that live on the GPU: the [P, 62] table (gs.py:297-343) is laid out by ONE launch
+    (igs_params_to_ply) and leaves the device as a single copy; the host writes header + bytes."""
+    from . import _cabi
+    xyz = raw["xyz"].detach().contiguous().float()
+    dev, P = xyz.device, xyz.shape[0]
+    if dev.type != "cuda":
+        raise RuntimeError("write_gaussian_ply_gpu: leaves must be on a GPU (the host-only writer is write_gaussian_ply)")
+    g = lambda k: raw[k].detach().contiguous().float()
+    shs, rot, op, sc = g("shs"), g("rotation"), g("opacity"), g("scaling")
+    K = shs.shape[1]
+    table = torch.empty((P, 14 + 3 * K), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        rc = _cabi.lib().igs_params_to_ply(torch.cuda.current_stream(dev).cuda_stream, P, K, xyz.data_ptr(), rot.data_ptr(), shs.data_ptr(),
+                                           op.data_ptr(), sc.data_ptr(), table.data_ptr())
+    if rc != 0:
+        raise RuntimeError("igs_params_to_ply failed: %d" % rc)
+    names = ["x", "y", "z", "nx", "ny", "nz"] + ["f_dc_%d" % i for i in range(3)] + ["f_rest_%d" % i for i in range(3 * K - 3)] \
+        + ["opacity"] + ["scale_%d" % i for i in range(3)] + ["rot_%d" % i for i in range(4)]
+    os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+    with open(path, "wb") as f:
+        f.write(b"ply\nformat binary_little_endian 1.0\n")
+        f.write(("element vertex %d\n" % P).encode())
+        for n in names:
+            f.write(("property float %s\n" % n).encode())
+        f.write(b"end_header\n")
+        f.write(table.cpu().numpy().astype("<f4").tobytes())
+
+
 def load_cameras_json(path, training_only=True):
     """infer_data.py:93-95,412-440: entries {img_name, rotation 3x3 (c2w), position, fx, fy, width, height}; the first entry is
     the held-out test view (`cameras_data[1:]` are the training views).  Returns (list of dicts with c2w 4x4, FOV, size, name)."""

@@ -394,6 +394,18 @@ int igs_l1_loss_fwd_bwd(void* stream, size_t n, const float* pred, const float* 
 int igs_l1_mean_fwd_bwd(void* stream, size_t n, const float* pred, const float* gt, float* grad, float* mean_out, float* partials,
                         unsigned* counter);
 
+/* On-disk format <-> parameter store on the device (extension).  The host reads / writes the file; these do the
+ * per-Gaussian re-layout and arithmetic of igs/models/gs.py:400-462 (load_ply) and :297-343 (save_ply) in one pass each.
+ *   igs_ply_to_params: `table` = the PLY's vertex element as [P][stride] float32 on the device; `cols` (HOST memory, n_cols = 15 + 3 (K - 1)
+ *     entries) = the column of x y z | f_dc_0..2 | f_rest_0 .. f_rest_{3(K-1)-1} | opacity | scale_0..2 | rot_0..3 | filter_3D (-1: absent).
+ *     Writes xyz [P,3], rotation [P,4], shs [P,K,3] (the file is channel-major), opacity [P] (logit), scaling [P,3] (log); with a filter_3D
+ *     column the Mip-Splatting filter is folded in exactly as gs.py:480-490 + inverse_sigmoid / log (:451-455).
+ *   igs_params_to_ply: the [P][14 + 3 K] table save_ply writes (normals zero, f_dc / f_rest channel-major). */
+int igs_ply_to_params(void* stream, int P, const float* table, int stride, const int* cols, int n_cols, int K,
+                      float* xyz, float* rotation, float* shs, float* opacity, float* scaling);
+int igs_params_to_ply(void* stream, int P, int K, const float* xyz, const float* rotation, const float* shs, const float* opacity,
+                      const float* scaling, float* table);
+
 /* Morton (Z-order) permutation of the Gaussians' positions (extension, no reference counterpart; used by the refine loop's store so
  * that consecutive Gaussians project to neighbouring tiles -- the binning stage then reserves instance slots once per (workgroup,
  * tile) instead of once per instance).  perm[i] = index of the Gaussian that comes i-th; ties keep their order (stable radix sort

@@ -316,3 +316,46 @@ def test_two_host_threads_render_and_differentiate_concurrently(dev):
                 assert close > 0.999, (tid, rep, i, k, close)
     finally:
         rasterizer.NAN_CHECKS = prev
+
+
+@pytest.mark.parametrize("with_filter", [True, False])
+def test_ply_table_to_parameter_store_on_the_gpu(dev, tmp_path, with_filter):
+    """SURVEY 8f rank 3 on the device: igs_ply_to_params (column gathering, channel-major SH -> [P, K, 3], `filter_3D` folded into scale and
+    opacity: gs.py:400-462, 480-490) against the host reader of igs_amd/io.py on the same file -- written by the host writer with the
+    reference's property order plus, as real assets have them, columns in another order; and igs_params_to_ply against the host writer."""
+    import numpy as np
+    from igs_amd import io
+    raw, _, _ = cfg1_scene(P=5000, size=64)
+    gen = torch.Generator().manual_seed(4)
+    filt = (0.002 + 0.05 * torch.rand(5000, 1, generator=gen)) if with_filter else None
+    path = str(tmp_path / "start.ply")
+    io.write_gaussian_ply(path, raw, filter_3D=filt)
+    want = io.load_start_gaussians(path)
+    got = io.load_start_gaussians_gpu(path, dev)
+    for k in want:
+        assert got[k].shape == want[k].shape and got[k].device.type == "cuda", k
+        torch.testing.assert_close(got[k].cpu(), want[k], rtol=2e-6, atol=2e-6), k
+    if with_filter:       # the fold really happened: scales grew, opacities shrank
+        assert float((got["scaling"].cpu() - raw["scaling"]).min()) > 0 and float((got["opacity"].cpu() - raw["opacity"]).max()) < 0
+    else:
+        for k in raw:
+            assert torch.equal(got[k].cpu(), raw[k].float()), k
+    # a file whose columns come in another order (rot before scale, filter first): the header decides, not the position
+    v = io.read_ply_vertices(path)
+    names = list(v.dtype.names)
+    perm = [n for n in names if n.startswith("rot")] + [n for n in names if n == "filter_3D"] + [n for n in names if not n.startswith("rot") and n != "filter_3D"]
+    p2 = str(tmp_path / "shuffled.ply")
+    with open(p2, "wb") as f:
+        f.write(b"ply\nformat binary_little_endian 1.0\n" + ("element vertex %d\n" % len(v)).encode())
+        for n in perm:
+            f.write(("property float %s\n" % n).encode())
+        f.write(b"end_header\n")
+        f.write(np.stack([v[n] for n in perm], axis=1).astype("<f4").tobytes())
+    got2 = io.load_start_gaussians_gpu(p2, dev)
+    for k in got:
+        assert torch.equal(got2[k], got[k]), k
+    # the writer: same bytes as the host writer for leaves on the GPU
+    p3, p4 = str(tmp_path / "a.ply"), str(tmp_path / "b.ply")
+    io.write_gaussian_ply(p3, raw)
+    io.write_gaussian_ply_gpu(p4, {k: t.to(dev) for k, t in raw.items()})
+    assert open(p3, "rb").read() == open(p4, "rb").read()
