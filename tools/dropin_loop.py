@@ -67,27 +67,26 @@ class CallerModel:
 
 
 def forward_single_view(gs, cam, bg, sh_degree=3, package=None):
-    """`infer_batch.py:39-124` against `package` (default: diff_gaussian_rasterization_rade)."""
+    """The operations of `infer_batch.py:39-124`, in its order, against `package` (default: diff_gaussian_rasterization_rade):
+    a zeros + 0 gradient sink for the screen-space means with retain_grad(), a settings tuple built by keyword, a fresh rasterizer module,
+    keyword call with SHs (no precomputed colours / covariances), the visibility mask from the radii."""
     if package is None:
         import diff_gaussian_rasterization_rade as package
-    tanfovx = math.tan(cam.FoVx * 0.5)
-    tanfovy = math.tan(cam.FoVy * 0.5)
-    screenspace_points = torch.zeros_like(gs.get_xyz, dtype=gs.get_xyz.dtype, requires_grad=True, device="cuda") + 0
+    sink = torch.zeros_like(gs.get_xyz, dtype=gs.get_xyz.dtype, requires_grad=True, device="cuda") + 0
     try:
-        screenspace_points.retain_grad()
+        sink.retain_grad()
     except Exception:  # noqa: BLE001
         pass
-    raster_settings = package.GaussianRasterizationSettings(
-        image_height=int(cam.height), image_width=int(cam.width), tanfovx=tanfovx, tanfovy=tanfovy, bg=bg, scale_modifier=1.0,
-        viewmatrix=cam.world_view_transform, projmatrix=cam.full_proj_transform.float(), sh_degree=sh_degree,
-        campos=cam.camera_center, prefiltered=False, debug=False, kernel_size=0.0, require_coord=True, require_depth=True)
-    rasterizer = package.GaussianRasterizer(raster_settings=raster_settings)
-    means2D = screenspace_points.contiguous().float()
-    image, radii, coord, mcoord, depth, mdepth, alpha, normal = rasterizer(
-        means3D=gs.get_xyz, means2D=means2D, shs=gs.get_features, colors_precomp=None, opacities=gs.get_opacity,
-        scales=gs.get_scaling, rotations=gs.get_rotation, cov3D_precomp=None)
+    cfg = dict(image_height=int(cam.height), image_width=int(cam.width), tanfovx=math.tan(cam.FoVx * 0.5), tanfovy=math.tan(cam.FoVy * 0.5),
+               bg=bg, scale_modifier=1.0, viewmatrix=cam.world_view_transform, projmatrix=cam.full_proj_transform.float(),
+               sh_degree=sh_degree, campos=cam.camera_center, prefiltered=False, debug=False,
+               kernel_size=0.0, require_coord=True, require_depth=True)          # (the RaDe-GS defaults the reference passes)
+    render = package.GaussianRasterizer(raster_settings=package.GaussianRasterizationSettings(**cfg))
+    outs = render(means3D=gs.get_xyz, means2D=sink.contiguous().float(), shs=gs.get_features, colors_precomp=None,
+                  opacities=gs.get_opacity, scales=gs.get_scaling, rotations=gs.get_rotation, cov3D_precomp=None)
+    image, radii, coord, mcoord, depth, mdepth, alpha, normal = outs
     return {"images_pred": image, "bg_color": bg, "depth_pred": depth, "radii": radii, "visibility_filter": radii > 0,
-            "viewspace_points": screenspace_points, "mdepth": mdepth, "normal": normal, "alpha": alpha, "coord": coord, "mcoord": mcoord}
+            "viewspace_points": sink, "mdepth": mdepth, "normal": normal, "alpha": alpha, "coord": coord, "mcoord": mcoord}
 
 
 def make_losses(kind, ssim_fn=None):
