@@ -472,19 +472,26 @@ def main():
                     def dropin(loss_, optimizer, nan, n_steps):
                         rasterizer.NAN_CHECKS = bool(nan)
                         gs = CallerModel(raw_sorted, dev, DEFAULT_LRS, optimizer=optimizer)
+                        body = lambda v: refine_iteration(gs, cams[v], gts[v], bg, loss=loss_, losses=lf)
+                        if optimizer.endswith("_capturable"):
+                            # the same loop body, replayed from one hipGraph per view (igs_amd/graphs.py: first visit eager, second
+                            # captured; the 20 untimed iterations below cover both for every view)
+                            from igs_amd.graphs import GraphedLoop
+                            body = GraphedLoop(body)
                         for i in range(20):
-                            refine_iteration(gs, cams[i % len(cams)], gts[i % len(cams)], bg, loss=loss_, losses=lf)
+                            body(i % len(cams))
                         torch.cuda.synchronize()
                         t = time.perf_counter()
                         for i in range(n_steps):
-                            refine_iteration(gs, cams[i % len(cams)], gts[i % len(cams)], bg, loss=loss_, losses=lf)
+                            body(i % len(cams))
                         torch.cuda.synchronize()
                         return 1000.0 * (time.perf_counter() - t) / n_steps
                     n_d = args.dropin_steps
                     # host-bound timing is noisy (the first variant of a process runs 10-20 % slower than the same variant later): two
                     # interleaved passes over the variants, the faster of the two is reported, both are kept
                     variants = (("l1_ms", "l1", "fused", 0, n_d), ("nan_checks_ms", "l1", "fused", 1, n_d), ("l1_ssim_ms", "l1_ssim", "fused", 0, n_d),
-                                ("l1_ssim_nan_checks_ms", "l1_ssim", "fused", 1, n_d), ("l1_torch_adam_ms", "l1", "torch", 1, max(20, n_d // 3)))
+                                ("l1_ssim_nan_checks_ms", "l1_ssim", "fused", 1, n_d), ("l1_torch_adam_ms", "l1", "torch", 1, max(20, n_d // 3)),
+                                ("l1_graph_ms", "l1", "fused_capturable", 1, n_d), ("l1_ssim_graph_ms", "l1_ssim", "fused_capturable", 1, n_d))
                     passes = [{k: dropin(ls, opt, nan, n) for k, ls, opt, nan, n in variants} for _ in range(2)]
                     d = {k: min(passes[0][k], passes[1][k]) for k in passes[0]}
                     d["steps"] = n_d
@@ -493,7 +500,9 @@ def main():
                                  "the compiled `_C` module; `igs_amd.losses` for l1_loss / ssim (one import line) and, except in l1_torch_adam_ms, "
                                  "`igs_amd.optim.Adam` for torch.optim.Adam (one constructor); nan_checks = the reference's NaN asserts on "
                                  "(one word from the per-Gaussian kernel, collected at the end of the backward pass).  The caller's own ~35 small "
-                                 "PyTorch kernels per iteration (activations and their backward, PSNR line, fills) bound this figure from the host side")
+                                 "PyTorch kernels per iteration (activations and their backward, PSNR line, fills) bound this figure from the host side; "
+                                 "*_graph_ms = the same loop body wrapped in igs_amd.graphs.GraphedLoop (captured once per view with torch.cuda.graph, "
+                                 "then one graph launch per iteration; igs_amd.optim.Adam(capturable=True)), which removes that host cost")
                     out_extra["dropin"] = d
                     log("drop-in leg: %s" % {k: round(v, 4) for k, v in d.items() if isinstance(v, float)})
                 except Exception as e:  # noqa: BLE001

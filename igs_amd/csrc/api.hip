@@ -536,7 +536,7 @@ extern "C" int igs_rast_forward_nowait(
 // What the last slab-binned forward of this thread and device posted.  *overflow != 0: a tile needed that many instance slots and
 // the per-tile slabs were smaller -- the frame (and everything computed from it) is invalid; the slab hint has been raised, so a
 // new capture / an ordinary igs_rast_forward will fit.  Only meaningful once the stream has been synchronised.
-extern "C" int igs_rast_last_status(int* num_rendered, unsigned* overflow, unsigned* prefilter_flag)
+static int last_status(int* num_rendered, unsigned* overflow, unsigned* prefilter_flag, bool check_seq)
 {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= IGS_MAX_DEVICES || !g_slots.slot[dev].pinned)
@@ -544,7 +544,8 @@ extern "C" int igs_rast_last_status(int* num_rendered, unsigned* overflow, unsig
     const uint32_t* p = g_slots.slot[dev].pinned;
     // the sequence word is stored last by the kernel (release): if it is not the number baked into the last igs_rast_forward_nowait of this
     // thread (the last capture), no replay of that capture has posted yet and the other three words still belong to an EARLIER (eager) frame
-    if (__atomic_load_n(&p[3], __ATOMIC_ACQUIRE) != (g_nowait_seq ? g_nowait_seq : g_host_seq))
+    const uint32_t seq = __atomic_load_n(&p[3], __ATOMIC_ACQUIRE);
+    if (check_seq && seq != (g_nowait_seq ? g_nowait_seq : g_host_seq))
         return fail(IGS_RAST_E_RETRY, "igs_rast_last_status: the captured forward has not posted its status yet (replay the graph and synchronise the stream first)");
     const uint32_t R = __atomic_load_n(&p[0], __ATOMIC_ACQUIRE), ov = __atomic_load_n(&p[1], __ATOMIC_ACQUIRE);
     if (num_rendered) *num_rendered = R > 0x7FFFFFFFu ? 0x7FFFFFFF : (int)R;
@@ -555,6 +556,14 @@ extern "C" int igs_rast_last_status(int* num_rendered, unsigned* overflow, unsig
         if (want > g_hint.slab) g_hint.slab = (uint32_t)(want > TILE_SORT_BIG ? TILE_SORT_BIG : want);
     }
     return 0;
+}
+extern "C" int igs_rast_last_status(int* num_rendered, unsigned* overflow, unsigned* prefilter_flag)
+{
+    return last_status(num_rendered, overflow, prefilter_flag, true);
+}
+extern "C" int igs_rast_last_posted_status(int* num_rendered, unsigned* overflow, unsigned* prefilter_flag)
+{
+    return last_status(num_rendered, overflow, prefilter_flag, false);
 }
 
 extern "C" void igs_rast_set_slab_hint(unsigned slots_per_tile) { g_hint.slab = slots_per_tile > TILE_SORT_BIG ? TILE_SORT_BIG : slots_per_tile; }
@@ -880,21 +889,29 @@ extern "C" int igs_refine_step(const igs_refine_step_args* a)
         f.guard_overflow = g_last_fwd.overflow; f.guard_prefilter = g_last_fwd.prefilter;
         f.blend_done = fused_ran ? 1 : 0;
         if (fused_ran) __atomic_store_n(&g_last_bwd_instance, fused_inst, __ATOMIC_RELAXED);
-        if (dssim) {
-            prof_mark((hipStream_t)a->stream, ST_GAP);
-            if (launch_ssim_l1((hipStream_t)a->stream, a->width, a->height, color, a->gt, a->lambda_dssim, a->loss_weight, a->loss_scratch,
-                               grad_img, false, a->gt_stats, a->gt_stats_valid != 0) != hipSuccess)
-                return fail(IGS_RAST_E_HIP, "ssim loss launch");
-            prof_mark((hipStream_t)a->stream, ST_MEMSET);          // (the stage slot the fused step does not otherwise use: "loss")
-        }
+        DepthNormalJob dnj;
         if (dn) {
             // depth-normal regulariser on the maps just rendered: its three gradient maps switch the blend backward to the
             // <depth, normal> instance
+            dnj.fx = a->width / (2.0f * a->tan_fovx); dnj.fy = a->height / (2.0f * a->tan_fovy);
+            dnj.depth = depth; dnj.mdepth = mdepth; dnj.normal = normal; dnj.weight = a->loss_weight * a->lambda_depth_normal;
+            dnj.depth_ratio = a->depth_ratio > 0.f ? a->depth_ratio : 0.6f;
+            dnj.g_depth = dn_gd; dnj.g_mdepth = dn_gm; dnj.g_normal = dn_gn; dnj.loss_shards = dn_shards;
+        }
+        static const bool no_mix = getenv("IGS_NO_LOSS_MIX") != nullptr;      // (A/B switch for measurements)
+        const bool mix = dssim && dn && !no_mix;       // both image-space losses: the regulariser rides in the SSIM gradient's launch
+        if (dssim) {
+            prof_mark((hipStream_t)a->stream, ST_GAP);
+            if (launch_ssim_l1((hipStream_t)a->stream, a->width, a->height, color, a->gt, a->lambda_dssim, a->loss_weight, a->loss_scratch,
+                               grad_img, false, a->gt_stats, a->gt_stats_valid != 0, mix ? &dnj : nullptr) != hipSuccess)
+                return fail(IGS_RAST_E_HIP, "ssim loss launch");
+            prof_mark((hipStream_t)a->stream, ST_MEMSET);          // (the stage slot the fused step does not otherwise use: "loss")
+        }
+        if (dn && !mix) {
             hipStream_t ms = (hipStream_t)a->stream;
             HIP_TRY(zero_fill_async(ms, dn_shards, 4096), "zero shards");
-            const float fx = a->width / (2.0f * a->tan_fovx), fy = a->height / (2.0f * a->tan_fovy);
-            HIP_TRY(launch_depth_normal(ms, a->width, a->height, fx, fy, depth, mdepth, normal, a->loss_weight * a->lambda_depth_normal,
-                                        a->depth_ratio > 0.f ? a->depth_ratio : 0.6f, dn_gd, dn_gm, dn_gn, dn_shards), "depth_normal launch");
+            HIP_TRY(launch_depth_normal(ms, a->width, a->height, dnj.fx, dnj.fy, depth, mdepth, normal, dnj.weight, dnj.depth_ratio, dn_gd, dn_gm,
+                                        dn_gn, dn_shards), "depth_normal launch");
         }
         const int rc = backward_impl(a->stream, a->P, a->D, a->M, R, a->background, a->width, a->height, xyz, shs, nullptr, alpha, scal, 1.0f,
                                      rotn, nullptr, a->viewmatrix, a->projmatrix, a->cam_pos, a->tan_fovx, a->tan_fovy, 0.0f, a->radii,

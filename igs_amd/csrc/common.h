@@ -231,8 +231,11 @@ hipError_t launch_sh_adam_views(hipStream_t s, int P, int D, int M, int V, const
 hipError_t launch_depth_normal(hipStream_t s, int W, int H, float fx, float fy, const float* depth, const float* mdepth, const float* normal,
                                float weight, float depth_ratio, float* g_depth, float* g_mdepth, float* g_normal, float* loss_shards);
 // 0.8 L1 + 0.2 (1 - SSIM)-style loss, forward + backward (loss_ops.hip); scratch: igs_ssim_l1_scratch_bytes
+// (optional `dn`: the depth-normal regulariser of the same step, run inside the SSIM gradient's launch: loss_ops.hip)
+struct DepthNormalJob { float fx, fy; const float *depth, *mdepth, *normal; float weight, depth_ratio; float *g_depth, *g_mdepth, *g_normal, *loss_shards; };
 hipError_t launch_ssim_l1(hipStream_t s, int W, int H, const float* pred, const float* gt, float lambda_dssim, float weight,
-                          void* scratch, float* grad, bool zero_shards, float* gt_stats = nullptr, bool gt_stats_valid = false);
+                          void* scratch, float* grad, bool zero_shards, float* gt_stats = nullptr, bool gt_stats_valid = false,
+                          const DepthNormalJob* dn = nullptr);
 
 // ---------------------------------------------------------------------------------------------
 // device helpers

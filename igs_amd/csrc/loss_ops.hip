@@ -70,8 +70,11 @@ enum { GT_INLINE = 0, GT_FILL = 1, GT_CACHED = 2 };
 template <int GT>
 __global__ void __launch_bounds__(256) SSIM_WPE_ATTR
 ssim_stats_kernel(const SsimWin win, int W, int H, const float* __restrict__ x, const float* __restrict__ y,
-                  float* __restrict__ maps, float* __restrict__ ssim_sum, float* __restrict__ ystats)
+                  float* __restrict__ maps, float* __restrict__ ssim_sum, float* __restrict__ ystats, float* __restrict__ zero1k)
 {
+    // (workgroup 0, on the side: 1024 floats somebody behind this kernel wants zeroed -- the depth-normal regulariser's loss shards in
+    //  igs_refine_step: one launch less per step)
+    if (blockIdx.x == 0 && zero1k) ((float4*)zero1k)[threadIdx.x] = make_float4(0.f, 0.f, 0.f, 0.f);
     constexpr int NST = GT == GT_CACHED ? 3 : 5;          // blurred planes: x, (y), x x, (y y), x y
     // LDS: the halo of x and y, and the horizontally blurred planes.  IN PLACE (round 4): blur(x) of a halo row goes back into the row it
     // came from (columns 0..31 of sx[r]), blur(y) -- or, with the ground-truth statistics cached, blur(x y) -- into sy[r]; only the
@@ -199,15 +202,16 @@ ssim_stats_kernel(const SsimWin win, int W, int H, const float* __restrict__ x, 
         atomicAdd(&ssim_sum[16 * ((blockIdx.x * 4u + (unsigned)(tid >> 6)) & 63u)], val);
 }
 
-__global__ void __launch_bounds__(256)
-ssim_grad_kernel(const SsimWin win, int W, int H, const float* __restrict__ x, const float* __restrict__ y,
-                 const float* __restrict__ maps, float c_ssim, float c_l1, float* __restrict__ grad, float* __restrict__ l1_sum)
+typedef float SsimGradLds[3][SSIM_H][SSIM_HS];
+// `b`: the workgroup's index among the ssim_grad workgroups (XCD-band mapping, band_tile); `sm`: 22 KB of LDS
+__device__ __forceinline__ void
+ssim_grad_body(SsimGradLds& sm, const unsigned b, const SsimWin& win, int W, int H, const float* __restrict__ x, const float* __restrict__ y,
+               const float* __restrict__ maps, float c_ssim, float c_l1, float* __restrict__ grad, float* __restrict__ l1_sum)
 {
     // (in place, as ssim_stats_kernel: the horizontally blurred row replaces columns 0..31 of the halo row it was computed from, behind
     //  one extra barrier: 22 KB of LDS per workgroup instead of 40 -- six workgroups per CU instead of three)
-    __shared__ __attribute__((aligned(16))) float sm[3][SSIM_H][SSIM_HS];
     unsigned bx, by, bz;
-    if (!band_tile(blockIdx.x, (unsigned)(W + SSIM_T - 1) / SSIM_T, (unsigned)(H + SSIM_T - 1) / SSIM_T, 3u, bx, by, bz)) return;
+    if (!band_tile(b, (unsigned)(W + SSIM_T - 1) / SSIM_T, (unsigned)(H + SSIM_T - 1) / SSIM_T, 3u, bx, by, bz)) return;
     const int tid = threadIdx.x, c = (int)bz;
     const int x0 = (int)bx * SSIM_T - SSIM_R, y0 = (int)by * SSIM_T - SSIM_R;
     const size_t HW = (size_t)W * H;
@@ -287,7 +291,14 @@ ssim_grad_kernel(const SsimWin win, int W, int H, const float* __restrict__ x, c
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) l1 += __shfl_down(l1, off, 64);
     if ((tid & 63) == 0 && l1 != 0.f)
-        atomicAdd(&l1_sum[16 * ((blockIdx.x * 4u + (unsigned)(tid >> 6)) & 63u)], l1);
+        atomicAdd(&l1_sum[16 * ((b * 4u + (unsigned)(tid >> 6)) & 63u)], l1);
+}
+__global__ void __launch_bounds__(256)
+ssim_grad_kernel(const SsimWin win, int W, int H, const float* __restrict__ x, const float* __restrict__ y,
+                 const float* __restrict__ maps, float c_ssim, float c_l1, float* __restrict__ grad, float* __restrict__ l1_sum)
+{
+    __shared__ __attribute__((aligned(16))) SsimGradLds sm;
+    ssim_grad_body(sm, blockIdx.x, win, W, H, x, y, maps, c_ssim, c_l1, grad, l1_sum);
 }
 
 // scratch = { maps [3 channels][3][H][W] | 64 SSIM-sum shards | 64 L1-sum shards } (shards 16 floats apart)
@@ -302,26 +313,6 @@ static inline float* scratch_shards(void* scratch, int width, int height)
 
 // gt_stats (may be NULL): [2][3][H][W] floats of the caller, one buffer per ground-truth image; gt_stats_valid: it holds blur(gt),
 // blur(gt gt) of THIS ground truth already (an earlier call with the same buffer and gt_stats_valid = 0 filled it)
-hipError_t launch_ssim_l1(hipStream_t s, int W, int H, const float* pred, const float* gt, float lambda_dssim, float weight,
-                          void* scratch, float* grad, bool zero_shards, float* gt_stats, bool gt_stats_valid)
-{
-    static const SsimWin win = make_window();
-    float* maps = (float*)scratch;
-    float* shards = scratch_shards(scratch, W, H);
-    if (zero_shards) {
-        const hipError_t e = zero_fill_async(s, shards, 2 * 4096);
-        if (e != hipSuccess) return e;
-    }
-    const dim3 grid(band_grid((unsigned)(W + SSIM_T - 1) / SSIM_T, (unsigned)(H + SSIM_T - 1) / SSIM_T, 3u)), block(256);
-    const float n = 3.f * (float)W * (float)H;
-    if (!gt_stats) hipLaunchKernelGGL(ssim_stats_kernel<GT_INLINE>, grid, block, 0, s, win, W, H, pred, gt, maps, shards, (float*)nullptr);
-    else if (!gt_stats_valid) hipLaunchKernelGGL(ssim_stats_kernel<GT_FILL>, grid, block, 0, s, win, W, H, pred, gt, maps, shards, gt_stats);
-    else hipLaunchKernelGGL(ssim_stats_kernel<GT_CACHED>, grid, block, 0, s, win, W, H, pred, gt, maps, shards, gt_stats);
-    hipLaunchKernelGGL(ssim_grad_kernel, grid, block, 0, s, win, W, H, pred, gt, maps, -lambda_dssim * weight / n,
-                       (1.f - lambda_dssim) * weight / n, grad, shards + 1024);
-    return hipGetLastError();
-}
-
 extern "C" size_t igs_ssim_gt_stats_bytes(int width, int height)
 {
     return (size_t)6 * (size_t)(width > 0 ? width : 0) * (size_t)(height > 0 ? height : 0) * 4;
@@ -372,14 +363,15 @@ struct DnArgs {
 // multiplied by 1 / fx, 1 / fy instead of divided, and the normalisation uses v_rsq_f32 (1 ulp) -- the kernel issued ~600 instructions
 // per wave for 20 bytes per pixel each way.
 #define DN_T 14
-__global__ void __launch_bounds__(256)
-depth_normal_kernel(const DnArgs a)
+#define DN_LDS_FLOATS (2 * (DN_T + 4) * (DN_T + 5) + 3 * (DN_T + 2) * (DN_T + 3) + 2 * (DN_T + 2) * (DN_T + 2) * 6)
+// `b`: the workgroup's index among the depth-normal workgroups; `lds`: DN_LDS_FLOATS floats
+__device__ __forceinline__ void depth_normal_body(float* __restrict__ lds, const unsigned b, const DnArgs& a)
 {
-    __shared__ float dep[2][DN_T + 4][DN_T + 5];
-    __shared__ float rn[3][DN_T + 2][DN_T + 3];
-    __shared__ float G[2][DN_T + 2][DN_T + 2][6];
+    float (*dep)[DN_T + 4][DN_T + 5] = (float (*)[DN_T + 4][DN_T + 5])lds;
+    float (*rn)[DN_T + 2][DN_T + 3] = (float (*)[DN_T + 2][DN_T + 3])(lds + 2 * (DN_T + 4) * (DN_T + 5));
+    float (*G)[DN_T + 2][DN_T + 2][6] = (float (*)[DN_T + 2][DN_T + 2][6])(lds + 2 * (DN_T + 4) * (DN_T + 5) + 3 * (DN_T + 2) * (DN_T + 3));
     unsigned bx, by, bz;
-    if (!band_tile(blockIdx.x, (unsigned)(a.W + DN_T - 1) / DN_T, (unsigned)(a.H + DN_T - 1) / DN_T, 1u, bx, by, bz)) return;
+    if (!band_tile(b, (unsigned)(a.W + DN_T - 1) / DN_T, (unsigned)(a.H + DN_T - 1) / DN_T, 1u, bx, by, bz)) return;
     const int tid = threadIdx.x;
     const int tx0 = (int)bx * DN_T, ty0 = (int)by * DN_T;
     const size_t HW = (size_t)a.W * a.H;
@@ -466,17 +458,83 @@ depth_normal_kernel(const DnArgs a)
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) lsum += __shfl_down(lsum, off, 64);
-    if ((tid & 63) == 0 && lsum != 0.f) atomicAdd(&a.loss_sum[16 * ((blockIdx.x * 4u + (unsigned)(tid >> 6)) & 63u)], lsum);
+    if ((tid & 63) == 0 && lsum != 0.f) atomicAdd(&a.loss_sum[16 * ((b * 4u + (unsigned)(tid >> 6)) & 63u)], lsum);
+}
+__global__ void __launch_bounds__(256)
+depth_normal_kernel(const DnArgs a)
+{
+    __shared__ float lds[DN_LDS_FLOATS];
+    depth_normal_body(lds, blockIdx.x, a);
 }
 
-hipError_t launch_depth_normal(hipStream_t s, int W, int H, float fx, float fy, const float* depth, const float* mdepth, const float* normal,
-                               float weight, float depth_ratio, float* g_depth, float* g_mdepth, float* g_normal, float* loss_shards)
+// ssim_grad AND depth_normal in ONE launch (igs_refine_step with both losses, BASELINE configs[4]): the two kernels are independent (one
+// reads the colour image's statistics maps, the other depth / median depth / normal), each leaves half the chip's bandwidth unused on its
+// own (3.7 and 2.2 TB/s of compulsory traffic), and two kernels on one stream never overlap.  Workgroups come in groups of 8 (one per XCD,
+// so that band_tile keeps its meaning); the groups of the two roles are interleaved in proportion (Bresenham), so both kinds are resident
+// on every CU from the first moment to the last.
+struct MixArgs { unsigned groups_ssim, groups_dn; };
+__global__ void __launch_bounds__(256)
+ssim_grad_dn_kernel(const SsimWin win, int W, int H, const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ maps,
+                    float c_ssim, float c_l1, float* __restrict__ grad, float* __restrict__ l1_sum, const DnArgs dn, const MixArgs mix)
+{
+    __shared__ __attribute__((aligned(16))) SsimGradLds sm;
+    static_assert(sizeof(SsimGradLds) >= DN_LDS_FLOATS * sizeof(float), "the depth-normal stage must fit the SSIM stage's LDS");
+    const unsigned g = blockIdx.x >> 3, xcd = blockIdx.x & 7u, total = mix.groups_ssim + mix.groups_dn;
+    // groups [0, total): group g is an SSIM group iff floor((g + 1) S / total) > floor(g S / total); `before` SSIM groups precede it
+    const unsigned before = (unsigned)(((unsigned long long)g * mix.groups_ssim) / total);
+    const bool is_ssim = (unsigned)(((unsigned long long)(g + 1) * mix.groups_ssim) / total) > before;
+    if (is_ssim) ssim_grad_body(sm, before * 8u + xcd, win, W, H, x, y, maps, c_ssim, c_l1, grad, l1_sum);
+    else depth_normal_body(&sm[0][0][0], (g - before) * 8u + xcd, dn);
+}
+
+static DnArgs make_dn_args(int W, int H, float fx, float fy, const float* depth, const float* mdepth, const float* normal, float weight,
+                           float depth_ratio, float* g_depth, float* g_mdepth, float* g_normal, float* loss_shards)
 {
     DnArgs a;
     a.W = W; a.H = H; a.fx = fx; a.fy = fy; a.inv_fx = 1.0f / fx; a.inv_fy = 1.0f / fy; a.depth = depth; a.mdepth = mdepth; a.normal = normal;
     const float n = (float)W * (float)H;
     a.s0 = weight * (1.f - depth_ratio) / n; a.s1 = weight * depth_ratio / n;
     a.g_depth = g_depth; a.g_mdepth = g_mdepth; a.g_normal = g_normal; a.loss_sum = loss_shards;
+    return a;
+}
+
+// `dn` (igs_refine_step with both losses): the depth-normal regulariser rides in the same launch as ssim_grad, and its loss shards are
+// zeroed by workgroup 0 of ssim_stats
+hipError_t launch_ssim_l1(hipStream_t s, int W, int H, const float* pred, const float* gt, float lambda_dssim, float weight,
+                          void* scratch, float* grad, bool zero_shards, float* gt_stats, bool gt_stats_valid, const DepthNormalJob* dn)
+{
+    static const SsimWin win = make_window();
+    float* maps = (float*)scratch;
+    float* shards = scratch_shards(scratch, W, H);
+    if (zero_shards) {
+        const hipError_t e = zero_fill_async(s, shards, 2 * 4096);
+        if (e != hipSuccess) return e;
+    }
+    const unsigned n_ssim = band_grid((unsigned)(W + SSIM_T - 1) / SSIM_T, (unsigned)(H + SSIM_T - 1) / SSIM_T, 3u);
+    const dim3 grid(n_ssim), block(256);
+    const float n = 3.f * (float)W * (float)H;
+    float* z = dn ? dn->loss_shards : nullptr;
+    if (!gt_stats) hipLaunchKernelGGL(ssim_stats_kernel<GT_INLINE>, grid, block, 0, s, win, W, H, pred, gt, maps, shards, (float*)nullptr, z);
+    else if (!gt_stats_valid) hipLaunchKernelGGL(ssim_stats_kernel<GT_FILL>, grid, block, 0, s, win, W, H, pred, gt, maps, shards, gt_stats, z);
+    else hipLaunchKernelGGL(ssim_stats_kernel<GT_CACHED>, grid, block, 0, s, win, W, H, pred, gt, maps, shards, gt_stats, z);
+    if (!dn) {
+        hipLaunchKernelGGL(ssim_grad_kernel, grid, block, 0, s, win, W, H, pred, gt, maps, -lambda_dssim * weight / n,
+                           (1.f - lambda_dssim) * weight / n, grad, shards + 1024);
+    } else {
+        const DnArgs da = make_dn_args(W, H, dn->fx, dn->fy, dn->depth, dn->mdepth, dn->normal, dn->weight, dn->depth_ratio, dn->g_depth,
+                                       dn->g_mdepth, dn->g_normal, dn->loss_shards);
+        const unsigned n_dn = band_grid((unsigned)(W + DN_T - 1) / DN_T, (unsigned)(H + DN_T - 1) / DN_T, 1u);
+        MixArgs mix; mix.groups_ssim = n_ssim / 8u; mix.groups_dn = n_dn / 8u;
+        hipLaunchKernelGGL(ssim_grad_dn_kernel, dim3(n_ssim + n_dn), block, 0, s, win, W, H, pred, gt, maps, -lambda_dssim * weight / n,
+                           (1.f - lambda_dssim) * weight / n, grad, shards + 1024, da, mix);
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_depth_normal(hipStream_t s, int W, int H, float fx, float fy, const float* depth, const float* mdepth, const float* normal,
+                               float weight, float depth_ratio, float* g_depth, float* g_mdepth, float* g_normal, float* loss_shards)
+{
+    const DnArgs a = make_dn_args(W, H, fx, fy, depth, mdepth, normal, weight, depth_ratio, g_depth, g_mdepth, g_normal, loss_shards);
     hipLaunchKernelGGL(depth_normal_kernel, dim3(band_grid((unsigned)(W + DN_T - 1) / DN_T, (unsigned)(H + DN_T - 1) / DN_T, 1u)), dim3(256), 0, s, a);
     return hipGetLastError();
 }

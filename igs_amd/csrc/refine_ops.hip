@@ -101,14 +101,28 @@ extern "C" int igs_adam_step_groups(void* stream, int ngroups, const size_t* off
 
 // The same update over up to 8 SEPARATE tensors in one launch (igs_amd/optim.py: a torch.optim.Optimizer whose parameters are ordinary
 // nn.Parameters, each with its own gradient / moment allocation and its own step count).  blockIdx.y = tensor.
-struct AdamMulti { int n; float* p[8]; const float* g[8]; float* m[8]; float* v[8]; size_t cnt[8]; float lr_over_bc1[8]; float inv_sqrt_bc2[8]; };
+struct AdamMulti { int n; float* p[8]; const float* g[8]; float* m[8]; float* v[8]; size_t cnt[8]; float lr_over_bc1[8]; float inv_sqrt_bc2[8]; const float* step[8]; };
+// DEV_STEP: the step counts live in device memory (one float per tensor, torch.optim.Adam's `capturable` layout), so that the launch can
+// be replayed from a hipGraph: the bias corrections are computed here (in double, as the host does) instead of arriving as arguments,
+// and lr_over_bc1 holds the plain learning rate
+template <bool DEV_STEP>
 __global__ void __launch_bounds__(256)
 adam_multi_kernel(const AdamMulti G, float b1, float b2, float eps)
 {
     const int k = blockIdx.y;
     if (k >= G.n) return;
     const size_t n = G.cnt[k];
-    const float lr = G.lr_over_bc1[k], isb = G.inv_sqrt_bc2[k];
+    float lr = G.lr_over_bc1[k], isb = G.inv_sqrt_bc2[k];
+    if (DEV_STEP) {
+        __shared__ float bc[2];
+        if (threadIdx.x == 0) {
+            const double t = (double)G.step[k][0];
+            bc[0] = (float)((double)lr / (1.0 - pow((double)b1, t)));
+            bc[1] = (float)(1.0 / sqrt(1.0 - pow((double)b2, t)));
+        }
+        __syncthreads();
+        lr = bc[0]; isb = bc[1];
+    }
     float* pp = G.p[k]; const float* gg = G.g[k]; float* mm = G.m[k]; float* vv = G.v[k];
     const bool aligned = (((uintptr_t)pp | (uintptr_t)gg | (uintptr_t)mm | (uintptr_t)vv) & 15) == 0;
     const size_t n4 = aligned ? n / 4 : 0;
@@ -133,26 +147,58 @@ adam_multi_kernel(const AdamMulti G, float b1, float b2, float eps)
         pp[i] -= lr * mi / (sqrtf(vi) * isb + eps);
     }
 }
-extern "C" int igs_adam_step_multi(void* stream, int ntensors, float* const* param, const float* const* grad, float* const* exp_avg,
-                                   float* const* exp_avg_sq, const size_t* count, const float* lr, const float* bias_correction1,
-                                   const float* bias_correction2_sqrt, float beta1, float beta2, float eps)
+struct StepPtrs { int n; float* step[8]; };
+__global__ void adam_count_step_kernel(const StepPtrs S)
+{
+    if ((int)threadIdx.x < S.n) S.step[threadIdx.x][0] += 1.0f;
+}
+static int adam_multi(void* stream, int ntensors, float* const* param, const float* const* grad, float* const* exp_avg,
+                      float* const* exp_avg_sq, const size_t* count, const float* lr, const float* bias_correction1,
+                      const float* bias_correction2_sqrt, float* const* step, float beta1, float beta2, float eps)
 {
     if (ntensors <= 0) return 0;
-    if (ntensors > 8 || !param || !grad || !exp_avg || !exp_avg_sq || !count || !lr || !bias_correction1 || !bias_correction2_sqrt)
-        return IGS_RAST_E_INVALID;
+    if (ntensors > 8 || !param || !grad || !exp_avg || !exp_avg_sq || !count || !lr) return IGS_RAST_E_INVALID;
+    if (!step && (!bias_correction1 || !bias_correction2_sqrt)) return IGS_RAST_E_INVALID;
     AdamMulti G; G.n = ntensors;
+    StepPtrs S; S.n = ntensors;
     size_t nmax = 0;
     for (int k = 0; k < ntensors; k++) {
         if (count[k] && (!param[k] || !grad[k] || !exp_avg[k] || !exp_avg_sq[k])) return IGS_RAST_E_INVALID;
+        if (step && !step[k]) return IGS_RAST_E_INVALID;
         G.p[k] = param[k]; G.g[k] = grad[k]; G.m[k] = exp_avg[k]; G.v[k] = exp_avg_sq[k]; G.cnt[k] = count[k];
-        G.lr_over_bc1[k] = lr[k] / bias_correction1[k]; G.inv_sqrt_bc2[k] = 1.0f / bias_correction2_sqrt[k];
+        G.lr_over_bc1[k] = step ? lr[k] : lr[k] / bias_correction1[k]; G.inv_sqrt_bc2[k] = step ? 1.0f : 1.0f / bias_correction2_sqrt[k];
+        G.step[k] = step ? step[k] : nullptr; S.step[k] = step ? step[k] : nullptr;
         if (count[k] > nmax) nmax = count[k];
     }
     size_t blocks = (nmax / 4 + 255) / 256;
     if (blocks > 1024) blocks = 1024;
     if (blocks == 0) blocks = 1;
-    hipLaunchKernelGGL(adam_multi_kernel, dim3((unsigned)blocks, (unsigned)ntensors), dim3(256), 0, (hipStream_t)stream, G, beta1, beta2, eps);
+    const dim3 grid((unsigned)blocks, (unsigned)ntensors);
+    if (step) {
+        for (int a = 0; a < ntensors; a++)
+            for (int b = a + 1; b < ntensors; b++)
+                if (step[a] == step[b]) return IGS_RAST_E_INVALID;              // (one counter per tensor: each is advanced once)
+        hipLaunchKernelGGL(adam_count_step_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, S);
+        hipLaunchKernelGGL(adam_multi_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, G, beta1, beta2, eps);
+    } else {
+        hipLaunchKernelGGL(adam_multi_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, G, beta1, beta2, eps);
+    }
     return hipGetLastError() == hipSuccess ? 0 : IGS_RAST_E_HIP;
+}
+extern "C" int igs_adam_step_multi(void* stream, int ntensors, float* const* param, const float* const* grad, float* const* exp_avg,
+                                   float* const* exp_avg_sq, const size_t* count, const float* lr, const float* bias_correction1,
+                                   const float* bias_correction2_sqrt, float beta1, float beta2, float eps)
+{
+    if (!bias_correction1 || !bias_correction2_sqrt) return ntensors <= 0 ? 0 : IGS_RAST_E_INVALID;
+    return adam_multi(stream, ntensors, param, grad, exp_avg, exp_avg_sq, count, lr, bias_correction1, bias_correction2_sqrt, nullptr, beta1,
+                      beta2, eps);
+}
+extern "C" int igs_adam_step_multi_dev(void* stream, int ntensors, float* const* param, const float* const* grad, float* const* exp_avg,
+                                       float* const* exp_avg_sq, const size_t* count, const float* lr, float* const* step, float beta1,
+                                       float beta2, float eps)
+{
+    if (!step) return ntensors <= 0 ? 0 : IGS_RAST_E_INVALID;
+    return adam_multi(stream, ntensors, param, grad, exp_avg, exp_avg_sq, count, lr, nullptr, nullptr, step, beta1, beta2, eps);
 }
 
 // mean |pred - gt| and its gradient in ONE launch, the value finished on the device: every workgroup leaves its partial sum in
@@ -167,15 +213,28 @@ l1_mean_kernel(size_t n4, size_t n, const float* __restrict__ pred, const float*
     __shared__ bool last;
     const size_t stride = (size_t)gridDim.x * 256;
     float acc = 0.f;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
-        const float4 a = ((const float4*)pred)[i], b = ((const float4*)gt)[i];
-        float4 g;
-        float d;
-        d = a.x - b.x; acc += fabsf(d); g.x = d > 0.f ? inv_n : (d < 0.f ? -inv_n : 0.f);
-        d = a.y - b.y; acc += fabsf(d); g.y = d > 0.f ? inv_n : (d < 0.f ? -inv_n : 0.f);
-        d = a.z - b.z; acc += fabsf(d); g.z = d > 0.f ? inv_n : (d < 0.f ? -inv_n : 0.f);
-        d = a.w - b.w; acc += fabsf(d); g.w = d > 0.f ? inv_n : (d < 0.f ? -inv_n : 0.f);
-        ((float4*)grad)[i] = g;
+    // four float4 pairs per thread in flight before the first is used: with one pair per loop trip (and `s_waitcnt vmcnt(0)` behind it) a
+    // wave had 2 KB outstanding and the kernel streamed its 49 MB at 1.2 TB/s (40 us at 1352 x 1014)
+    for (size_t base = (size_t)blockIdx.x * 1024 + threadIdx.x; base < n4; base += stride * 4) {
+        float4 a[4], b[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const size_t i = base + (size_t)u * 256;
+            if (i < n4) { a[u] = ((const float4*)pred)[i]; b[u] = ((const float4*)gt)[i]; }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const size_t i = base + (size_t)u * 256;
+            if (i < n4) {
+                float4 g;
+                float d;
+                d = a[u].x - b[u].x; acc += fabsf(d); g.x = d > 0.f ? inv_n : (d < 0.f ? -inv_n : 0.f);
+                d = a[u].y - b[u].y; acc += fabsf(d); g.y = d > 0.f ? inv_n : (d < 0.f ? -inv_n : 0.f);
+                d = a[u].z - b[u].z; acc += fabsf(d); g.z = d > 0.f ? inv_n : (d < 0.f ? -inv_n : 0.f);
+                d = a[u].w - b[u].w; acc += fabsf(d); g.w = d > 0.f ? inv_n : (d < 0.f ? -inv_n : 0.f);
+                ((float4*)grad)[i] = g;
+            }
+        }
     }
     for (size_t i = n4 * 4 + (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
         const float d = pred[i] - gt[i];
@@ -187,21 +246,35 @@ l1_mean_kernel(size_t n4, size_t n, const float* __restrict__ pred, const float*
     if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = acc;
     __syncthreads();
     if (threadIdx.x == 0) {
-        partials[blockIdx.x] = ws[0] + ws[1] + ws[2] + ws[3];
-        __threadfence();
-        last = atomicAdd(counter, 1u) == gridDim.x - 1;
+        // Publish the partial sum WITHOUT a device-scope release fence: on this GPU `__threadfence()` is `buffer_wbl2 sc1` -- write back
+        // every dirty line of the XCD's L2 -- and this kernel has just stored 16 MB of gradient through that L2: a thousand workgroups
+        // each waiting for such a write-back made the kernel take 40 us for 49 MB of traffic (round 4; the two-level counter and the
+        // four loads in flight below changed nothing until the fences went).  An agent-scope atomic store is written through by itself;
+        // `s_waitcnt vmcnt(0)` holds the counter increment back until it has been acknowledged.
+        __hip_atomic_store(partials + blockIdx.x, ws[0] + ws[1] + ws[2] + ws[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // "who is last" over two levels (groups of 32 workgroups, then the groups; the group words 256 bytes apart): returning atomics on
+        // one address retire one by one, and the workgroups of a streaming kernel all finish together
+        const unsigned g = blockIdx.x >> 5, ng = (gridDim.x + 31u) >> 5;
+        const unsigned gsize = (g == ng - 1u) ? gridDim.x - (g << 5) : 32u;
+        bool l = false;
+        if (__hip_atomic_fetch_add(counter + 64u * (1u + g), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gsize - 1u) {
+            __hip_atomic_store(counter + 64u * (1u + g), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            l = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == ng - 1u;
+        }
+        last = l;
     }
     __syncthreads();
     if (!last) return;
-    __threadfence();
     float t = 0.f;
-    for (unsigned i = threadIdx.x; i < gridDim.x; i += 256) t += __builtin_nontemporal_load(partials + i);      // (fixed order per lane)
+    for (unsigned i = threadIdx.x; i < gridDim.x; i += 256)                       // (fixed order per lane; agent-scope loads: not from a stale L2 line)
+        t += __hip_atomic_load(partials + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) t += __shfl_down(t, off, 64);
     __syncthreads();
     if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = t;
     __syncthreads();
-    if (threadIdx.x == 0) { mean_out[0] = (ws[0] + ws[1] + ws[2] + ws[3]) * inv_n; *counter = 0u; }
+    if (threadIdx.x == 0) { mean_out[0] = (ws[0] + ws[1] + ws[2] + ws[3]) * inv_n; __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 }
 extern "C" int igs_l1_mean_fwd_bwd(void* stream, size_t n, const float* pred, const float* gt, float* grad, float* mean_out, float* partials,
                                    unsigned* counter)
@@ -210,7 +283,7 @@ extern "C" int igs_l1_mean_fwd_bwd(void* stream, size_t n, const float* pred, co
     if (!pred || !gt || !grad || !mean_out || !partials || !counter) return IGS_RAST_E_INVALID;
     const bool aligned = (((uintptr_t)pred | (uintptr_t)gt | (uintptr_t)grad) & 15) == 0;
     const size_t n4 = aligned ? n / 4 : 0;
-    size_t blocks = (n / 4 + 255) / 256;
+    size_t blocks = (n / 4 + 1023) / 1024;          // (1024 float4 per workgroup and trip)
     if (blocks > 1024) blocks = 1024;
     if (blocks == 0) blocks = 1;
     hipLaunchKernelGGL(l1_mean_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, n4, n, pred, gt, grad, mean_out, partials, counter,

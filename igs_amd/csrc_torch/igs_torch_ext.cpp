@@ -233,13 +233,17 @@ Tensor mark_visible(const Tensor& means3D, const Tensor& viewmatrix, const Tenso
 // igs_adam_step_multi over lists of tensors (igs_amd/optim.py): one launch for up to 8 parameters
 void adam_step_multi(const std::vector<Tensor>& params, const std::vector<Tensor>& grads, const std::vector<Tensor>& exp_avgs,
                      const std::vector<Tensor>& exp_avg_sqs, const std::vector<double>& lrs, const std::vector<double>& bc1,
-                     const std::vector<double>& bc2_sqrt, double beta1, double beta2, double eps)
+                     const std::vector<double>& bc2_sqrt, double beta1, double beta2, double eps, const std::vector<Tensor>& steps)
 {
+    // `steps` (optional): one float32 GPU scalar per tensor = the step count, advanced on the device (igs_adam_step_multi_dev; bc1 /
+    // bc2_sqrt are then ignored) -- the form a hipGraph can replay
     const size_t n = params.size();
     if (n == 0) return;
-    if (n > 8 || grads.size() != n || exp_avgs.size() != n || exp_avg_sqs.size() != n || lrs.size() != n || bc1.size() != n || bc2_sqrt.size() != n)
+    const bool dev_step = !steps.empty();
+    if (n > 8 || grads.size() != n || exp_avgs.size() != n || exp_avg_sqs.size() != n || lrs.size() != n
+        || (dev_step ? steps.size() != n : (bc1.size() != n || bc2_sqrt.size() != n)))
         throw RasterizerError("adam_step_multi: between 1 and 8 tensors, all lists of the same length");
-    float* p[8]; const float* g[8]; float* m[8]; float* v[8]; size_t cnt[8]; float lr[8], b1c[8], b2c[8];
+    float* p[8]; const float* g[8]; float* m[8]; float* v[8]; size_t cnt[8]; float lr[8], b1c[8], b2c[8]; float* st[8];
     std::vector<Tensor> keep;
     const c10::Device dev = params[0].device();
     for (size_t k = 0; k < n; k++) {
@@ -250,17 +254,31 @@ void adam_step_multi(const std::vector<Tensor>& params, const std::vector<Tensor
         Tensor G = (grads[k].is_contiguous() && grads[k].scalar_type() == at::kFloat) ? grads[k] : grads[k].to(at::kFloat).contiguous();
         keep.push_back(G);
         p[k] = P_.data_ptr<float>(); g[k] = G.data_ptr<float>(); m[k] = exp_avgs[k].data_ptr<float>(); v[k] = exp_avg_sqs[k].data_ptr<float>();
-        cnt[k] = (size_t)P_.numel(); lr[k] = (float)lrs[k]; b1c[k] = (float)bc1[k]; b2c[k] = (float)bc2_sqrt[k];
+        cnt[k] = (size_t)P_.numel(); lr[k] = (float)lrs[k];
+        if (dev_step) {
+            const Tensor& S_ = steps[k];
+            if (!S_.is_cuda() || S_.device() != dev || S_.scalar_type() != at::kFloat || S_.numel() != 1)
+                throw RasterizerError("adam_step_multi: every step count must be a one-element float32 tensor on the parameters' GPU");
+            st[k] = S_.data_ptr<float>();
+        } else {
+            b1c[k] = (float)bc1[k]; b2c[k] = (float)bc2_sqrt[k];
+        }
     }
     const c10::hip::HIPGuardMasqueradingAsCUDA guard(dev);
-    const int rc = igs_adam_step_multi(c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(dev.index()).stream(), (int)n, p, g, m, v, cnt, lr, b1c, b2c, (float)beta1,
-                                       (float)beta2, (float)eps);
+    hipStream_t stream = c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(dev.index()).stream();
+    const int rc = dev_step ? igs_adam_step_multi_dev(stream, (int)n, p, g, m, v, cnt, lr, st, (float)beta1, (float)beta2, (float)eps)
+                            : igs_adam_step_multi(stream, (int)n, p, g, m, v, cnt, lr, b1c, b2c, (float)beta1, (float)beta2, (float)eps);
     if (rc != 0) throw RasterizerError("igs_adam_step_multi failed: " + std::to_string(rc));
 }
 
 // ---- the two image losses of the refine loop as single calls (igs_amd/losses.py wraps them in autograd Functions) ----
 // small per-(device, stream) scratch kept for the life of the process
 struct LossScratch { Tensor l1; Tensor ssim; int64_t ssim_w = 0, ssim_h = 0; };
+bool stream_is_capturing(hipStream_t stream)
+{
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    return hipStreamIsCapturing(stream, &st) == hipSuccess && st != hipStreamCaptureStatusNone;
+}
 LossScratch& loss_scratch(const c10::Device& dev, hipStream_t stream)
 {
     static std::mutex mu;
@@ -277,12 +295,19 @@ std::tuple<Tensor, Tensor> l1_mean(const Tensor& a, const Tensor& b)
     const c10::hip::HIPGuardMasqueradingAsCUDA guard(dev);
     In x(a, dev, "a"), y(b, dev, "b");
     hipStream_t stream = c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(dev.index()).stream();
-    LossScratch& sc = loss_scratch(dev, stream);
     auto fopt = at::TensorOptions().dtype(at::kFloat).device(dev);
-    if (!sc.l1.defined()) sc.l1 = at::zeros({1025}, fopt);            // 1024 partial sums | the self-resetting counter word
+    // 1024 partial sums | the self-resetting counter words: kept per (device, stream) -- except on a capturing stream, where the scratch
+    // must be memory the graph owns (allocated here, from the capture's private pool, zeroed by a node of the graph)
+    Tensor l1s;
+    if (stream_is_capturing(stream)) l1s = at::zeros({1024 + 33 * 64}, fopt);
+    else {
+        LossScratch& sc = loss_scratch(dev, stream);
+        if (!sc.l1.defined()) sc.l1 = at::zeros({1024 + 33 * 64}, fopt);
+        l1s = sc.l1;
+    }
     Tensor grad = at::empty_like(x.keep), out = at::empty({}, fopt);
     const int rc = igs_l1_mean_fwd_bwd(stream, (size_t)x.keep.numel(), x.p, y.p, grad.data_ptr<float>(), out.data_ptr<float>(),
-                                       sc.l1.data_ptr<float>(), (unsigned*)(sc.l1.data_ptr<float>() + 1024));
+                                       l1s.data_ptr<float>(), (unsigned*)(l1s.data_ptr<float>() + 1024));
     if (rc != 0) throw RasterizerError("igs_l1_mean_fwd_bwd failed: " + std::to_string(rc));
     return { out, grad };
 }
@@ -298,14 +323,20 @@ std::tuple<Tensor, Tensor> ssim_mean(const Tensor& a, const Tensor& b)
     const int64_t H = a.size(-2), W = a.size(-1);
     if (a.numel() != 3 * H * W) throw RasterizerError("ssim_mean: one 3-channel image per side");
     hipStream_t stream = c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(dev.index()).stream();
-    LossScratch& sc = loss_scratch(dev, stream);
-    if (!sc.ssim.defined() || sc.ssim_w != W || sc.ssim_h != H) {
-        sc.ssim = at::empty({(int64_t)igs_ssim_l1_scratch_bytes((int)W, (int)H)}, at::TensorOptions().dtype(at::kByte).device(dev));
-        sc.ssim_w = W; sc.ssim_h = H;
+    Tensor scratch;
+    const auto bopt = at::TensorOptions().dtype(at::kByte).device(dev);
+    if (stream_is_capturing(stream)) scratch = at::empty({(int64_t)igs_ssim_l1_scratch_bytes((int)W, (int)H)}, bopt);      // (graph-owned, as in l1_mean)
+    else {
+        LossScratch& sc = loss_scratch(dev, stream);
+        if (!sc.ssim.defined() || sc.ssim_w != W || sc.ssim_h != H) {
+            sc.ssim = at::empty({(int64_t)igs_ssim_l1_scratch_bytes((int)W, (int)H)}, bopt);
+            sc.ssim_w = W; sc.ssim_h = H;
+        }
+        scratch = sc.ssim;
     }
     auto fopt = at::TensorOptions().dtype(at::kFloat).device(dev);
     Tensor grad = at::empty_like(x.keep), sums = at::empty({2048}, fopt);
-    const int rc = igs_ssim_l1_loss_fwd_bwd(stream, (int)W, (int)H, x.p, y.p, 1.0f, 1.0f, sc.ssim.data_ptr(), grad.data_ptr<float>(), sums.data_ptr<float>());
+    const int rc = igs_ssim_l1_loss_fwd_bwd(stream, (int)W, (int)H, x.p, y.p, 1.0f, 1.0f, scratch.data_ptr(), grad.data_ptr<float>(), sums.data_ptr<float>());
     if (rc != 0) throw RasterizerError("igs_ssim_l1_loss_fwd_bwd failed: " + std::to_string(rc));
     Tensor mean = sums.narrow(0, 0, 1024).sum() / (double)x.keep.numel();
     return { mean, grad };               // grad = d(1 - mean SSIM)/da: the caller negates
@@ -388,7 +419,9 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
         check(rc, "igs_rast_forward_finish");
         return py::int_(rc);
     });
-    m.def("adam_step_multi", &adam_step_multi, py::call_guard<py::gil_scoped_release>());
+    m.def("adam_step_multi", &adam_step_multi, py::arg("params"), py::arg("grads"), py::arg("exp_avgs"), py::arg("exp_avg_sqs"), py::arg("lrs"),
+          py::arg("bias_correction1"), py::arg("bias_correction2_sqrt"), py::arg("beta1"), py::arg("beta2"), py::arg("eps"),
+          py::arg("steps") = std::vector<Tensor>(), py::call_guard<py::gil_scoped_release>());
     m.def("l1_mean", &l1_mean, py::arg("a"), py::arg("b"), py::call_guard<py::gil_scoped_release>());
     m.def("ssim_mean", &ssim_mean, py::arg("a"), py::arg("b"), py::call_guard<py::gil_scoped_release>());
     m.def("abi_version", []() { return igs_rast_version(); });

@@ -12,7 +12,9 @@ Layers (reference file:line in parentheses; DGR = submodules/RaDe-GS/submodules/
 torch is used for device memory and the current stream only; all arithmetic runs in libigs_rast.so.
 There is no CPU path: calling these functions without the HIP library / the compiled module / a GPU raises.
 """
+import contextlib
 import ctypes as C
+import threading
 from typing import NamedTuple
 
 import torch
@@ -79,6 +81,57 @@ class _ScratchPool:
 _POOL = _ScratchPool()
 
 
+class CaptureScratch:
+    """Scratch sets for a FAMILY of captured graphs that never run concurrently (igs_amd/graphs.py: one graph per view, replayed on one
+    stream).  A forward recorded with a fresh, graph-owned set has to zero-fill that set inside the graph -- its memory goes back to the
+    graph's pool between the backward and the next replay's forward -- which costs ~30 us per replay at 1352 x 1014.  Inside
+    `capture_scratch(holder)` the n-th render of the body always takes the holder's n-th set instead: created and grown by the EAGER
+    visit (ordinary allocator memory, born zero-filled, left clean by every forward + backward pair), then baked into every graph of
+    the family.  The holder must outlive the graphs; a set that would have to grow while capturing (larger slabs than the eager
+    visit needed) is refused loudly."""
+
+    def __init__(self):
+        self.sets, self._n = {}, {}
+
+    def begin(self):
+        self._n = {}
+
+    def take(self, key, capturing):
+        k = key[:4]
+        i = self._n.get(k, 0)
+        self._n[k] = i + 1
+        lst = self.sets.setdefault(k, [])
+        if i < len(lst):
+            return lst[i]
+        if capturing:
+            return None                    # no eager visit has made this one: a graph-owned set (and its zero-fill) after all
+        lst.append(ScratchSet(k[3], True))
+        return lst[i]
+
+    def discard(self, item):
+        for lst in self.sets.values():
+            if item in lst:
+                lst.remove(item)
+
+
+_TLS = threading.local()
+
+
+@contextlib.contextmanager
+def capture_scratch(holder):
+    prev = getattr(_TLS, "scope", None)
+    _TLS.scope = holder
+    holder.begin()
+    try:
+        yield holder
+    finally:
+        _TLS.scope = prev
+
+
+def _set_addresses(ss):
+    return tuple(t.data_ptr() if t is not None and t.numel() else 0 for t in (ss.geom, ss.binning, ss.img))
+
+
 class _Lease:
     """Returns its scratch set to the pool when the owning autograd context is garbage-collected.
 
@@ -86,12 +139,29 @@ class _Lease:
     must be memory the GRAPH owns -- it is allocated fresh while capturing (from the graph's private memory pool, which the
     graph keeps reserved for as long as it lives) and never handed to `_POOL`, where an eager call with the same key would
     share it and a pool eviction would let the allocator recycle it under later replays."""
-    __slots__ = ("key", "item", "pooled")
+    __slots__ = ("key", "item", "pooled", "scope", "baked")
 
     def __init__(self, key, capturing):
         self.key = key
+        self.scope = getattr(_TLS, "scope", None)
+        self.baked = None
+        if self.scope is not None:
+            item = self.scope.take(key, capturing)
+            if item is not None:
+                self.pooled, self.item = False, item
+                if capturing:
+                    self.baked = _set_addresses(item)
+                return
         self.pooled = not capturing
         self.item = _POOL.acquire(key) if self.pooled else ScratchSet(key[3], True)
+
+    def check_baked(self):
+        """After a forward recorded into a graph with a set of a CaptureScratch holder: the set must not have grown (new memory
+        would belong to the graph's pool while the holder hands the set to eager calls and other graphs)."""
+        if self.baked is not None and _set_addresses(self.item) != self.baked:
+            self.scope.discard(self.item)
+            raise RasterizerError("the scratch set of this capture family had to grow while capturing (the eager visit needed less): "
+                                  "run the body eagerly once more, then capture again")
 
     def __del__(self):
         try:
@@ -133,13 +203,15 @@ def rasterize_finish():
     return _C.forward_finish()
 
 
-def capture_status():
+def capture_status(any_capture=False):
     """(num_rendered, overflow) of the last forward of this host thread on the current device -- for forwards that ran as part of
     a replayed graph (`torch.cuda.graph`), after the caller has synchronised.  overflow != 0: a tile needed that many instance
     slots and the slabs baked into the capture were smaller; the results of that replay are invalid -- capture again (the slab
-    hint has been raised)."""
+    hint has been raised).  `any_capture=True`: whatever the last executed forward posted, for callers who replay several graphs
+    in turn (the strict form only accepts the most recently captured one)."""
     n, ov, pf = C.c_int(0), C.c_uint(0), C.c_uint(0)
-    _check(_cabi.lib().igs_rast_last_status(C.byref(n), C.byref(ov), C.byref(pf)), "igs_rast_last_status")
+    fn = _cabi.lib().igs_rast_last_posted_status if any_capture else _cabi.lib().igs_rast_last_status
+    _check(fn(C.byref(n), C.byref(ov), C.byref(pf)), "igs_rast_last_status")
     if pf.value:
         raise RasterizerError("Point is filtered although prefiltered is set. This shouldn't happen!")
     return n.value, ov.value
@@ -227,6 +299,8 @@ def _make_function(clamp_grads):
             else:
                 # (pooled / capture-owned sets are born zero-filled and touched by this library only: no per-frame zero-fill launch)
                 out = _C.rasterize_gaussians(*args, scratch=ss, mode=mode, scratch_clean=ss is not None)
+            if lease is not None and lease.baked is not None:
+                lease.check_baked()
             num_rendered, color, coord, mcoord, alpha, normal, depth, mdepth, radii, geomBuffer, binningBuffer, imgBuffer = out
             ctx.raster_settings = rs
             ctx.num_rendered = num_rendered

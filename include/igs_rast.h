@@ -137,6 +137,9 @@ int igs_rast_forward_nowait(
     float* out_color, float* out_coord, float* out_mcoord, float* out_depth, float* out_mdepth, float* out_alpha,
     float* out_normal, int* radii, int require_coord, int require_depth, int debug);
 int igs_rast_last_status(int* num_rendered, unsigned* overflow, unsigned* prefilter_flag);
+/* The same without the sequence check, for callers who replay SEVERAL captured graphs in turn (only the last capture's number is
+ * remembered) and know that a forward has run since: what the last forward that EXECUTED on this thread's slot posted. */
+int igs_rast_last_posted_status(int* num_rendered, unsigned* overflow, unsigned* prefilter_flag);
 
 /* One-shot promise for the NEXT igs_rast_forward / _async / _nowait of the calling thread: the image buffer its callback will hand out
  * was zero-filled when it was allocated and has been used by this library only since.  Every slab-binned forward leaves the binning
@@ -268,6 +271,13 @@ int igs_adam_step_multi(void* stream, int ntensors, float* const* param, const f
                         float* const* exp_avg_sq, const size_t* count, const float* lr, const float* bias_correction1,
                         const float* bias_correction2_sqrt, float beta1, float beta2, float eps);
 
+/* The same with the step counts in DEVICE memory (step[k]: one float per tensor, the layout of torch.optim.Adam(capturable=True)): a
+ * one-thread launch advances every count by 1, then the update computes its bias corrections from them.  Nothing of the call depends
+ * on host state that changes from step to step, so it can be captured into a hipGraph and replayed. */
+int igs_adam_step_multi_dev(void* stream, int ntensors, float* const* param, const float* const* grad, float* const* exp_avg,
+                            float* const* exp_avg_sq, const size_t* count, const float* lr, float* const* step, float beta1, float beta2,
+                            float eps);
+
 /* ---- one whole refine iteration on one view, single GPU --------------------------------------------------------------
  * Native form of the body of the reference's per-frame refine loop (infer_batch.py:279-324 with the L1 photometric loss,
  * igs/utils/loss_utils.py:17; activations of igs/models/gaussian_model.py:90-127; torch.optim.Adam of :295-348):
@@ -389,7 +399,7 @@ int igs_depth_normal_loss_fwd_bwd(void* stream, int width, int height, float tan
  * the caller: same-address atomics would serialise). */
 int igs_l1_loss_fwd_bwd(void* stream, size_t n, const float* pred, const float* gt, float* grad, float* loss_sum, float scale);
 /* The same with the VALUE finished on the device, in one launch: mean_out[0] = mean |pred - gt|, grad[i] = sign(pred[i] - gt[i]) / n.
- * partials: 1024 floats of scratch; counter: one word that is zero on entry and zero again on exit (a buffer the caller zero-fills once
+ * partials: 1024 floats of scratch; counter: 33 * 64 words (2112) that are zero on entry and zero again on exit (a buffer the caller zero-fills once
  * and keeps; calls that share it must be ordered on one stream). */
 int igs_l1_mean_fwd_bwd(void* stream, size_t n, const float* pred, const float* gt, float* grad, float* mean_out, float* partials,
                         unsigned* counter);

@@ -227,6 +227,98 @@ def test_unchanged_caller_loop_equals_the_fused_step(dev, loss):
             assert float(d.max()) <= 2.05 * lr * steps, (optimizer, k, float(d.max()))
 
 
+def test_capturable_adam_counts_its_steps_on_the_device(dev, monkeypatch):
+    """igs_amd.optim.Adam(capturable=True): `state[p]["step"]` is a GPU scalar advanced by the launch (igs_adam_step_multi_dev), the bias
+    corrections come from it -- eagerly and replayed from a hipGraph it must walk with torch.optim.Adam."""
+    from igs_amd.optim import Adam
+    gen = torch.Generator().manual_seed(5)
+    shapes = [(500, 3), (500, 16, 3), (9,)]
+    lrs = [1.6e-3, 2.5e-3, 5e-2]
+    init = [torch.randn(s, generator=gen) for s in shapes]
+
+    def make(cls, **kw):
+        ps = [torch.nn.Parameter(t.clone().to(dev)) for t in init]
+        return ps, cls([{"params": [p], "lr": lr} for p, lr in zip(ps, lrs)], lr=0.0, eps=1e-15, **kw)
+    pa, oa = make(Adam, capturable=True)
+    pb, ob = make(torch.optim.Adam)
+    grads = [[torch.randn(sh, generator=gen).to(dev) * (10.0 ** (k - 2)) for sh in shapes] for k in range(7)]
+    static = [torch.zeros_like(p) for p in pa]
+    for x, st in zip(pa, static):
+        x.grad = st                                          # the graph reads the gradients from fixed addresses
+    oa.init_state()
+    assert all(torch.is_tensor(oa.state[x]["step"]) and oa.state[x]["step"].is_cuda for x in pa)
+    for k in range(3):                                       # three eager steps
+        for st, y, g in zip(static, pb, grads[k]):
+            st.copy_(g); y.grad = g.clone()
+        oa.step(); ob.step()
+    graph = torch.cuda.CUDAGraph()
+    torch.cuda.synchronize()
+    with torch.cuda.graph(graph):
+        oa.step()
+    for k in range(3, 7):                                    # four replayed steps
+        for st, y, g in zip(static, pb, grads[k]):
+            st.copy_(g); y.grad = g.clone()
+        graph.replay(); ob.step()
+    torch.cuda.synchronize()
+    for i, (x, y) in enumerate(zip(pa, pb)):
+        assert float(oa.state[x]["step"]) == 7.0 == float(ob.state[y]["step"])
+        torch.testing.assert_close(x.detach(), y.detach(), rtol=2e-6, atol=2e-4 * lrs[i])
+        torch.testing.assert_close(oa.state[x]["exp_avg_sq"], ob.state[y]["exp_avg_sq"], rtol=2e-5, atol=1e-6 * float(ob.state[y]["exp_avg_sq"].abs().max()))
+    # a step whose state does not exist yet cannot be captured: loud, not a graph that allocates (the capture state is faked: a capture
+    # that ends in an exception leaves this ROCm's later captures of the process unusable)
+    pc, oc = make(Adam, capturable=True)
+    for x in pc:
+        x.grad = torch.ones_like(x)
+    monkeypatch.setattr(torch.cuda, "is_current_stream_capturing", lambda: True)
+    with pytest.raises(RuntimeError, match="before a step is captured"):
+        oc.step()
+
+
+@pytest.mark.parametrize("loss", ["l1", "l1_ssim"])
+def test_caller_loop_replayed_from_graphs_equals_the_eager_loop(dev, loss):
+    """igs_amd.graphs.GraphedLoop around the unchanged loop body (tools/dropin_loop.py; optimizer = igs_amd.optim.Adam(capturable=True)):
+    first visit of a view eager, second captured, then replays -- must land where the eager loop lands after the same schedule, and
+    the values it returns must be those of the iteration just replayed."""
+    from igs_amd.graphs import GraphedLoop
+    from igs_amd.refine import render, DEFAULT_LRS
+    from igs_amd.scenes import perturbed_copy
+    from tools.dropin_loop import CallerModel, refine_iteration, make_losses
+    from igs_amd.scenes import sear_steak_like_scene
+    raw, cams, bg = sear_steak_like_scene(P=3000, n_cams=2, width=160, height=120, focal=90.0, scale_mean=-2.0)
+    cams = [c.to(dev) for c in cams]
+    bgd = bg.to(dev)
+    gt_raw = {k: v.to(dev) for k, v in perturbed_copy(raw, sigma=0.03).items()}
+    with torch.no_grad():
+        gts = [render(activate(gt_raw), c, bgd)["images_pred"].clone() for c in cams]
+    lf = make_losses("igs")
+    schedule = [i % len(cams) for i in range(9)]
+    ge = CallerModel(raw, dev, DEFAULT_LRS, optimizer="fused")
+    eager_losses = []
+    for v in schedule:
+        _, total = refine_iteration(ge, cams[v], gts[v], bgd, loss=loss, losses=lf)
+        eager_losses.append(float(total))
+    gg = CallerModel(raw, dev, DEFAULT_LRS, optimizer="fused_capturable")
+    loop = GraphedLoop(lambda v: refine_iteration(gg, cams[v], gts[v], bgd, loss=loss, losses=lf))
+    graph_losses = []
+    for v in schedule:
+        pkg, total = loop(v)
+        graph_losses.append(float(total))
+    assert len(loop._graphs) == len(cams)
+    loop.check()                                             # (no replayed forward overflowed its tile slabs)
+    assert sum(len(v) for v in loop._scratch.sets.values()) == 1          # one scratch set serves the eager visits and both graphs
+    assert tuple(pkg["viewspace_points"].grad.shape) == (3000, 3) and float(pkg["viewspace_points"].grad.abs().max()) > 0
+    for a, b in zip(eager_losses, graph_losses):
+        assert abs(a - b) <= 2e-3 * abs(a), (eager_losses, graph_losses)
+    assert graph_losses[-1] < graph_losses[0]
+    want, got = ge.raw(), gg.raw()
+    steps = len(schedule)
+    for k in want:
+        d = (got[k] - want[k]).abs()
+        lr = DEFAULT_LRS[k]
+        assert float(torch.quantile(d.flatten()[:100000], 0.98)) < 0.02 * lr * steps, (k, float(torch.quantile(d.flatten()[:100000], 0.98)))
+        assert float(d.max()) <= 2.05 * lr * steps, (k, float(d.max()))
+
+
 def test_inputs_are_converted_and_errors_are_loud(dev):
     """The compiled glue accepts what the reference's does -- non-contiguous and float64 inputs are made contiguous float32
     (rasterize_points.cu:98-130 calls .contiguous().data<float>()) -- and refuses what it cannot serve with a RasterizerError."""

@@ -25,12 +25,16 @@ def run_variant(raw, cams, bg, gts, dev, loss, optimizer, nan, losses="igs", ste
     gs = CallerModel(raw, dev, DEFAULT_LRS, optimizer=optimizer, fused_activations="fa" in flags)
     lf = make_losses(losses)
     kw = dict(loss=loss, losses=lf, psnr_line="np" not in flags)
-    for i in range(warm):
-        refine_iteration(gs, cams[i % len(cams)], gts[i % len(cams)], bg, **kw)
+    body = lambda v: refine_iteration(gs, cams[v], gts[v], bg, **kw)
+    if optimizer.endswith("_capturable"):          # the loop body replayed from one hipGraph per view (igs_amd/graphs.py)
+        from igs_amd.graphs import GraphedLoop
+        body = GraphedLoop(body)
+    for i in range(max(warm, 2 * len(cams))):
+        body(i % len(cams))
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(steps):
-        refine_iteration(gs, cams[i % len(cams)], gts[i % len(cams)], bg, **kw)
+        body(i % len(cams))
     torch.cuda.synchronize()
     return 1000 * (time.perf_counter() - t0) / steps
 
@@ -38,7 +42,8 @@ def run_variant(raw, cams, bg, gts, dev, loss, optimizer, nan, losses="igs", ste
 def main():
     dev = torch.device("cuda:0")
     steps = int(sys.argv[1]) if len(sys.argv) > 1 else 100
-    variants = sys.argv[2:] or ["l1:fused:0", "l1:fused:1", "l1_ssim:fused:0", "l1:torch_fused:0", "l1:torch:0", "l1:fused:0:torch", "l1_ssim:fused:1"]
+    variants = sys.argv[2:] or ["l1:fused:0", "l1:fused:1", "l1_ssim:fused:0", "l1:torch_fused:0", "l1:torch:0", "l1:fused:0:torch", "l1_ssim:fused:1",
+                                "l1:fused_capturable:1", "l1_ssim:fused_capturable:1", "l1:torch_capturable:1"]
     raw, cams, bg, gts = setup(dev)
     out = {}
     for v in variants:

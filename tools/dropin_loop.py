@@ -13,7 +13,8 @@ Not reproduced: building the Camera from a c2w matrix per iteration (`Camera.fro
 host, nothing the package under test sees) and moving the image to the GPU (`:290-291`); cameras and images are resident.
 
 `optimizer`: "torch" = torch.optim.Adam as the reference constructs it; "fused" = igs_amd.optim.Adam, the one-line replacement
-that runs all groups in one HIP launch (same update rule).
+that runs all groups in one HIP launch (same update rule); "fused_capturable" / "torch_capturable" = either with its step counts on the
+GPU, for a loop body replayed from hipGraphs (igs_amd/graphs.py).
 `losses`: "igs" = `from igs_amd.losses import l1_loss, ssim` (the one-line import change of INTEGRATION.md); "torch" = plain
 PyTorch l1 (abs / mean) and whatever SSIM function the caller passes in.
 """
@@ -40,9 +41,11 @@ class CallerModel:
             self.optimizer = torch.optim.Adam(l, lr=0.0, eps=1e-15)
         elif optimizer == "torch_fused":
             self.optimizer = torch.optim.Adam(l, lr=0.0, eps=1e-15, fused=True)
+        elif optimizer == "torch_capturable":
+            self.optimizer = torch.optim.Adam(l, lr=0.0, eps=1e-15, capturable=True)
         else:
             from igs_amd.optim import Adam
-            self.optimizer = Adam(l, lr=0.0, eps=1e-15)
+            self.optimizer = Adam(l, lr=0.0, eps=1e-15, capturable=(optimizer == "fused_capturable"))
 
     get_xyz = property(lambda self: self._xyz)
     get_features = property(lambda self: self._shs)
