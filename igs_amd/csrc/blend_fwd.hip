@@ -23,10 +23,15 @@ blend_fwd_kernel(const BlendFwdArgs a)
     __shared__ uint32_t order_hist[2 * LOAD_CLASSES];
 
     if (blockIdx.x == 0 && threadIdx.x == 0 && a.host_dst) {
-        a.host_dst[0] = a.stats_src[0]; a.host_dst[1] = a.stats_src[1]; a.host_dst[2] = a.flag_src[0];
-        __threadfence_system();
-        __hip_atomic_store(&a.host_dst[3], a.host_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);      // the host polls this word
-        __threadfence_system();
+        // three words, then (once they have been acknowledged) the sequence word the host polls -- as system-scope atomic stores, which
+        // go to the pinned host memory by themselves: a release FENCE here is an L2 write-back (buffer_wbl2), three of them in the
+        // workgroup that opens the kernel (refine_ops.hip: l1_mean_kernel has the measurement of what those can cost; here: no measurable
+        // difference, same-box A/B)
+        __hip_atomic_store(&a.host_dst[0], a.stats_src[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(&a.host_dst[1], a.stats_src[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(&a.host_dst[2], a.flag_src[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_store(&a.host_dst[3], a.host_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);      // the host polls this word
     }
     // workgroup 0, on the side: the tile order of the backward blend (common.h: build_tile_order), before it turns to its own tile
     if (blockIdx.x == 0 && a.tile_order) build_tile_order(a.ranges, (uint32_t)(a.gx * a.gy), a.tile_order, order_hist);

@@ -43,10 +43,15 @@ blend_step_kernel(const BlendFwdArgs f, const BlendBwdArgs b)
     __shared__ int wave_max[4];
 
     if (blockIdx.x == 0 && threadIdx.x == 0 && f.host_dst) {      // {R, overflow, prefilter flag} -> host-visible memory, as in blend_fwd_kernel
-        f.host_dst[0] = f.stats_src[0]; f.host_dst[1] = f.stats_src[1]; f.host_dst[2] = f.flag_src[0];
-        __threadfence_system();
-        __hip_atomic_store(&f.host_dst[3], f.host_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-        __threadfence_system();
+        // three words, then (once they have been acknowledged) the sequence word the host polls -- as system-scope atomic stores, which
+        // go to the pinned host memory by themselves: a release FENCE here is an L2 write-back (buffer_wbl2), three of them in the
+        // workgroup that opens the kernel (refine_ops.hip: l1_mean_kernel has the measurement of what those can cost; here: no measurable
+        // difference, same-box A/B)
+        __hip_atomic_store(&f.host_dst[0], f.stats_src[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(&f.host_dst[1], f.stats_src[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(&f.host_dst[2], f.flag_src[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_store(&f.host_dst[3], f.host_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);      // the host polls this word
     }
     uint32_t tile;
     BTL(0, wall_clock64());

@@ -319,6 +319,47 @@ def test_caller_loop_replayed_from_graphs_equals_the_eager_loop(dev, loss):
         assert float(d.max()) <= 2.05 * lr * steps, (k, float(d.max()))
 
 
+def test_graphed_loop_reports_a_replay_that_overflowed_its_slabs(dev):
+    """A replayed forward cannot tell the host that a tile outgrew the instance slab baked into its graph; GraphedLoop.check() reads what
+    the last replay posted (igs_rast_last_posted_status: no sequence check, several graphs take turns) and raises.  Provoked by
+    capturing with small slabs on small splats, then inflating every splat before the next replay."""
+    from igs_amd import _cabi
+    from igs_amd.graphs import GraphedLoop
+    from igs_amd.rasterizer import RasterizerError
+    from igs_amd.refine import render, DEFAULT_LRS
+    from igs_amd.scenes import sear_steak_like_scene
+    from tools.dropin_loop import CallerModel, refine_iteration, make_losses
+    L = _cabi.lib()
+    raw, cams, bg = sear_steak_like_scene(P=4000, n_cams=1, width=160, height=120, focal=90.0, scale_mean=-4.5)
+    cams = [c.to(dev) for c in cams]
+    bgd = bg.to(dev)
+    with torch.no_grad():
+        gts = [render(activate({k: v.to(dev) for k, v in raw.items()}), cams[0], bgd)["images_pred"].clone()]
+    old_hint = L.igs_rast_get_slab_hint()
+    try:
+        L.igs_rast_set_slab_hint(256)
+        gg = CallerModel(raw, dev, {k: 0.0 for k in DEFAULT_LRS}, optimizer="fused_capturable")       # (learning rates 0: the test moves the splats itself)
+        lf = make_losses("igs")
+        loop = GraphedLoop(lambda v: refine_iteration(gg, cams[v], gts[v], bgd, loss="l1", losses=lf))
+        for _ in range(3):
+            loop(0)                                          # eager, capture + replay, replay
+        loop.check()
+        assert L.igs_rast_get_slab_hint() == 256             # nothing overflowed so far: the graph has 256-slot slabs baked in
+        with torch.no_grad():
+            gg._scaling.add_(3.0)                            # every splat 20 x larger: hundreds of instances per tile
+        loop(0)
+        with pytest.raises(RasterizerError, match="overflowed"):
+            loop.check()
+        assert L.igs_rast_get_slab_hint() > 256              # the hint has been raised: a new capture will fit
+        loop.reset()
+        for _ in range(3):
+            pkg, total = loop(0)
+        loop.check()
+        assert torch.isfinite(total)
+    finally:
+        L.igs_rast_set_slab_hint(old_hint)
+
+
 def test_inputs_are_converted_and_errors_are_loud(dev):
     """The compiled glue accepts what the reference's does -- non-contiguous and float64 inputs are made contiguous float32
     (rasterize_points.cu:98-130 calls .contiguous().data<float>()) -- and refuses what it cannot serve with a RasterizerError."""
