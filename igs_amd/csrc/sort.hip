@@ -465,6 +465,38 @@ __device__ __forceinline__ void wave_sort_tile(const uint64_t* __restrict__ src,
     for (int r = 0; r < E; r++) { const uint32_t i = lane * E + r; if (i < n) dst[i] = min((uint32_t)v[r], id_max); }
 }
 
+// A tile of 257-320 instances by one wave: the first 256 keys sorted in registers (E = 4), the up to 64 others one per lane, merged BY RANK
+// instead of by a 512-slot network (E = 8: 2 400 dependent instructions, 13.5 us -- the five such tiles of the bench scene were the
+// tile sort's whole span behind the 10.9 us of everything else, profiles/r03_sort_timeline.txt).  Keys are distinct (the id is part of
+// the key), so the final position of a key is the number of keys below it: its index among the sorted 256 plus the extras below it, or,
+// for an extra, the main keys below it (a ballot per register) plus the extras below it.  One trip per extra, ~20 instructions.
+__device__ __forceinline__ void wave_sort_tile_320(const uint64_t* __restrict__ src, uint32_t* __restrict__ dst, uint32_t n, uint32_t lane, uint32_t id_max)
+{
+    uint64_t v[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) v[r] = src[lane * 4 + r];                 // (n > 256: all there)
+    const uint32_t nx = n - 256u;
+    const uint64_t x = lane < nx ? src[256u + lane] : ~0ull;
+    wave_bitonic_sort<4>(v, lane);
+    uint32_t mcnt[4] = { 0u, 0u, 0u, 0u }, xcnt = 0u, xmain = 0u;
+    for (uint32_t j = 0; j < nx; j++) {                                     // (uniform trip count)
+        const uint64_t xj = (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)x, (int)j)
+                          | ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(x >> 32), (int)j) << 32);
+        uint32_t below = 0u;
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const bool lt = v[r] < xj;
+            below += (uint32_t)__popcll(__ballot(lt));
+            mcnt[r] += lt ? 0u : 1u;
+        }
+        xcnt += xj < x ? 1u : 0u;
+        xmain = lane == j ? below : xmain;
+    }
+#pragma unroll
+    for (int r = 0; r < 4; r++) dst[lane * 4 + r + mcnt[r]] = min((uint32_t)v[r], id_max);
+    if (lane < nx) dst[xmain + xcnt] = min((uint32_t)x, id_max);
+}
+
 #ifdef SORT_TIMELINE
 // debug build only (tools/debug/sort_timeline.py): per tile, its size and the 100 MHz clock at the marks of its workgroup's life
 #define SORT_TL_MARKS 6
@@ -590,7 +622,8 @@ tile_sort_kernel(uint32_t T, uint32_t* __restrict__ tile_count, const uint64_t* 
 #ifndef TILE_SORT_NO_PRIO
                     __builtin_amdgcn_s_setprio(3);
 #endif
-                    if (n_true <= 512) wave_sort_tile<8>(src, dst, n_true, lane, id_max);
+                    if (n_true <= 320) wave_sort_tile_320(src, dst, n_true, lane, id_max);
+                    else if (n_true <= 512) wave_sort_tile<8>(src, dst, n_true, lane, id_max);
                     else if (n_true <= 1024) wave_sort_tile<16>(src, dst, n_true, lane, id_max);
                 }
                 STLT(t, 4, wall_clock64());

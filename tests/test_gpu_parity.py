@@ -1863,7 +1863,7 @@ def test_tile_sort_every_size_class_against_numpy(dev, slab):
     from igs_amd import _cabi
     L = _cabi.lib()
     P = 1 << 20
-    sizes = [0, 1, 2, 63, 64, 65, 127, 128, 129, 255, 256, 257, 300, 511, 512, 513, 700, 1000, 1023, 1024]
+    sizes = [0, 1, 2, 63, 64, 65, 127, 128, 129, 255, 256, 257, 258, 263, 300, 319, 320, 321, 511, 512, 513, 700, 1000, 1023, 1024]
     if slab > 1024:
         sizes += [1025, 1500, 2047, 2048]
     if slab > 2048:
