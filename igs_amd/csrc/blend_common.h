@@ -66,55 +66,6 @@ __device__ __forceinline__ uint32_t quad_reach_mask(float4 q0, float4 q1, float 
     return m;
 }
 
-// The same test for the eight 8x4 HALF-quads of a tile (experiment FWD_HALF2, round 4): bit h = 2 * quad + (rows 4..7 of the quad).
-__device__ __forceinline__ uint32_t half_reach_mask(float4 q0, float4 q1, float tile_x0, float tile_y0)
-{
-    const float o = q1.y;
-    if (o < (1.0f / 255.0f)) return 0u;
-    const float cx = q0.z, cy = q0.w, cz = q1.x;
-    const float det = cx * cz - cy * cy;
-    if (!(det > 0.f) || !(cx > 0.f) || !(cz > 0.f) || !(det < 3.0e38f)) return 0xFFu;
-    const float two_tau = 2.0f * __logf(255.0f * o) * 1.002f + 1e-3f;
-    if (!(two_tau < 3.0e38f)) return 0xFFu;
-    const float inv = __builtin_amdgcn_rcpf(det);
-    const float ex = __builtin_amdgcn_sqrtf(two_tau * cz * inv) * 1.001f + 0.02f;
-    const float ey = __builtin_amdgcn_sqrtf(two_tau * cx * inv) * 1.001f + 0.02f;
-    if (!(ex < 3.0e38f) || !(ey < 3.0e38f)) return 0xFFu;
-    const float lx = q0.x - ex - tile_x0, hx = q0.x + ex - tile_x0;
-    const float ly = q0.y - ey - tile_y0, hy = q0.y + ey - tile_y0;
-    const bool x0 = (hx >= 0.f) && (lx <= 7.f), x1 = (hx >= 8.f) && (lx <= 15.f);
-    uint32_t m = 0u;
-#pragma unroll
-    for (int s = 0; s < 4; s++) {                                  // four strips of four pixel rows
-        const bool ys = (hy >= (float)(4 * s)) && (ly <= (float)(4 * s + 3));
-        const int qy = s >> 1, hf = s & 1;
-        if (ys && x0) m |= 1u << (2 * (2 * qy + 0) + hf);
-        if (ys && x1) m |= 1u << (2 * (2 * qy + 1) + hf);
-    }
-    if (m == 0u) return 0u;
-    const float nbc = -cy * __builtin_amdgcn_rcpf(cz), nba = -cy * __builtin_amdgcn_rcpf(cx);
-    const float bx = (tile_x0 - 0.02f) - q0.x, by = (tile_y0 - 0.02f) - q0.y;
-#pragma unroll
-    for (int h = 0; h < 8; h++) {
-        const int q = h >> 1, hf = h & 1;
-        const float xl = bx + (float)((q & 1) * 8), xh = xl + 7.04f;
-        const float yl = by + (float)((q >> 1) * 8 + hf * 4), yh = yl + 3.04f;
-        const bool xin = (xl <= 0.f) && (xh >= 0.f), yin = (yl <= 0.f) && (yh >= 0.f);
-        const float fx = xl > 0.f ? xl : xh;
-        const float dyv = fminf(fmaxf(nbc * fx, yl), yh);
-        const float qv = cx * fx * fx + 2.0f * cy * fx * dyv + cz * dyv * dyv;
-        const float fy = yl > 0.f ? yl : yh;
-        const float dxh = fminf(fmaxf(nba * fy, xl), xh);
-        const float qh = cx * dxh * dxh + 2.0f * cy * dxh * fy + cz * fy * fy;
-        float qmin = 3.0e38f;
-        if (!xin) qmin = qv;
-        if (!yin) qmin = fminf(qmin, qh);
-        if (xin && yin) qmin = 0.f;
-        if (qmin > two_tau) m &= ~(1u << h);
-    }
-    return m;
-}
-
 // Workgroup barrier of the tile kernels: __syncthreads() with its release side spelled out.
 // Round 3: the forward's round loop ends with `wave_done[wid] = ...` (ds_write_b32) and begins with __syncthreads() followed by the
 // read of all four flags that decides `break` -- and hipcc emitted a bare s_barrier at that loop header, with no s_waitcnt lgkmcnt(0)

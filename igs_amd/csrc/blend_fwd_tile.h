@@ -9,12 +9,8 @@
 // loop) the fuller machine hides more of a row's dependency chain: 64.4 -> 61.0 us on the bench scene (same-box A/B, round 2)
 #define FWD_CHUNK 192
 #define FWD_NSW (FWD_CHUNK / 64)     // staging waves
-// EXPERIMENT (round 4; default off): the two 8x4 halves of a quad walk their OWN splat lists -- lanes 0..31 and 32..63 of
-// a wave blend DIFFERENT splats in one row while both lists have entries, then the longer list's tail runs with half the lanes masked.
-#ifndef FWD_HALF2
-#define FWD_HALF2 0
-#endif
-#define FWD_NLIST (FWD_HALF2 ? 8 : 4)     // to-do lists per tile: quads, or half-quads
+#define FWD_NLIST 4                  // to-do lists per tile: one per quad (the half-quad experiment of round 4 -- two splats per row -- was parity-
+                                     // green and slower; it lives in tools/experiments/fwd_half2.patch)
 
 // what a pixel's lane knows when the forward of its tile is done (the fused kernel hands it straight to the backward)
 struct FwdPix {
@@ -71,7 +67,7 @@ __device__ __forceinline__ void blend_fwd_tile(const BlendFwdArgs& a, const uint
             }
             chunk[tid * NQ + 0] = q0; chunk[tid * NQ + 1] = q1; chunk[tid * NQ + 2] = q2;
             if constexpr (GEO) { chunk[tid * NQ + 3] = src[3]; chunk[tid * NQ + 4] = src[4]; chunk[tid * NQ + 5] = src[5]; }
-            qmask = FWD_HALF2 ? half_reach_mask(q0, q1, tile_x0, tile_y0) : quad_reach_mask(q0, q1, tile_x0, tile_y0);
+            qmask = quad_reach_mask(q0, q1, tile_x0, tile_y0);
         }
         if (wid < FWD_NSW) {
 #pragma unroll
@@ -128,40 +124,6 @@ __device__ __forceinline__ void blend_fwd_tile(const BlendFwdArgs& a, const uint
         };
         if (__ballot(Tl != 0.0f) != 0ull) {
             bool wave_finished = false;
-#if FWD_HALF2
-            const bool upper = lane >= 32;                       // rows 4..7 of the quad
-            for (int sw = 0; sw < FWD_NSW && !wave_finished; sw++) {
-                uint64_t bitsA = uniform64(quad_bits[2 * wid][sw]), bitsB = uniform64(quad_bits[2 * wid + 1][sw]);
-                while (bitsA != 0ull && bitsB != 0ull) {         // both halves have a splat: one row serves two splats
-                    const int ja = __builtin_ctzll(bitsA), jb = __builtin_ctzll(bitsB);
-                    asm("s_bitset0_b64 %0, %1" : "+s"(bitsA) : "s"(ja));
-                    asm("s_bitset0_b64 %0, %1" : "+s"(bitsB) : "s"(jb));
-                    const uint32_t jl = (uint32_t)(sw * 64) + (uint32_t)(upper ? jb : ja);
-                    blend_row((const float4*)((const char*)chunk + jl * (uint32_t)(NQ * 16)), jl);
-                }
-                // the longer list's tail: the other half of the wave sits these rows out (EXEC-masked; wave-uniform record address)
-                if (bitsA != 0ull) {
-                    if (!upper) {
-                        while (bitsA != 0ull) {
-                            const int jj = __builtin_ctzll(bitsA);
-                            asm("s_bitset0_b64 %0, %1" : "+s"(bitsA) : "s"(jj));
-                            const int j = sw * 64 + jj;
-                            blend_row((const float4*)((const char*)chunk + (uint32_t)j * (uint32_t)(NQ * 16)), (uint32_t)j);
-                        }
-                    }
-                } else if (bitsB != 0ull) {
-                    if (upper) {
-                        while (bitsB != 0ull) {
-                            const int jj = __builtin_ctzll(bitsB);
-                            asm("s_bitset0_b64 %0, %1" : "+s"(bitsB) : "s"(jj));
-                            const int j = sw * 64 + jj;
-                            blend_row((const float4*)((const char*)chunk + (uint32_t)j * (uint32_t)(NQ * 16)), (uint32_t)j);
-                        }
-                    }
-                }
-                if (__ballot(Tl != 0.0f) == 0ull) wave_finished = true;
-            }
-#else
             for (int sw = 0; sw < FWD_NSW && !wave_finished; sw++) {
                 uint64_t bits = uniform64(quad_bits[wid][sw]);     // wave-uniform
                 while (bits != 0ull) {
@@ -178,7 +140,6 @@ __device__ __forceinline__ void blend_fwd_tile(const BlendFwdArgs& a, const uint
                 // rest of one 64-splat word is blended into lanes that no longer take anything
                 if (__ballot(Tl != 0.0f) == 0ull) wave_finished = true;
             }
-#endif
         }
         const bool all_done = __ballot(Tl != 0.0f) == 0ull;       // (the ballot must be taken by the whole wave)
         if (lane == 0) wave_done[wid] = all_done ? 1 : 0;
