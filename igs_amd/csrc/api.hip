@@ -1,6 +1,7 @@
 // api.hip -- C-ABI entry points (include/igs_rast.h) and host-side orchestration on a HIP stream.
 // Counterpart of CudaRasterizer::Rasterizer::{forward,backward,markVisible}
 // (DGR/cuda_rasterizer/rasterizer_impl.cu:176-188, 254-425, 429-571).
+#include <atomic>
 #include "common.h"
 #include <math.h>
 #include "../../include/igs_rast.h"
@@ -166,6 +167,7 @@ struct FwdExtra {
     float* zero_loss2 = nullptr;
     bool scratch_clean = false;         // igs_refine_step_args::scratch_clean: the image buffer's binning counters are known clean
     bool skip_bwd_state = false;        // ... the loss is colour-only: blend_fwd need not store the geometry branches' backward state
+    uint32_t plane_tag = 0;             // ... nonzero: a plane / depth / normal gradient will come back: keep Sigma^-1 per Gaussian under this tag
     // igs_refine_step with the L1 loss: run the colour-only blend backward inside the forward's tile kernel (blend_step.hip).  The
     // caller fills everything of the backward's arguments that forward_impl does not know (bg, gacc, l1_*, want_absgrad); the
     // list / record / geometry fields are set here.  *fused_ran reports whether that kernel was used (slab binning only).
@@ -238,6 +240,7 @@ static int forward_impl(
     fp.view = viewmatrix; fp.proj = projmatrix; fp.campos = cam_pos;
     fp.raw_activations = ex.raw_activations ? 1 : 0;
     fp.zero_gacc = ex.zero_gacc; fp.zero_loss = ex.zero_loss; fp.zero_loss2 = ex.zero_loss2;
+    if (ex.plane_tag) { fp.plane_cache = (float*)(gbase + GL.planes); fp.plane_tag = ex.plane_tag; }
     fp.zero_gacc_stride = ex.skip_bwd_state ? GACC_COMPACT_F : GACC_F;      // (colour-only loss <=> compact accumulator rows)
     g_last_fwd = LastFwd();
 
@@ -731,6 +734,7 @@ static int backward_impl(
     ga.fx = fx; ga.fy = fy; ga.kernel_size = kernel_size;
     ga.view = viewmatrix; ga.proj = projmatrix; ga.campos = campos;
     ga.rec = ba.rec; ga.gacc = gacc; ga.gacc_compact = gacc_compact ? 1 : 0;
+    if (fuse && fuse->plane_tag) { ga.plane_cache = (const float*)(gbase + GL.planes); ga.plane_tag = fuse->plane_tag; }
     ga.dL_dmean2D = dL_dmean2D; ga.dL_dcolor = dL_dcolor; ga.dL_dopacity = dL_dopacity; ga.dL_dmean3D = dL_dmean3D;
     ga.dL_dcov3D = dL_dcov3D; ga.dL_dsh = dL_dsh; ga.dL_dscale = dL_dscale; ga.dL_drot = dL_drot;
     if (fuse) {
@@ -864,6 +868,15 @@ extern "C" int igs_refine_step(const igs_refine_step_args* a)
         ex.defer_status = attempt == 0;            // second attempt: synchronous forward, which sorts out its scratch sizes itself
         ex.raw_activations = true;
         ex.skip_bwd_state = !dn;                   // (colour-only backward instance: see BlendFwdArgs)
+        static const bool no_plane_cache = getenv("IGS_NO_PLANE_CACHE") != nullptr;      // (A/B switch for measurements)
+        if (dn && !no_plane_cache) {
+            // the regulariser sends depth / normal gradients back: the forward keeps Sigma^-1 of every visible Gaussian, the
+            // per-Gaussian backward takes it from there instead of running the eigen-solver again (geom_math.h: PlaneCache)
+            static std::atomic<uint32_t> nonce{0};
+            uint32_t t = ++nonce;
+            if (t == 0) t = ++nonce;
+            ex.plane_tag = t; f.plane_tag = t;
+        } else f.plane_tag = 0;
         ex.scratch_clean = a->scratch_clean != 0;
         // L1 loss, colour-only backward: forward and backward blend of a tile in one kernel (blend_step.hip)
         BlendBwdArgs fused_bwd;

@@ -44,7 +44,7 @@ static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; 
 #define SORT_MAX_BLOCKS 256                // one block per CU
 
 struct GeomLayout {          // sizes in bytes, offsets from a 256-byte aligned base
-    size_t rec, tiles, keys_a, keys_b, vals_a, vals_b, hist, blocksum, counters, total;
+    size_t rec, tiles, keys_a, keys_b, vals_a, vals_b, hist, blocksum, counters, planes, total;
     __host__ explicit GeomLayout(size_t P) {
         size_t o = 0;
         rec = o;      o += align_up(P * REC_F * 4, 256);
@@ -55,7 +55,8 @@ struct GeomLayout {          // sizes in bytes, offsets from a 256-byte aligned 
         vals_b = o;   o += align_up(P * 4, 256);
         hist = o;     o += align_up((size_t)SORT_MAX_PASSES * 256 * SORT_MAX_BLOCKS * 4, 256);
         blocksum = o; o += align_up((P / 256 + 2) * 4, 256);   // per-256 block instance counts / offsets (depth order)
-        counters = o; o += (COUNTER_SHARDS + 1) * COUNTER_SHARD_STRIDE * 4;   // [1] prefilter flag, [16*(1+s)] count shard s
+        counters = o; o += align_up((COUNTER_SHARDS + 1) * COUNTER_SHARD_STRIDE * 4, 256);   // [1] prefilter flag, [16*(1+s)] count shard s
+        planes = o;   o += align_up(P * 12 * 4, 256);          // PlaneCache (geom_math.h): Sigma^-1 per visible Gaussian, kept on request for the backward
         total = o + 256;
     }
 };
@@ -117,6 +118,7 @@ struct FwdParams {
     float* zero_gacc; float* zero_loss; float* zero_loss2;     // refine step: backward accumulators / loss shards to zero-fill on the side (NULL = no)
     int raw_activations;                    // refine step: opacities / scales / rotations are the raw optimiser leaves
                                             // (sigmoid / exp / normalize applied here: gaussian_model.py:90-127)
+    float* plane_cache = nullptr; uint32_t plane_tag = 0;      // refine step with a plane / depth / normal gradient to come: keep Sigma^-1 (geom_math.h: PlaneCache)
 };
 
 // ---- launchers (each returns hipError_t of the launch) ----
@@ -192,6 +194,7 @@ struct GeomBwdArgs {
     // address); the host looks at the word after an event recorded behind the kernel.  NULL = no report.
     uint32_t* nan_host = nullptr; uint32_t nan_seq = 0;
     float clamp = 0.f;          // > 0 (unfused kernel): dL/d(means3D, sh, opacity, scale, rotation) clamped to +-clamp as they are written (clamp package)
+    const float* plane_cache = nullptr; uint32_t plane_tag = 0;      // what the forward of this frame kept (NULL = nothing: run the eigen-solver)
 };
 hipError_t launch_geom_bwd(hipStream_t s, const GeomBwdArgs& a);
 
@@ -211,6 +214,7 @@ struct RefineFuse {
     float loss_scale, loss_scale2, loss_scale3, loss_bias;
     int prezeroed;                                                         // the accumulators were zero-filled by the forward
     int blend_done = 0;                                                    // the blend backward already ran inside the forward's tile kernel (blend_step.hip)
+    uint32_t plane_tag = 0;                                                // nonzero: the forward of this step kept Sigma^-1 under this tag (PlaneCache)
     // N > 1: the view's colour gradients are final as soon as the blend backward is done -- backward_impl extracts them into color_out
     // right there and records `color_event` on the stream, so that the ranks' all-gather can run underneath the per-Gaussian kernel
     void* color_event = nullptr;

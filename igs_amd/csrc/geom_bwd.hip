@@ -288,6 +288,8 @@ geom_bwd_kernel(const GBArgs args)
         const float4* R4 = (const float4*)(a.rec + (size_t)idx * REC_F);
         const float4* G4 = (const float4*)(a.gacc + (size_t)idx * ((COLOUR_ONLY || a.gacc_compact) ? GACC_COMPACT_F : GACC_F));
         const float4 r0 = R4[0], r1 = R4[1], r2 = R4[2], r4 = R4[4], r5 = R4[5], r6 = R4[6], r7 = R4[7];
+        PlaneCacheEntry pce; pce.have = false;
+        if (!COLOUR_ONLY && a.plane_cache) pce = plane_cache_fetch(a.plane_cache + (size_t)idx * PLANE_CACHE_F);      // (kernel-uniform condition)
         float4 g0, g1, g2, g3, g4, g5, g6;
         if (COLOUR_ONLY || a.gacc_compact) {
             // colour-only blend instance: {c0 c1 c2 Q0} {Qx Qy Qxx Qxy} {Qyy Z - -}; every plane / depth / normal moment is zero
@@ -335,7 +337,8 @@ geom_bwd_kernel(const GBArgs args)
                                  | (Sy0 != 0.f) | (Sy1 != 0.f) | (Sy2 != 0.f) | (St != 0.f) | (Stx != 0.f) | (Sty != 0.f)
                                  | (dL_dnormal.x != 0.f) | (dL_dnormal.y != 0.f) | (dL_dnormal.z != 0.f));
         Cov2DCtx c;
-        cov2d_ctx(c, mean, cov3D, a.view, a.fx, a.fy, a.tan_fovx, a.tan_fovy, a.kernel_size, need_planes);
+        cov2d_ctx(c, mean, cov3D, a.view, a.fx, a.fy, a.tan_fovx, a.tan_fovy, a.kernel_size, need_planes,
+                  &pce, a.plane_tag);
         const float3 t = c.t;
         const float u = c.txtz, v = c.tytz, u2 = u * u, v2 = v * v, uv = u * v;
         const float combined_opacity = dLc_z;          // sic: dL_dconic.w, see header

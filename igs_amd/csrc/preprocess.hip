@@ -107,6 +107,7 @@ preprocess_body(const FwdParams& p, const uint32_t blk, float* __restrict__ rec,
             }
             Cov2DCtx c;
             cov2d_ctx(c, p_orig, cov3D, p.view, p.fx, p.fy, p.tan_fovx, p.tan_fovy, p.kernel_size, RECORD);      // (the binning role skips the eigen-solver)
+            if (RECORD && p.plane_cache) plane_cache_store(p.plane_cache + (size_t)idx * PLANE_CACHE_F, c, p.plane_tag);
             TL(2);
             float cp[6] = { 0, 0, 0, 0, 0, 0 }, rp[2] = { 0, 0 };
             float3 nrm = make_float3(0, 0, 0);

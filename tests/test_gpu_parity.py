@@ -1226,12 +1226,20 @@ def test_fused_depth_normal_regulariser_matches_autograd(dev, shape):
     assert float(gd[0].abs().max()) > 0 and float(gn[:, 0, :].abs().max()) == 0.0      # border pixels: n = 0
 
 
-def test_fused_step_with_depth_normal_regulariser(dev):
+@pytest.mark.parametrize("thin", [False, True])
+def test_fused_step_with_depth_normal_regulariser(dev, thin):
     """BASELINE cfg-5 shape natively: igs_refine_step with lambda_depth_normal (regulariser in one HIP launch, <depth, normal>
-    backward instance, L1 or L1 + D-SSIM alongside) against the autograd step (igs_amd.losses.depth_normal_loss = the same kernel as an autograd Function) and the loss value of the PyTorch restatement (oracle/torch_losses.py)."""
+    backward instance, L1 or L1 + D-SSIM alongside) against the autograd step (igs_amd.losses.depth_normal_loss = the same kernel as an autograd Function) and the loss value of the PyTorch restatement (oracle/torch_losses.py).
+    The fused step's per-Gaussian backward takes Sigma^-1 from what its forward kept (geom_math.h: PlaneCache) where the autograd
+    path runs the eigen-solver again; `thin`: every fifth Gaussian is a disc of thickness e^-10.5 (smallest eigenvalue below 1e-8: the
+    rank-deficient branch of forward.cu:139-167, whose backward needs the eigenvectors and therefore bypasses the cache)."""
     from igs_amd.refine import GaussianParams, Refiner, render
     from igs_amd.scenes import perturbed_copy
     raw, cams, bg = cfg1_scene(P=3000, size=128)
+    if thin:
+        raw = {k: v.clone() for k, v in raw.items()}
+        raw["scaling"][::5, 2] = -10.5
+        raw["scaling"][::5, :2] += 1.0                      # (wide enough to be seen)
     cams = [cams[0].to(dev)]
     bg = bg.to(dev)
     gt_raw = {k: v.to(dev) for k, v in perturbed_copy(raw, sigma=0.03).items()}
