@@ -51,6 +51,36 @@ def test_product_path_fails_loudly_without_gpu_and_validates_arguments():
         ras.integrate()
 
 
+def test_round4_entry_points_validate_before_they_launch():
+    """Argument checks of the entry points added in round 4 that can be exercised without a GPU: every one of them returns
+    IGS_RAST_E_INVALID (or 0 for "nothing to do") before any HIP call, and the Python optimiser / graph helper refuse CPU work loudly."""
+    import ctypes as C
+    from igs_amd import _cabi
+    L = _cabi.lib()
+    INVALID = -1
+    P8 = C.c_void_p * 8
+    F8 = C.c_float * 8
+    S8 = C.c_size_t * 8
+    fake = P8(*[0x1000 * (k + 1) for k in range(8)])             # never dereferenced: the checks below all fail first
+    same = P8(*[0x1000] * 8)
+    cnt, lr = S8(*[4] * 8), F8(*[1e-3] * 8)
+    assert L.igs_adam_step_multi_dev(None, 0, fake, fake, fake, fake, cnt, lr, fake, 0.9, 0.999, 1e-15) == 0          # nothing to do
+    assert L.igs_adam_step_multi_dev(None, 9, fake, fake, fake, fake, cnt, lr, fake, 0.9, 0.999, 1e-15) == INVALID    # at most 8 tensors
+    assert L.igs_adam_step_multi_dev(None, 2, fake, fake, fake, fake, cnt, lr, None, 0.9, 0.999, 1e-15) == INVALID    # no step counts
+    assert L.igs_adam_step_multi_dev(None, 2, fake, fake, fake, fake, cnt, lr, same, 0.9, 0.999, 1e-15) == INVALID    # one counter for two tensors
+    assert L.igs_adam_step_multi(None, 2, fake, fake, fake, fake, cnt, lr, None, None, 0.9, 0.999, 1e-15) == INVALID  # no bias corrections
+    assert L.igs_l1_mean_fwd_bwd(None, 0, fake, fake, fake, fake, fake, fake) == INVALID
+    assert L.igs_l1_mean_fwd_bwd(None, 16, None, fake, fake, fake, fake, fake) == INVALID
+    from igs_amd.optim import Adam
+    p = torch.nn.Parameter(torch.zeros(3)); p.grad = torch.ones(3)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        Adam([p], lr=1e-3, capturable=True).step()
+    if not torch.cuda.is_available():
+        from igs_amd.graphs import GraphedLoop
+        with pytest.raises(RuntimeError, match="needs a GPU"):
+            GraphedLoop(lambda k: None)(0)
+
+
 def test_no_product_module_imports_the_oracle():
     for base in ("igs_amd", "diff_gaussian_rasterization_rade", "diff_gaussian_rasterization_rade_clamp"):
         for dp, _, files in os.walk(os.path.join(ROOT, base)):
