@@ -114,11 +114,21 @@ def test_random_scene_matches_oracle(dev, seed):
         np.testing.assert_array_equal(d["ranges"].cpu().numpy().astype(np.uint32), it["ranges"])
         # contributor counts follow the blend thresholds: exact except where an expf last-bit difference flips one (check_images' `flips`)
         nc = d["n_contrib"].cpu().numpy().astype(np.uint32)
-        assert (nc != it["n_contrib"]).mean() <= 5e-4, (nc != it["n_contrib"]).mean()
-    check_images(out, oo, flips=5e-4)
+        assert (nc != it["n_contrib"]).mean() <= max(5e-4, 2.0 / max(1, cam.width * cam.height)), (nc != it["n_contrib"]).mean()      # (two pixels at least: seed 13773 is 19 x 45)
+    flipped = check_images(out, oo, flips=5e-4)
     if P == 0:
         return
     grads = rand_grads(oo, seed)
+    if flipped is not None and flipped.any():
+        # Gradient parity is asked for GIVEN the same discrete decisions: at a pixel whose forward took the other side of a blend
+        # threshold (one splat more or less at alpha = 1/255) the two backward passes differentiate different sums, and for a sharp
+        # splat that one pixel is a large part of its gradient (seed 12037: one pixel of 23 064, dL/dmean2D of one Gaussian off by
+        # 14.7 in NDC-scaled units; the round-3 build flips the same pixel).  No upstream gradient arrives at those pixels, on either side.
+        print("fuzz seed %d: %d flipped pixel(s) take no upstream gradient" % (seed, int(flipped.sum())))
+        for k in grads:
+            g = grads[k]
+            if g.ndim >= 2 and g.shape[-2:] == flipped.shape:
+                g[..., flipped] = 0.0
     gout = hip_backward(out, ad, mats, cam, bg, dev, grads, req, **kw)
     obk = dict(deg=deg, colors=okw["colors"], cov=okw["cov"])
     gr = oracle_backward(st, oo, a, cam, bg, grads, **obk)

@@ -114,18 +114,22 @@ def check_images(out, oo, flips=None, label=""):
     one splat at the `alpha < 1/255` threshold moves an accumulated output by alpha T <= 1/255 of its range, stopping one splat
     early or late at `T (1 - alpha) < 1e-4` by <= 1e-4 of it (two flips in one pixel: 2/255 -- asserted below as 0.01 of the
     range); only the two MEDIAN outputs (mcoord, mdepth) jump to a neighbouring splat's value, anywhere within the range.
-    Appends what was measured to IMAGE_REPORT and prints it."""
+    Appends what was measured to IMAGE_REPORT and prints it.  Returns the [H, W] mask of the flipped pixels (None: no image)."""
     nr, color, coord, mcoord, alpha, normal, depth, mdepth = out[:8]
+    flipped = None                   # [H, W]: pixels where some output sits on the other side of a blend threshold (returned)
     for k, v in [("color", color), ("coord", coord), ("mcoord", mcoord), ("depth", depth), ("mdepth", mdepth), ("alpha", alpha), ("normal", normal)]:
         o = oo[k]
         if flips is None:
             flips_k = max(1e-5, 2.0 / max(1, o.shape[-1] * o.shape[-2]))
         else:
-            flips_k = flips
+            flips_k = max(flips, 2.0 / max(1, o.shape[-1] * o.shape[-2]))      # (a fraction cannot resolve less than a pixel: two pixels at least)
         d = np.abs(np.asarray(v.cpu().numpy(), np.float64) - o)
         rng = float(np.abs(o).max()) if o.size else 0.0
         bound = image_bound(k, rng)
         bad = d > bound
+        if bad.size:
+            b2 = bad.reshape((-1,) + bad.shape[-2:]).any(0)
+            flipped = b2 if flipped is None else (flipped | b2)
         frac = float(bad.mean()) if bad.size else 0.0
         good_max = float(d[~bad].max()) if (~bad).any() else 0.0
         flip_max = float(d[bad].max()) if bad.any() else 0.0
@@ -133,8 +137,17 @@ def check_images(out, oo, flips=None, label=""):
         print("images %s %-6s: max abs err %.3e (bound %.3e, range %.3g); flipped pixels %.2e of all, largest %.3e of range"
               % (label, k, good_max, bound, rng, frac, flip_max / max(rng, 1.0)))
         assert frac <= flips_k, (k, frac, flip_max)
-        if k not in ("mcoord", "mdepth"):
+        if k == "normal" and bad.any():
+            # the normal image is the accumulated normal divided by its LENGTH (forward.cu:720-727): one splat more or less at the
+            # `alpha < 1/255` threshold turns the accumulated vector by up to ~2 (1/255) / |N|, and |N| <= the pixel's accumulated alpha
+            # -- a faint pixel's direction moves by far more than 1/255 (fuzz seed 12037: 0.020 at one pixel of 23 064 whose colour,
+            # alpha and depth show the same single flip)
+            w = np.broadcast_to(np.asarray(oo["alpha"], np.float64), d.shape)
+            allowed = np.minimum(2.0, 2.0 * (2.0 / 255.0) / np.maximum(w, 2.0 / 255.0))
+            assert (d[bad] <= np.maximum(allowed[bad], 0.01)).all(), (k, flip_max, float(w[bad].min()))
+        elif k not in ("mcoord", "mdepth"):
             assert flip_max <= 0.01 * max(rng, 1.0), (k, flip_max, rng)
+    return flipped
 
 
 def check_grads(gout, gr, bulk=0.96, p99=1e-2, worst=0.25):
