@@ -192,7 +192,12 @@ def test_random_scene_fused_refine_step_matches_unfused(dev, seed):
     print("fuzz refine seed %d: P %d, %dx%d, loss %s, lambda_dn %.2f" % (seed, P, cam.width, cam.height, loss, ldn))
     assert torch.equal(pa.flat, before) and pa.step_count == 0
     assert torch.equal(pka["radii"], pkb["radii"])
-    np.testing.assert_allclose(pka["images_pred"].detach().cpu().numpy(), pkb["images_pred"].detach().cpu().numpy(), atol=2e-5)
+    # same kernels on both sides, but with the regulariser on the unfused side is the AUTOGRAD path (Refiner._mode), whose activations are
+    # PyTorch's exp / sigmoid / normalize: a last-bit difference in a conic can put one splat on the other side of `alpha < 1/255` at one
+    # pixel (seeds 20087, 20581: one pixel of 44 000, 4.0e-3 and 1.2e-3) -- the flip of check_images, with its bounds
+    dimg = np.abs(pka["images_pred"].detach().cpu().numpy().astype(np.float64) - pkb["images_pred"].detach().cpu().numpy()).max(0)
+    off = dimg > 2e-5
+    assert off.mean() <= max(5e-4, 2.0 / off.size) and (not off.any() or dimg[off].max() <= 0.01), (int(off.sum()), float(dimg.max()))
     for k in pa.leaves:
         A, B = pa.leaves[k].grad.cpu().numpy().astype(np.float64), pb.leaves[k].grad.cpu().numpy().astype(np.float64)
         scale = max(np.abs(B).max(), 1e-30)
