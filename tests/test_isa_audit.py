@@ -48,3 +48,27 @@ def test_audit_finds_a_planted_hazard():
           (12, "s_nop", "0", None), (16, "ds_write_addtid_b32", "v4", None), (20, "s_endpgm", "", None)]
     _, addtid = A.analyse(m0)
     assert addtid == [(4, 0), (16, 1)]
+
+
+def test_no_kernel_writes_back_its_l2():
+    """No `buffer_wbl2` in any kernel of libigs_rast.so: on gfx950 a device- or system-scope RELEASE fence (`__threadfence()`,
+    `__threadfence_system()`, a release atomic) is a write-back of every dirty line of the XCD's L2, and a kernel that has just streamed its
+    output through that L2 waits for all of it -- round 4: a thousand workgroups fencing in front of a done-counter made a 10 us kernel
+    take 40 (profiles/r04_l1_mean_fence_ab.txt).  Cross-workgroup hand-offs inside a kernel use agent-scope atomic stores / loads and
+    `s_waitcnt vmcnt(0)` instead (refine_ops.hip: l1_mean_kernel; blend_fwd.hip: the status words for the host)."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from igs_amd import build
+    build.build()
+    import audit_barriers as A
+    tmp, cos = A.code_objects(build.LIB)
+    try:
+        seen = 0
+        for co in cos:
+            for f, insns in A.parse(co).items():
+                seen += len(insns)
+                hits = [hex(a) for a, mn, _, _ in insns if mn.startswith("buffer_wbl2")]
+                assert not hits, (f, "L2 write-back (a release fence) inside a kernel", hits)
+        assert seen > 50000, seen          # (the scan really saw the library: ~99 000 instructions)
+    finally:
+        import shutil
+        shutil.rmtree(tmp, ignore_errors=True)
