@@ -50,8 +50,12 @@ class CallerModel:
     get_xyz = property(lambda self: self._xyz)
     get_features = property(lambda self: self._shs)
     def _act(self, i):
-        if not self.fused_activations:
-            return (torch.sigmoid(self._opacity), torch.exp(self._scaling), torch.nn.functional.normalize(self._rotation))[i]
+        if not self.fused_activations:          # gaussian_model.py:90-127: every getter applies ITS activation only
+            if i == 0:
+                return torch.sigmoid(self._opacity)
+            if i == 1:
+                return torch.exp(self._scaling)
+            return torch.nn.functional.normalize(self._rotation)
         cur = getattr(self, "_act_cache", None)          # one fused launch serves the three getters of an iteration
         key = (self._opacity._version, self._scaling._version, self._rotation._version)
         if cur is None or cur[0] != key or cur[2] >= 3:
