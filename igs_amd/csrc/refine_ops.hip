@@ -101,10 +101,16 @@ extern "C" int igs_adam_step_groups(void* stream, int ngroups, const size_t* off
 
 // The same update over up to 8 SEPARATE tensors in one launch (igs_amd/optim.py: a torch.optim.Optimizer whose parameters are ordinary
 // nn.Parameters, each with its own gradient / moment allocation and its own step count).  blockIdx.y = tensor.
-struct AdamMulti { int n; float* p[8]; const float* g[8]; float* m[8]; float* v[8]; size_t cnt[8]; float lr_over_bc1[8]; float inv_sqrt_bc2[8]; const float* step[8]; };
+struct AdamMulti { int n; float* p[8]; const float* g[8]; float* m[8]; float* v[8]; size_t cnt[8]; float lr_over_bc1[8]; float inv_sqrt_bc2[8]; float* step[8]; unsigned* done; };
+#define ADAM_DONE_GROUP 64u          // workgroups per first-level done-counter
+#define ADAM_DONE_STRIDE 32u         // words between counters (one cache line each)
+#define ADAM_DONE_WORDS ((1u + (8u * 1024u + ADAM_DONE_GROUP - 1u) / ADAM_DONE_GROUP) * ADAM_DONE_STRIDE)
 // DEV_STEP: the step counts live in device memory (one float per tensor, torch.optim.Adam's `capturable` layout), so that the launch can
 // be replayed from a hipGraph: the bias corrections are computed here (in double, as the host does) instead of arriving as arguments,
-// and lr_over_bc1 holds the plain learning rate
+// and lr_over_bc1 holds the plain learning rate.  step[k] = number of COMPLETED steps: every workgroup reads it when it starts and uses
+// step + 1; the workgroup that finishes LAST -- after every other one has started, hence read -- advances the counts for the next launch
+// (two-level done-counter in `done`, relaxed agent-scope atomics, no fences: refine_ops.hip l1_mean_kernel has the reason), so the
+// update stays ONE launch.
 template <bool DEV_STEP>
 __global__ void __launch_bounds__(256)
 adam_multi_kernel(const AdamMulti G, float b1, float b2, float eps)
@@ -116,7 +122,7 @@ adam_multi_kernel(const AdamMulti G, float b1, float b2, float eps)
     if (DEV_STEP) {
         __shared__ float bc[2];
         if (threadIdx.x == 0) {
-            const double t = (double)G.step[k][0];
+            const double t = (double)__hip_atomic_load(G.step[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1.0;
             bc[0] = (float)((double)lr / (1.0 - pow((double)b1, t)));
             bc[1] = (float)(1.0 / sqrt(1.0 - pow((double)b2, t)));
         }
@@ -146,28 +152,42 @@ adam_multi_kernel(const AdamMulti G, float b1, float b2, float eps)
         mm[i] = mi; vv[i] = vi;
         pp[i] -= lr * mi / (sqrtf(vi) * isb + eps);
     }
-}
-struct StepPtrs { int n; float* step[8]; };
-__global__ void adam_count_step_kernel(const StepPtrs S)
-{
-    if ((int)threadIdx.x < S.n) S.step[threadIdx.x][0] += 1.0f;
+    if (DEV_STEP) {
+        __syncthreads();                                   // (thread 0 read the counts long ago; every wave of the workgroup is done streaming)
+        if (threadIdx.x == 0) {
+            const unsigned id = blockIdx.y * gridDim.x + blockIdx.x, total = gridDim.x * gridDim.y;
+            const unsigned g = id / ADAM_DONE_GROUP, ng = (total + ADAM_DONE_GROUP - 1u) / ADAM_DONE_GROUP;
+            const unsigned gsize = (g == ng - 1u) ? total - g * ADAM_DONE_GROUP : ADAM_DONE_GROUP;
+            unsigned* gc = G.done + ADAM_DONE_STRIDE * (1u + g);
+            if (__hip_atomic_fetch_add(gc, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gsize - 1u) {
+                __hip_atomic_store(gc, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (__hip_atomic_fetch_add(G.done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == ng - 1u) {
+                    __hip_atomic_store(G.done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    for (int q = 0; q < G.n; q++) {
+                        const float c = __hip_atomic_load(G.step[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_store(G.step[q], c + 1.0f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                }
+            }
+        }
+    }
 }
 static int adam_multi(void* stream, int ntensors, float* const* param, const float* const* grad, float* const* exp_avg,
                       float* const* exp_avg_sq, const size_t* count, const float* lr, const float* bias_correction1,
-                      const float* bias_correction2_sqrt, float* const* step, float beta1, float beta2, float eps)
+                      const float* bias_correction2_sqrt, float* const* step, unsigned* done, float beta1, float beta2, float eps)
 {
     if (ntensors <= 0) return 0;
     if (ntensors > 8 || !param || !grad || !exp_avg || !exp_avg_sq || !count || !lr) return IGS_RAST_E_INVALID;
     if (!step && (!bias_correction1 || !bias_correction2_sqrt)) return IGS_RAST_E_INVALID;
-    AdamMulti G; G.n = ntensors;
-    StepPtrs S; S.n = ntensors;
+    if (step && !done) return IGS_RAST_E_INVALID;
+    AdamMulti G; G.n = ntensors; G.done = done;
     size_t nmax = 0;
     for (int k = 0; k < ntensors; k++) {
         if (count[k] && (!param[k] || !grad[k] || !exp_avg[k] || !exp_avg_sq[k])) return IGS_RAST_E_INVALID;
         if (step && !step[k]) return IGS_RAST_E_INVALID;
         G.p[k] = param[k]; G.g[k] = grad[k]; G.m[k] = exp_avg[k]; G.v[k] = exp_avg_sq[k]; G.cnt[k] = count[k];
         G.lr_over_bc1[k] = step ? lr[k] : lr[k] / bias_correction1[k]; G.inv_sqrt_bc2[k] = step ? 1.0f : 1.0f / bias_correction2_sqrt[k];
-        G.step[k] = step ? step[k] : nullptr; S.step[k] = step ? step[k] : nullptr;
+        G.step[k] = step ? step[k] : nullptr;
         if (count[k] > nmax) nmax = count[k];
     }
     size_t blocks = (nmax / 4 + 255) / 256;
@@ -178,7 +198,6 @@ static int adam_multi(void* stream, int ntensors, float* const* param, const flo
         for (int a = 0; a < ntensors; a++)
             for (int b = a + 1; b < ntensors; b++)
                 if (step[a] == step[b]) return IGS_RAST_E_INVALID;              // (one counter per tensor: each is advanced once)
-        hipLaunchKernelGGL(adam_count_step_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, S);
         hipLaunchKernelGGL(adam_multi_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, G, beta1, beta2, eps);
     } else {
         hipLaunchKernelGGL(adam_multi_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, G, beta1, beta2, eps);
@@ -190,15 +209,16 @@ extern "C" int igs_adam_step_multi(void* stream, int ntensors, float* const* par
                                    const float* bias_correction2_sqrt, float beta1, float beta2, float eps)
 {
     if (!bias_correction1 || !bias_correction2_sqrt) return ntensors <= 0 ? 0 : IGS_RAST_E_INVALID;
-    return adam_multi(stream, ntensors, param, grad, exp_avg, exp_avg_sq, count, lr, bias_correction1, bias_correction2_sqrt, nullptr, beta1,
-                      beta2, eps);
+    return adam_multi(stream, ntensors, param, grad, exp_avg, exp_avg_sq, count, lr, bias_correction1, bias_correction2_sqrt, nullptr, nullptr,
+                      beta1, beta2, eps);
 }
+extern "C" size_t igs_adam_step_multi_dev_scratch_words(void) { return ADAM_DONE_WORDS; }
 extern "C" int igs_adam_step_multi_dev(void* stream, int ntensors, float* const* param, const float* const* grad, float* const* exp_avg,
-                                       float* const* exp_avg_sq, const size_t* count, const float* lr, float* const* step, float beta1,
-                                       float beta2, float eps)
+                                       float* const* exp_avg_sq, const size_t* count, const float* lr, float* const* step,
+                                       unsigned* done_scratch, float beta1, float beta2, float eps)
 {
-    if (!step) return ntensors <= 0 ? 0 : IGS_RAST_E_INVALID;
-    return adam_multi(stream, ntensors, param, grad, exp_avg, exp_avg_sq, count, lr, nullptr, nullptr, step, beta1, beta2, eps);
+    if (!step || !done_scratch) return ntensors <= 0 ? 0 : IGS_RAST_E_INVALID;
+    return adam_multi(stream, ntensors, param, grad, exp_avg, exp_avg_sq, count, lr, nullptr, nullptr, step, done_scratch, beta1, beta2, eps);
 }
 
 // mean |pred - gt| and its gradient in ONE launch, the value finished on the device: every workgroup leaves its partial sum in

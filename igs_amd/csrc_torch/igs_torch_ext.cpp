@@ -233,10 +233,12 @@ Tensor mark_visible(const Tensor& means3D, const Tensor& viewmatrix, const Tenso
 // igs_adam_step_multi over lists of tensors (igs_amd/optim.py): one launch for up to 8 parameters
 void adam_step_multi(const std::vector<Tensor>& params, const std::vector<Tensor>& grads, const std::vector<Tensor>& exp_avgs,
                      const std::vector<Tensor>& exp_avg_sqs, const std::vector<double>& lrs, const std::vector<double>& bc1,
-                     const std::vector<double>& bc2_sqrt, double beta1, double beta2, double eps, const std::vector<Tensor>& steps)
+                     const std::vector<double>& bc2_sqrt, double beta1, double beta2, double eps, const std::vector<Tensor>& steps,
+                     const OptTensor& done_scratch)
 {
     // `steps` (optional): one float32 GPU scalar per tensor = the step count, advanced on the device (igs_adam_step_multi_dev; bc1 /
-    // bc2_sqrt are then ignored) -- the form a hipGraph can replay
+    // bc2_sqrt are then ignored) -- the form a hipGraph can replay; `done_scratch`: int32 GPU tensor of
+    // igs_adam_step_multi_dev_scratch_words() zeros the caller keeps between calls
     const size_t n = params.size();
     if (n == 0) return;
     const bool dev_step = !steps.empty();
@@ -266,7 +268,14 @@ void adam_step_multi(const std::vector<Tensor>& params, const std::vector<Tensor
     }
     const c10::hip::HIPGuardMasqueradingAsCUDA guard(dev);
     hipStream_t stream = c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(dev.index()).stream();
-    const int rc = dev_step ? igs_adam_step_multi_dev(stream, (int)n, p, g, m, v, cnt, lr, st, (float)beta1, (float)beta2, (float)eps)
+    unsigned* done = nullptr;
+    if (dev_step) {
+        if (!done_scratch.has_value() || !done_scratch->is_cuda() || done_scratch->device() != dev || done_scratch->scalar_type() != at::kInt
+            || (size_t)done_scratch->numel() < igs_adam_step_multi_dev_scratch_words() || !done_scratch->is_contiguous())
+            throw RasterizerError("adam_step_multi: device-side step counts need `done_scratch`, an int32 tensor of adam_dev_scratch_words() zeros on the parameters' GPU");
+        done = (unsigned*)done_scratch->data_ptr<int>();
+    }
+    const int rc = dev_step ? igs_adam_step_multi_dev(stream, (int)n, p, g, m, v, cnt, lr, st, done, (float)beta1, (float)beta2, (float)eps)
                             : igs_adam_step_multi(stream, (int)n, p, g, m, v, cnt, lr, b1c, b2c, (float)beta1, (float)beta2, (float)eps);
     if (rc != 0) throw RasterizerError("igs_adam_step_multi failed: " + std::to_string(rc));
 }
@@ -421,7 +430,8 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
     });
     m.def("adam_step_multi", &adam_step_multi, py::arg("params"), py::arg("grads"), py::arg("exp_avgs"), py::arg("exp_avg_sqs"), py::arg("lrs"),
           py::arg("bias_correction1"), py::arg("bias_correction2_sqrt"), py::arg("beta1"), py::arg("beta2"), py::arg("eps"),
-          py::arg("steps") = std::vector<Tensor>(), py::call_guard<py::gil_scoped_release>());
+          py::arg("steps") = std::vector<Tensor>(), py::arg("done_scratch") = py::none(), py::call_guard<py::gil_scoped_release>());
+    m.def("adam_dev_scratch_words", []() { return (int64_t)igs_adam_step_multi_dev_scratch_words(); });
     m.def("l1_mean", &l1_mean, py::arg("a"), py::arg("b"), py::call_guard<py::gil_scoped_release>());
     m.def("ssim_mean", &ssim_mean, py::arg("a"), py::arg("b"), py::call_guard<py::gil_scoped_release>());
     m.def("abi_version", []() { return igs_rast_version(); });

@@ -12,7 +12,7 @@ State layout and names are torch.optim.Adam's (`state[p] = {"step", "exp_avg", "
 code that edits `optimizer.state` (gaussian_model.py:466-557) keep working.  There is no CPU path: parameters must be float32 GPU tensors.
 
 `capturable=True` (torch.optim.Adam's name for the same thing): `state[p]["step"]` is a float32 scalar ON THE GPU, advanced by the
-launch itself (`igs_adam_step_multi_dev`), so `step()` reads nothing from the host that changes between steps and a whole refine
+launch itself (`igs_adam_step_multi_dev`: still ONE launch -- the workgroup that finishes last advances the counts), so `step()` reads nothing from the host that changes between steps and a whole refine
 iteration -- render, loss, backward, step -- can be captured into one hipGraph (`torch.cuda.graph`) and replayed.  The state must
 exist before the capture (one ordinary step on a side stream, as for any captured PyTorch optimizer, or `init_state()`).
 """
@@ -29,6 +29,7 @@ class Adam(torch.optim.Optimizer):
             raise ValueError("igs_amd.optim.Adam: invalid hyper-parameter")
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
         self.capturable = bool(capturable)
+        self._done = {}                 # capturable: per device, the self-resetting done-counters of the one-launch update
         self._ext = _cabi.ext()
         # torch.optim.Optimizer wraps the class's `step` in a profiler / hook trampoline that costs ~35 us of host time per call -- more than
         # the launch it guards, in a loop whose iteration is bound by host time (tools/profile_dropin_loop_host.py).  Instances call the
@@ -69,6 +70,8 @@ class Adam(torch.optim.Optimizer):
             for p in group["params"]:
                 if len(self.state[p]) == 0:
                     self._init_state(p)
+                if self.capturable and p.device not in self._done:
+                    self._done[p.device] = torch.zeros(self._ext.adam_dev_scratch_words(), dtype=torch.int32, device=p.device)
 
     @torch.no_grad()
     def _step_impl(self, closure=None):
@@ -106,7 +109,14 @@ class Adam(torch.optim.Optimizer):
                     t = st["step"] = int(st["step"]) + 1
                     b[5].append(1.0 - b1 ** t); b[6].append(math.sqrt(1.0 - b2 ** t))
         for (dev, b1, b2, eps), b in batches.items():
+            done = None
+            if self.capturable:
+                done = self._done.get(dev)
+                if done is None:
+                    if torch.cuda.is_current_stream_capturing():
+                        raise RuntimeError("igs_amd.optim.Adam: the optimizer state must exist before a step is captured (init_state())")
+                    done = self._done[dev] = torch.zeros(Cx.adam_dev_scratch_words(), dtype=torch.int32, device=dev)
             for i in range(0, len(b[0]), 8):
                 Cx.adam_step_multi(b[0][i:i + 8], b[1][i:i + 8], b[2][i:i + 8], b[3][i:i + 8], b[4][i:i + 8], b[5][i:i + 8], b[6][i:i + 8],
-                                   b1, b2, eps, b[7][i:i + 8])
+                                   b1, b2, eps, b[7][i:i + 8], done)
         return loss

@@ -271,12 +271,15 @@ int igs_adam_step_multi(void* stream, int ntensors, float* const* param, const f
                         float* const* exp_avg_sq, const size_t* count, const float* lr, const float* bias_correction1,
                         const float* bias_correction2_sqrt, float beta1, float beta2, float eps);
 
-/* The same with the step counts in DEVICE memory (step[k]: one float per tensor, the layout of torch.optim.Adam(capturable=True)): a
- * one-thread launch advances every count by 1, then the update computes its bias corrections from them.  Nothing of the call depends
- * on host state that changes from step to step, so it can be captured into a hipGraph and replayed. */
+/* The same with the step counts in DEVICE memory (step[k]: one float per tensor = the number of COMPLETED steps, the layout of
+ * torch.optim.Adam(capturable=True)): every workgroup computes its bias corrections from step + 1, the workgroup that finishes last
+ * advances the counts.  Nothing of the call depends on host state that changes from step to step, so it can be captured into a
+ * hipGraph and replayed.  done_scratch: igs_adam_step_multi_dev_scratch_words() 32-bit words, zero before the first call and zero
+ * again after every call (a buffer the caller zero-fills once and keeps; calls that share it must be ordered on one stream). */
+size_t igs_adam_step_multi_dev_scratch_words(void);
 int igs_adam_step_multi_dev(void* stream, int ntensors, float* const* param, const float* const* grad, float* const* exp_avg,
-                            float* const* exp_avg_sq, const size_t* count, const float* lr, float* const* step, float beta1, float beta2,
-                            float eps);
+                            float* const* exp_avg_sq, const size_t* count, const float* lr, float* const* step, unsigned* done_scratch,
+                            float beta1, float beta2, float eps);
 
 /* ---- one whole refine iteration on one view, single GPU --------------------------------------------------------------
  * Native form of the body of the reference's per-frame refine loop (infer_batch.py:279-324 with the L1 photometric loss,

@@ -64,10 +64,13 @@ def test_round4_entry_points_validate_before_they_launch():
     fake = P8(*[0x1000 * (k + 1) for k in range(8)])             # never dereferenced: the checks below all fail first
     same = P8(*[0x1000] * 8)
     cnt, lr = S8(*[4] * 8), F8(*[1e-3] * 8)
-    assert L.igs_adam_step_multi_dev(None, 0, fake, fake, fake, fake, cnt, lr, fake, 0.9, 0.999, 1e-15) == 0          # nothing to do
-    assert L.igs_adam_step_multi_dev(None, 9, fake, fake, fake, fake, cnt, lr, fake, 0.9, 0.999, 1e-15) == INVALID    # at most 8 tensors
-    assert L.igs_adam_step_multi_dev(None, 2, fake, fake, fake, fake, cnt, lr, None, 0.9, 0.999, 1e-15) == INVALID    # no step counts
-    assert L.igs_adam_step_multi_dev(None, 2, fake, fake, fake, fake, cnt, lr, same, 0.9, 0.999, 1e-15) == INVALID    # one counter for two tensors
+    scr = C.c_void_p(0x9000)
+    assert L.igs_adam_step_multi_dev_scratch_words() >= 33
+    assert L.igs_adam_step_multi_dev(None, 0, fake, fake, fake, fake, cnt, lr, fake, scr, 0.9, 0.999, 1e-15) == 0          # nothing to do
+    assert L.igs_adam_step_multi_dev(None, 9, fake, fake, fake, fake, cnt, lr, fake, scr, 0.9, 0.999, 1e-15) == INVALID    # at most 8 tensors
+    assert L.igs_adam_step_multi_dev(None, 2, fake, fake, fake, fake, cnt, lr, None, scr, 0.9, 0.999, 1e-15) == INVALID    # no step counts
+    assert L.igs_adam_step_multi_dev(None, 2, fake, fake, fake, fake, cnt, lr, fake, None, 0.9, 0.999, 1e-15) == INVALID   # no done-counters
+    assert L.igs_adam_step_multi_dev(None, 2, fake, fake, fake, fake, cnt, lr, same, scr, 0.9, 0.999, 1e-15) == INVALID    # one counter for two tensors
     assert L.igs_adam_step_multi(None, 2, fake, fake, fake, fake, cnt, lr, None, None, 0.9, 0.999, 1e-15) == INVALID  # no bias corrections
     assert L.igs_l1_mean_fwd_bwd(None, 0, fake, fake, fake, fake, fake, fake) == INVALID
     assert L.igs_l1_mean_fwd_bwd(None, 16, None, fake, fake, fake, fake, fake) == INVALID
