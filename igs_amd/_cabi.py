@@ -40,7 +40,7 @@ class RefineStepArgs(C.Structure):
 
 EXPORTS = ["igs_rast_version", "igs_rast_last_error", "igs_rast_forward", "igs_rast_backward_workspace_bytes",
            "igs_rast_forward_async", "igs_rast_forward_finish", "igs_rast_forward_nowait", "igs_rast_last_status", "igs_rast_last_posted_status", "igs_rast_hint_scratch_clean", "igs_rast_set_slab_hint", "igs_rast_get_slab_hint", "igs_rast_backward", "igs_rast_mark_visible", "igs_rast_debug_dump",
-           "igs_rast_profile_enable", "igs_rast_profile_read", "igs_adam_step", "igs_adam_step_groups", "igs_adam_step_multi", "igs_adam_step_multi_dev", "igs_adam_step_multi_dev_scratch_words", "igs_densify_stats", "igs_densify_remap", "igs_refine_step", "igs_refine_loss_scratch_bytes", "igs_ssim_l1_scratch_bytes", "igs_ssim_l1_loss_fwd_bwd", "igs_ssim_l1_loss_fwd_bwd_cached", "igs_ssim_gt_stats_bytes", "igs_depth_normal_loss_fwd_bwd", "igs_l1_loss_fwd_bwd", "igs_l1_mean_fwd_bwd", "igs_activate_fwd", "igs_activate_bwd",
+           "igs_rast_profile_enable", "igs_rast_profile_read", "igs_adam_step", "igs_adam_step_groups", "igs_adam_step_multi", "igs_adam_step_multi_dev", "igs_adam_step_multi_dev_scratch_words", "igs_densify_stats", "igs_densify_remap", "igs_refine_step", "igs_refine_loss_scratch_bytes", "igs_ssim_l1_scratch_bytes", "igs_ssim_l1_loss_fwd_bwd", "igs_ssim_l1_loss_fwd_bwd_cached", "igs_ssim_mean_fwd_bwd", "igs_ssim_gt_stats_bytes", "igs_depth_normal_loss_fwd_bwd", "igs_l1_loss_fwd_bwd", "igs_l1_mean_fwd_bwd", "igs_activate_fwd", "igs_activate_bwd",
            "igs_sh_grad_from_view_colors", "igs_adam_sh_from_view_colors", "igs_rast_last_backward_instance", "igs_rast_next_backward_options", "igs_rast_nan_report_wait", "igs_rast_nan_report_handle", "igs_rast_nan_report_wait_at", "igs_refine_step_args_size", "igs_rast_debug_poison_lds", "igs_adam_exchange_step", "igs_morton_order", "igs_morton_order_scratch_bytes", "igs_ply_to_params", "igs_params_to_ply", "igs_debug_tile_sort"]
 
 VERSION = 4       # IGS_RAST_VERSION this binding was written against (include/igs_rast.h)

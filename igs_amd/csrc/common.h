@@ -239,7 +239,7 @@ hipError_t launch_depth_normal(hipStream_t s, int W, int H, float fx, float fy, 
 struct DepthNormalJob { float fx, fy; const float *depth, *mdepth, *normal; float weight, depth_ratio; float *g_depth, *g_mdepth, *g_normal, *loss_shards; };
 hipError_t launch_ssim_l1(hipStream_t s, int W, int H, const float* pred, const float* gt, float lambda_dssim, float weight,
                           void* scratch, float* grad, bool zero_shards, float* gt_stats = nullptr, bool gt_stats_valid = false,
-                          const DepthNormalJob* dn = nullptr);
+                          const DepthNormalJob* dn = nullptr, float* ssim_mean_out = nullptr);
 
 // ---------------------------------------------------------------------------------------------
 // device helpers

@@ -206,8 +206,17 @@ typedef float SsimGradLds[3][SSIM_H][SSIM_HS];
 // `b`: the workgroup's index among the ssim_grad workgroups (XCD-band mapping, band_tile); `sm`: 22 KB of LDS
 __device__ __forceinline__ void
 ssim_grad_body(SsimGradLds& sm, const unsigned b, const SsimWin& win, int W, int H, const float* __restrict__ x, const float* __restrict__ y,
-               const float* __restrict__ maps, float c_ssim, float c_l1, float* __restrict__ grad, float* __restrict__ l1_sum)
+               const float* __restrict__ maps, float c_ssim, float c_l1, float* __restrict__ grad, float* __restrict__ l1_sum,
+               const float* __restrict__ ssim_shards = nullptr, float* __restrict__ ssim_mean_out = nullptr)
 {
+    // (workgroup 0, on the side: mean SSIM for a caller who wants the VALUE on the device -- igs_ssim_mean_fwd_bwd.  The 64 shards were
+    //  finished by ssim_stats_kernel, the launch in front of this one; fixed order of summation)
+    if (b == 0u && ssim_mean_out && threadIdx.x < 64) {
+        float v = ssim_shards[16 * threadIdx.x];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+        if (threadIdx.x == 0) ssim_mean_out[0] = v / (3.f * (float)W * (float)H);
+    }
     // (in place, as ssim_stats_kernel: the horizontally blurred row replaces columns 0..31 of the halo row it was computed from, behind
     //  one extra barrier: 22 KB of LDS per workgroup instead of 40 -- six workgroups per CU instead of three)
     unsigned bx, by, bz;
@@ -295,10 +304,11 @@ ssim_grad_body(SsimGradLds& sm, const unsigned b, const SsimWin& win, int W, int
 }
 __global__ void __launch_bounds__(256)
 ssim_grad_kernel(const SsimWin win, int W, int H, const float* __restrict__ x, const float* __restrict__ y,
-                 const float* __restrict__ maps, float c_ssim, float c_l1, float* __restrict__ grad, float* __restrict__ l1_sum)
+                 const float* __restrict__ maps, float c_ssim, float c_l1, float* __restrict__ grad, float* __restrict__ l1_sum,
+                 const float* __restrict__ ssim_shards, float* __restrict__ ssim_mean_out)
 {
     __shared__ __attribute__((aligned(16))) SsimGradLds sm;
-    ssim_grad_body(sm, blockIdx.x, win, W, H, x, y, maps, c_ssim, c_l1, grad, l1_sum);
+    ssim_grad_body(sm, blockIdx.x, win, W, H, x, y, maps, c_ssim, c_l1, grad, l1_sum, ssim_shards, ssim_mean_out);
 }
 
 // scratch = { maps [3 channels][3][H][W] | 64 SSIM-sum shards | 64 L1-sum shards } (shards 16 floats apart)
@@ -336,6 +346,17 @@ extern "C" int igs_ssim_l1_loss_fwd_bwd(void* stream, int width, int height, con
                                         float weight, void* scratch, float* grad, float* sums)
 {
     return ssim_l1_impl(stream, width, height, pred, gt, lambda_dssim, weight, scratch, grad, sums, nullptr, 0);
+}
+// mean SSIM(pred, gt) finished ON THE DEVICE (mean_out[0]) and grad = d(mean SSIM)/d pred (weight -1 of the loss 1 - mean SSIM), in the same two launches: what
+// igs_amd.losses.ssim needs -- no copy of the shards, no reduction kernel and no division behind them (three small launches per call)
+extern "C" int igs_ssim_mean_fwd_bwd(void* stream, int width, int height, const float* pred, const float* gt, void* scratch, float* grad,
+                                     float* mean_out)
+{
+    if (width <= 0 || height <= 0) return IGS_RAST_E_INVALID;
+    if (!pred || !gt || !scratch || !grad || !mean_out) return IGS_RAST_E_INVALID;
+    if (launch_ssim_l1((hipStream_t)stream, width, height, pred, gt, 1.0f, -1.0f, scratch, grad, true, nullptr, false, nullptr, mean_out) != hipSuccess)
+        return IGS_RAST_E_HIP;
+    return 0;
 }
 extern "C" int igs_ssim_l1_loss_fwd_bwd_cached(void* stream, int width, int height, const float* pred, const float* gt, float lambda_dssim,
                                                float weight, void* scratch, float* grad, float* sums, float* gt_stats, int gt_stats_valid)
@@ -501,7 +522,8 @@ static DnArgs make_dn_args(int W, int H, float fx, float fy, const float* depth,
 // `dn` (igs_refine_step with both losses): the depth-normal regulariser rides in the same launch as ssim_grad, and its loss shards are
 // zeroed by workgroup 0 of ssim_stats
 hipError_t launch_ssim_l1(hipStream_t s, int W, int H, const float* pred, const float* gt, float lambda_dssim, float weight,
-                          void* scratch, float* grad, bool zero_shards, float* gt_stats, bool gt_stats_valid, const DepthNormalJob* dn)
+                          void* scratch, float* grad, bool zero_shards, float* gt_stats, bool gt_stats_valid, const DepthNormalJob* dn,
+                          float* ssim_mean_out)
 {
     static const SsimWin win = make_window();
     float* maps = (float*)scratch;
@@ -519,7 +541,7 @@ hipError_t launch_ssim_l1(hipStream_t s, int W, int H, const float* pred, const 
     else hipLaunchKernelGGL(ssim_stats_kernel<GT_CACHED>, grid, block, 0, s, win, W, H, pred, gt, maps, shards, gt_stats, z);
     if (!dn) {
         hipLaunchKernelGGL(ssim_grad_kernel, grid, block, 0, s, win, W, H, pred, gt, maps, -lambda_dssim * weight / n,
-                           (1.f - lambda_dssim) * weight / n, grad, shards + 1024);
+                           (1.f - lambda_dssim) * weight / n, grad, shards + 1024, (const float*)shards, ssim_mean_out);
     } else {
         const DnArgs da = make_dn_args(W, H, dn->fx, dn->fy, dn->depth, dn->mdepth, dn->normal, dn->weight, dn->depth_ratio, dn->g_depth,
                                        dn->g_mdepth, dn->g_normal, dn->loss_shards);

@@ -321,8 +321,7 @@ std::tuple<Tensor, Tensor> l1_mean(const Tensor& a, const Tensor& b)
     return { out, grad };
 }
 
-// mean SSIM(a, b) over all elements and d(mean SSIM)/da in two launches (igs_ssim_l1_loss_fwd_bwd with lambda = 1: its gradient is that
-// of 1 - mean SSIM; loss_utils.py:34-63 with the 11x11 window).  a, b: [3, H, W] (or anything that reshapes to it)
+// mean SSIM(a, b) over all elements (finished on the device) and d(mean SSIM)/da in two launches (igs_ssim_mean_fwd_bwd; loss_utils.py:34-63 with the 11x11 window).  a, b: [3, H, W] (or anything that reshapes to it)
 std::tuple<Tensor, Tensor> ssim_mean(const Tensor& a, const Tensor& b)
 {
     if (!a.is_cuda() || !b.is_cuda() || a.dim() < 3 || a.numel() != b.numel()) throw RasterizerError("ssim_mean: two GPU images of the same size (no CPU fallback)");
@@ -344,11 +343,10 @@ std::tuple<Tensor, Tensor> ssim_mean(const Tensor& a, const Tensor& b)
         scratch = sc.ssim;
     }
     auto fopt = at::TensorOptions().dtype(at::kFloat).device(dev);
-    Tensor grad = at::empty_like(x.keep), sums = at::empty({2048}, fopt);
-    const int rc = igs_ssim_l1_loss_fwd_bwd(stream, (int)W, (int)H, x.p, y.p, 1.0f, 1.0f, scratch.data_ptr(), grad.data_ptr<float>(), sums.data_ptr<float>());
-    if (rc != 0) throw RasterizerError("igs_ssim_l1_loss_fwd_bwd failed: " + std::to_string(rc));
-    Tensor mean = sums.narrow(0, 0, 1024).sum() / (double)x.keep.numel();
-    return { mean, grad };               // grad = d(1 - mean SSIM)/da: the caller negates
+    Tensor grad = at::empty_like(x.keep), mean = at::empty({}, fopt);
+    const int rc = igs_ssim_mean_fwd_bwd(stream, (int)W, (int)H, x.p, y.p, scratch.data_ptr(), grad.data_ptr<float>(), mean.data_ptr<float>());
+    if (rc != 0) throw RasterizerError("igs_ssim_mean_fwd_bwd failed: " + std::to_string(rc));
+    return { mean, grad };               // grad = d(mean SSIM)/da
 }
 
 }      // namespace

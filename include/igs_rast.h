@@ -386,6 +386,11 @@ int igs_ssim_l1_loss_fwd_bwd(void* stream, int width, int height, const float* p
 size_t igs_ssim_gt_stats_bytes(int width, int height);
 int igs_ssim_l1_loss_fwd_bwd_cached(void* stream, int width, int height, const float* pred, const float* gt, float lambda_dssim, float weight,
                                     void* scratch, float* grad, float* sums, float* gt_stats, int gt_stats_valid);
+/* The SSIM term alone with its VALUE finished on the device: mean_out[0] = mean SSIM(pred, gt) over all 3 * width * height elements,
+ * grad = d(mean SSIM)/d pred; same scratch as igs_ssim_l1_loss_fwd_bwd, two launches, nothing for the host to add up
+ * (igs_amd.losses.ssim; loss_utils.py:34-63). */
+int igs_ssim_mean_fwd_bwd(void* stream, int width, int height, const float* pred, const float* gt, void* scratch, float* grad,
+                          float* mean_out);
 
 /* RaDe-GS depth-normal consistency regulariser, value and gradients in one launch
  * (submodules/RaDe-GS/utils/graphics_utils.py:97-126, train.py:143-160):
