@@ -1,5 +1,9 @@
 """Times the UNCHANGED caller loop (tools/dropin_loop.py = infer_batch.py:279-324) on the bench scene, per variant.
-usage: python tools/dropin_bench.py [steps] [variant ...]      variant = <loss>:<optimizer>:<nan 0|1>[:<losses igs|torch>[:<flags: fa (fused activations), np (no PSNR line)>]]"""
+usage: python tools/dropin_bench.py [steps] [variant ...]      variant = <loss>:<optimizer>:<nan 0|1>[:<losses igs|torch>[:<flags: fa (fused activations), np (no PSNR line)>]]
+IGS_DROPIN_MORTON=1: the Gaussians in Morton order of their positions, as bench.py's legs have them (GaussianParams.spatial_sort).
+Prints one line per variant as it finishes and a JSON list of [variant, ms] pairs at the end (bench.py runs its graph-replay legs through
+this script in a CHILD process: an invalid capture ends this ROCm's hipStreamEndCapture in a segmentation fault, not an error code, and the
+driver's one JSON line must not die with it)."""
 import json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -45,13 +49,21 @@ def main():
     variants = sys.argv[2:] or ["l1:fused:0", "l1:fused:1", "l1_ssim:fused:0", "l1:torch_fused:0", "l1:torch:0", "l1:fused:0:torch", "l1_ssim:fused:1",
                                 "l1:fused_capturable:1", "l1_ssim:fused_capturable:1", "l1:torch_capturable:1"]
     raw, cams, bg, gts = setup(dev)
+    if os.environ.get("IGS_DROPIN_MORTON") == "1":
+        from igs_amd.refine import GaussianParams
+        p = GaussianParams(raw, dev)
+        p.spatial_sort()
+        raw = {k: v.detach().clone() for k, v in p.leaves.items()}
     out = {}
+    pairs = []
     for v in variants:
         f = v.split(":")
         out[v] = round(run_variant(raw, cams, bg, gts, dev, f[0], f[1], int(f[2]), f[3] if len(f) > 3 else "igs", steps=steps,
                                    flags=f[4] if len(f) > 4 else ""), 4)
+        pairs.append([v, out[v]])
         print(v, out[v], flush=True)
     print(json.dumps(out))
+    print("PAIRS " + json.dumps(pairs), flush=True)
 
 
 if __name__ == "__main__":
